@@ -1,0 +1,287 @@
+"""Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
+
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr gram)
+Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
+expected outputs are what the reference computed); no reference source is stored.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from ref_harness import import_reference, base_config, build_reference_model  # noqa: E402
+from oracle.detweights import det_array, det_batch, det_gram  # noqa: E402
+from oracle import synth  # noqa: E402
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ----------------------------------------------------------------------------- index buffers
+def gold_index():
+    out = {}
+    for tag, size in (("224", 224), ("384", 384)):
+        cfg = base_config(vit="vit_base_patch16_%d" % size, image_size=size, vocab_size=64,
+                          max_vl_text_len=40, loss_names={"itm": 1, "mlm": 1, "ifm": 1})
+        m, _ = build_reference_model(cfg, "ufo")
+        for name in ("relative_position_index", "text_relative_position_index",
+                     "text_imag_relative_position_index", "vl_text_imag_relative_position_index"):
+            a = getattr(m, name).numpy()
+            out[f"{name}_{tag}"] = a
+            out[f"{name}_{tag}_sha256"] = np.array(sha(a))
+            print(name, tag, a.shape, a.dtype, int(a.sum()), sha(a)[:16])
+    np.savez_compressed(os.path.join(HERE, "index_buffers.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- merge (tiny)
+def fake_self(**cfg_over):
+    cfg = base_config(**cfg_over)
+    return types.SimpleNamespace(hparams=types.SimpleNamespace(config=cfg))
+
+
+def tiny_state(D=16, F=32, arch="all_moe", salt=0):
+    shapes = synth.state_shapes(D, F, arch, R=24, vocab=32, T=8, heads=2)
+    return {k: torch.from_numpy(det_array(k, s, salt)) for k, (s, dt) in shapes.items()}
+
+
+MERGE_CASES = [
+    dict(name="interp_r0.5", fn="merge_weights", cfg=dict(merge_ratio=0.5)),
+    dict(name="interp_r0.3", fn="merge_weights", cfg=dict(merge_ratio=0.3)),
+    dict(name="interp_r0.3_used_irtr", fn="merge_weights",
+         cfg=dict(merge_ratio=0.3, only_activate_used_experts=True, loss_names={"irtr": 1})),
+    dict(name="interp_r0.5_used_vqa", fn="merge_weights",
+         cfg=dict(merge_ratio=0.5, only_activate_used_experts=True, loss_names={"vqa": 1})),
+    dict(name="taskvec_l0.75", fn="sum_task_vectors", cfg=dict(sum_lambda=0.75)),
+    dict(name="taskvec_l0.4_used_irtr", fn="sum_task_vectors",
+         cfg=dict(sum_lambda=0.4, only_activate_used_experts=True, loss_names={"irtr": 1})),
+    dict(name="regmean_a1.0", fn="regmean", cfg=dict(scaling_for_non_diag=1.0, loss_names={"irtr": 1})),
+    dict(name="regmean_a0.9", fn="regmean", cfg=dict(scaling_for_non_diag=0.9, loss_names={"irtr": 1})),
+    dict(name="regmean_a0.9_pretrain", fn="regmean",
+         cfg=dict(scaling_for_non_diag=0.9, loss_names={"itm": 1, "mlm": 1, "ifm": 1})),
+    dict(name="interp_already_ufo", fn="merge_weights", cfg=dict(merge_ratio=0.5), arch="ufo"),
+]
+
+
+def gold_merge():
+    vm, _, _ = import_reference()
+    D, F = 16, 32
+    out = {}
+    tmpdir = "/tmp/vlm_golden"
+    os.makedirs(tmpdir, exist_ok=True)
+    central = tiny_state(D, F, "ufo", salt=7)
+    torch.save({"state_dict": central}, os.path.join(tmpdir, "central.ckpt"))
+    # regmean grams: v and l of every layer (vl experts never get one)
+    grams = {k: torch.from_numpy(det_gram(k, s[0])) for k, s in synth.gram_shapes(D, F).items()}
+    torch.save(grams, os.path.join(tmpdir, "grams.pth"))
+    for case in MERGE_CASES:
+        sd = tiny_state(D, F, case.get("arch", "all_moe"))
+        cfg = dict(case["cfg"])
+        cfg["central_weight"] = os.path.join(tmpdir, "central.ckpt")
+        cfg["gram_matrices"] = os.path.join(tmpdir, "grams.pth")
+        me = fake_self(**cfg)
+        res = getattr(vm.ViLTransformerSS, case["fn"])(me, sd)
+        keys = sorted(res.keys())
+        out[case["name"] + "/__keys__"] = np.array(json.dumps(keys))
+        for k in keys:
+            v = res[k]
+            if "transformer.blocks." in k and "gamma" not in k:
+                out[case["name"] + "/" + k] = v.numpy()
+        print(case["name"], len(keys), "keys;", sorted({str(v.dtype) for v in res.values()}))
+    np.savez_compressed(os.path.join(HERE, "merge_tiny.npz"), **out)
+
+
+def gold_merge_base():
+    """Full base-size all_moe -> ufo merges through the reference; only sha256 digests are kept."""
+    vm, _, _ = import_reference()
+    D, F = 768, 3072
+    shapes = synth.block_shapes(D, F, "all_moe")
+    sd = {k: torch.from_numpy(det_array(k, s)) for k, (s, dt) in shapes.items()}
+    dig = {}
+    for name, fn, cfg in (("interp_r0.5", "merge_weights", dict(merge_ratio=0.5)),
+                          ("interp_r0.3", "merge_weights", dict(merge_ratio=0.3))):
+        res = getattr(vm.ViLTransformerSS, fn)(fake_self(**cfg), sd)
+        dig[name] = {k: sha(v.numpy()) for k, v in res.items() if "gamma" not in k}
+        print(name, len(dig[name]))
+    # task vector: central = det ufo blocks with salt 7
+    cshapes = synth.block_shapes(D, F, "ufo")
+    central = {k: torch.from_numpy(det_array(k, s, 7)) for k, (s, dt) in cshapes.items()}
+    os.makedirs("/tmp/vlm_golden", exist_ok=True)
+    torch.save(central, "/tmp/vlm_golden/central_base.ckpt")
+    res = vm.ViLTransformerSS.sum_task_vectors(
+        fake_self(sum_lambda=0.75, central_weight="/tmp/vlm_golden/central_base.ckpt"), sd)
+    dig["taskvec_l0.75"] = {k: sha(v.numpy()) for k, v in res.items() if "gamma" not in k}
+    os.remove("/tmp/vlm_golden/central_base.ckpt")
+    with open(os.path.join(HERE, "merge_base_digests.json"), "w") as f:
+        json.dump(dig, f, indent=0, sort_keys=True)
+
+
+# ----------------------------------------------------------------------------- model
+def load_det_weights(model):
+    sd = model.state_dict()
+    new = {}
+    meta = {}
+    for k, v in sd.items():
+        meta[k] = (list(v.shape), str(v.dtype).replace("torch.", ""))
+        if v.is_floating_point() and "index" not in k and "mask_for" not in k:
+            new[k] = torch.from_numpy(det_array(k, v.shape))
+    model.load_state_dict(new, strict=False)
+    return meta
+
+
+def to_batch(nb):
+    b = {k: torch.from_numpy(v) for k, v in nb.items()}
+    b["image"] = [b["image"]]
+    return b
+
+
+def grads_summary(model):
+    out = {}
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            out[n] = None
+        else:
+            g = p.grad.double()
+            out[n] = [float(g.norm()), float(g.sum())]
+    return out
+
+
+def gold_model():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    vm, vit, obj = import_reference()
+    for arch in ("ufo", "all_moe"):
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_vl_text_len=40,
+                          max_text_len=40, vocab_size=1024, loss_names={"itm": 1, "mlm": 1, "ifm": 1},
+                          tasks=["vl"], drop_rate=0.1)
+        model, cfg = build_reference_model(cfg, arch)
+        meta = load_det_weights(model)
+        with open(os.path.join(HERE, f"keys_tiny_{arch}.json"), "w") as f:
+            json.dump(meta, f, indent=0, sort_keys=True)
+        model.eval()
+        nb = det_batch(2, 224, 40, 1024, seed=1234)
+        batch = to_batch(nb)
+        out = {}
+        with torch.no_grad():
+            r = model.infer(batch, mask_text=False)
+            for k in ("text_feats", "image_feats", "cls_feats", "raw_cls_feats"):
+                out["infer/" + k] = r[k].numpy()
+            r = model.infer(batch, mask_text=True)
+            out["infer_mlm/text_feats"] = r["text_feats"].numpy()
+            r = model.infer_image(batch)
+            for k in ("image_feats", "cls_feats", "cls_vlffn_feats"):
+                out["infer_image/" + k] = r[k].numpy()
+            r = model.infer_text(batch)
+            for k in ("text_feats", "cls_feats", "cls_vlffn_feats"):
+                out["infer_text/" + k] = r[k].numpy()
+            # per-op: block 0 and block 11 on a fixed hidden state
+            x = torch.from_numpy(det_array("probe.x", (2, 237, 192))) * 10
+            mask = torch.cat([batch["text_masks"], torch.ones(2, 197, dtype=torch.long)], 1)
+            bias = model.get_rel_pos_bias(model.text_imag_relative_position_index)
+            bl = torch.chunk(bias, 12, dim=0)
+            for li in (0, 11):
+                y, _ = model.transformer.blocks[li](x, mask=mask, type_id=2, relative_position_bias=bl[li])
+                out[f"block{li}/joint"] = y.numpy()
+        # one full training_step in eval mode (deterministic) + backward
+        model.zero_grad()
+        from vilt.modules import vilt_utils
+        vilt_utils.set_task(model)
+        ret = model({"vl": batch})
+        total = sum(v for k, v in ret.items() if "loss" in k)
+        total.backward()
+        for k in ("mlm_loss", "ifm_loss", "itm_loss"):
+            out["step/" + k] = np.array(float(ret[k]))
+        out["step/total_loss"] = np.array(float(total))
+        out["step/mlm_logits"] = ret["mlm_logits"].detach().numpy()
+        out["step/itm_logits"] = ret["itm_logits"].detach().numpy()
+        out["step/ifm_i2t_logits"] = ret["ifm_i2t_logits"].detach().numpy()
+        gs = grads_summary(model)
+        out["step/grad_summary"] = np.array(json.dumps(gs))
+        named = dict(model.named_parameters())
+        pick = ["relative_position_bias_table", "token_type_embeddings.weight", "transformer.cls_token",
+                "transformer.blocks.0.gamma_1", "transformer.blocks.11.gamma_2", "transformer.norm.weight",
+                "transformer.patch_embed.proj.bias", "logit_scale", "logit_vl_scale"]
+        pick += [n for n in named if n.startswith("transformer.blocks.5.") and named[n].dim() == 1]
+        for n in pick:
+            if named[n].grad is not None:
+                out["step/grad/" + n] = named[n].grad.numpy()
+        print(arch, {k: float(out["step/" + k]) for k in ("mlm_loss", "ifm_loss", "itm_loss", "total_loss")},
+              "no-grad params:", [n for n, v in gs.items() if v is None])
+        np.savez_compressed(os.path.join(HERE, f"model_tiny_{arch}.npz"), **out)
+
+
+def gold_irtr():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    vm, vit, obj = import_reference()
+    for arch in ("ufo", "all_moe"):
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_text_len=40,
+                          vocab_size=1024, loss_names={"irtr": 1}, drop_rate=0.1)
+        model, cfg = build_reference_model(cfg, arch)
+        meta = load_det_weights(model)
+        with open(os.path.join(HERE, f"keys_tiny_irtr_{arch}.json"), "w") as f:
+            json.dump(meta, f, indent=0, sort_keys=True)
+        model.eval()
+        batch = to_batch(det_batch(3, 224, 40, 1024, seed=77))
+        out = {}
+        grams = {}
+        if arch == "all_moe":
+            # the reference's gram hook (src/cache_gram_matrices.py:246-281), re-registered here because
+            # it is a closure inside main(); same module-name selection and arithmetic.
+            from collections import defaultdict
+            grams = defaultdict(float)
+            all_keys = ["mlp.fc1", "mlp.fc1", "mlp.v.fc1", "mlp.l.fc1", "mlp.vl.fc1", "mlp.v.fc2", "mlp.l.fc2",
+                        "mlp.vl.fc2", "attn", "attn.v", "attn.l", "attn.vl", "attn.proj", "attn.v.proj",
+                        "attn.l.proj", "attn.vl.proj"]
+
+            def hook_gram_input(module, input, output):
+                if isinstance(input, tuple):
+                    input = input[0]
+                fl = input.reshape(-1, input.shape[-1]).to(torch.float64)
+                grams[module.module_name] += torch.matmul(fl.T, fl).detach().cpu()
+
+            for name, module in model.named_modules():
+                if any(name.endswith(n) for n in all_keys) and ".bias" not in name:
+                    module.module_name = name
+                    module.register_forward_hook(hook_gram_input)
+        from vilt.modules import vilt_utils
+        vilt_utils.set_task(model)
+        model.zero_grad()
+        ret = model(batch)
+        ret["irtr_loss"].backward()
+        out["irtr_loss"] = np.array(float(ret["irtr_loss"]))
+        out["irtr_i2t_logits"] = ret["irtr_i2t_logits"].detach().numpy()
+        out["grad_summary"] = np.array(json.dumps(grads_summary(model)))
+        print(arch, "irtr loss", float(ret["irtr_loss"]), "grams:", len(grams))
+        if grams:
+            gk = sorted(grams.keys())
+            out["gram_keys"] = np.array(json.dumps(gk))
+            out["gram_summary"] = np.array(json.dumps(
+                {k: [list(grams[k].shape), float(grams[k].norm()), float(grams[k].sum())] for k in gk}))
+            for k in ("transformer.blocks.0.attn.v", "transformer.blocks.3.attn.l.proj",
+                      "transformer.blocks.7.mlp.v.fc1", "transformer.blocks.11.mlp.l.fc2"):
+                out["gram/" + k] = grams[k].numpy()[:192, :192]  # fc2's [768,768]: leading block only
+        np.savez_compressed(os.path.join(HERE, f"irtr_tiny_{arch}.npz"), **out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["index", "merge", "merge_base", "model", "irtr"]
+    torch.manual_seed(0)
+    for w in what:
+        {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
+         "irtr": gold_irtr}[w]()

@@ -1,0 +1,81 @@
+"""ctypes binding of libvlm_hip.so (the C ABI in include/vlm_hip.h).  Fails loudly when absent."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvlm_hip.so")
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+c_u64 = ctypes.c_uint64
+
+MERGE_LERP, MERGE_TASKVEC, MERGE_MEAN = 0, 1, 2
+MERGE_MAX_SRC = 4
+
+
+class MergeJob(ctypes.Structure):
+    _fields_ = [
+        ("dst", c_void_p),
+        ("base", c_void_p),
+        ("src", c_void_p * MERGE_MAX_SRC),
+        ("ratio", c_float * MERGE_MAX_SRC),
+        ("n_src", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
+        ("n_elem", c_u64),
+    ]
+
+
+class VlmError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "VLM_ERR_ARG", -2: "VLM_ERR_LAUNCH", -3: "VLM_ERR_WORKSPACE", -4: "VLM_ERR_UNSUPPORTED"}
+
+# name -> (restype, argtypes); every symbol include/vlm_hip.h declares
+SIGNATURES = {
+    "vlm_abi_version": (c_int, []),
+    "vlm_device_cus": (c_int, []),
+    "vlm_merge_plan_bytes": (c_size_t, [c_int, c_u64]),
+    "vlm_merge_plan_upload": (c_int, [ctypes.POINTER(MergeJob), c_int, c_void_p, c_size_t, c_void_p]),
+    "vlm_merge_run": (c_int, [c_void_p, c_void_p]),
+}
+
+
+def get_lib():
+    """Load the HIP library.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VlmError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VlmError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VlmError("vl_merging_amd ops run on the GPU only (tensor on %s); there is no CPU path" % t.device)
