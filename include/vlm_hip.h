@@ -67,6 +67,81 @@ int vlm_merge_plan_upload(const vlm_merge_job_t* jobs_host, int n_jobs, void* wo
 /* Run an uploaded plan: ONE kernel launch over all jobs. */
 int vlm_merge_run(const void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogue (K1/K6/K8/K9/K10): replaces F.linear at
+ * modules/vision_transformer.py:335 (qkv + cat(q_bias,0,v_bias)), :360 (proj), :291/:295 (fc1/fc2),
+ * LayerScale + residual at :586/:603 (x + drop_path(gamma * branch)), heads.py:14,27,36,49, and the
+ * autograd backward of each (dgrad / wgrad).
+ *   C[M,N] = epilogue( op(A)[M,K] . op(B)[K,N] ),   fp32 accumulation
+ *   ta=0: A is [M][K] (K contiguous)   ta=1: A is [K][M]
+ *   tb=0: B is [N][K] (nn.Linear weight layout)   tb=1: B is [K][N]
+ *   v   = alpha*acc + bias[n]
+ *   act = NONE/GELU : if aux != NULL, aux[m,n] = bf16(v) (pre-activation / pre-LayerScale branch output)
+ *         GELU      : v = gelu_erf(v)               (vision_transformer.py:292, exact erf GELU)
+ *         GELU_BWD  : v = v * gelu_erf'(aux[m,n])   (aux is an INPUT: the saved pre-activation)
+ *   out = residual[m,n] + row_scale[m] * col_scale[n] * v     (each factor optional)
+ *   C   = out  (bf16 or f32)  or  C += out (f32, accumulate != 0)
+ * Requirements: lda, ldb multiples of 8; ldc, ld_aux, ld_res multiples of 4; 16-B aligned bases; K % 64 == 0
+ * unless both operands are K-strided (ta=1 and tb=1).  Ragged M and N are handled in hardware.
+ */
+#define VLM_ACT_NONE 0
+#define VLM_ACT_GELU 1
+#define VLM_ACT_GELU_BWD 2
+
+typedef struct {
+  const float* bias;       /* f32 [N] or NULL */
+  const float* col_scale;  /* f32 [N] or NULL (LayerScale gamma) */
+  const float* row_scale;  /* f32 [M] or NULL (DropPath keep-mask / keep_prob per row) */
+  const float* residual;   /* f32 [M, ld_res] or NULL */
+  int64_t ld_res;
+  void* aux;               /* bf16 [M, ld_aux] or NULL */
+  int64_t ld_aux;
+  int32_t act;
+  float alpha;
+  int32_t accumulate;
+  int32_t reserved;
+} vlm_epilogue_t;
+
+int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                  int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise kernels (K5 + LayerScale backward + bias gradients).  D % 4 == 0, D <= 1024.
+ * LayerNorm: nn.LayerNorm(eps=1e-6) modules/vision_transformer.py:831, Block.apply_ln :495-523 (a
+ * modality-specific LayerNorm is one call per contiguous row range in the segment-major layout);
+ * eps=1e-12 for BertEmbeddings / the MLM transform (modules/vilt_module.py:63, heads.py:43).
+ *   fwd: y = (x-mean)*rstd*gamma+beta (bf16 or f32), stats[m] = {mean, rstd} (may be NULL)
+ *   bwd: dx = dLN/dx (+ dres if given: the residual-path gradient, fused add); dgamma/dbeta are
+ *        ACCUMULATED (atomicAdd) so grads of a weight shared by several passes add up in place.
+ */
+int vlm_layernorm_fwd(const float* x, int ldx, int M, int D, const float* gamma, const float* beta, float eps,
+                      void* y, int ldy, int y_is_f32, float* stats, void* stream);
+int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx, const float* stats,
+                      const float* gamma, int M, int D, const float* dres, int lddres, float* dx, int lddx,
+                      float* dgamma, float* dbeta, void* stream);
+/* Backward of x_new = x + row_scale[m]*gamma[n]*y[m,n] (vision_transformer.py:586,:603) w.r.t. the branch:
+ *   dy = bf16(row_scale*gamma*dx); dgamma[n] += sum_m row_scale*dx*y; dbias[n] += sum_m dy. */
+int vlm_layerscale_bwd(const float* dx, int lddx, const void* y_bf16, int ldy, const float* gamma,
+                       const float* row_scale, int M, int D, void* dy_bf16, int lddy, float* dgamma, float* dbias,
+                       void* stream);
+/* out[n] += sum_m a[m,n] (bf16 a; N % 8 == 0): bias gradients of qkv / fc1 / heads. */
+int vlm_colsum_bf16(const void* a, int lda, int M, int N, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat-buffer elementwise kernels.
+ * vlm_adamw_step: transformers-4.x AdamW as instantiated at modules/vilt_utils.py:314-317
+ *   (betas=(0.9, beta_2), eps=1e-8, bias-corrected step_size computed by the caller, decoupled decay applied
+ *   AFTER the Adam update); also writes the bf16 shadow of the parameters (GEMM operand) and may zero the grad.
+ * vlm_patch_im2col: front end of PatchEmbed (vision_transformer.py:714-728): NCHW fp32 image -> bf16 patch rows
+ *   [B*(lead_rows + patches), 3*P*P] (column = c*P*P + i*P + j); lead_rows zero rows per image hold the place of
+ *   the cls token (:974-975).
+ */
+int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float step_size, float grad_scale, int zero_grad,
+                   void* stream);
+int vlm_cast_f32_bf16(const float* src, void* dst_bf16, uint64_t n, void* stream);
+int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W, int P, int lead_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

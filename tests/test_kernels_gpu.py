@@ -1,0 +1,230 @@
+"""HIP kernels (through the C ABI) vs plain PyTorch fp32 references of the same op on the same inputs.
+
+Tolerances: inputs are bf16-exact (the references see the same bf16-rounded values in fp32), accumulation is
+fp32, so the only differences are summation order and the final rounding of a bf16 output:
+  f32 outputs : atol 2e-3 * scale, rtol 1e-3      bf16 outputs: rtol 2^-7 (one bf16 ulp) on top.
+"""
+import importlib
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    return importlib.import_module("vl_merging_amd.ops")
+
+
+@pytest.fixture(scope="module")
+def L(pkg):
+    return importlib.import_module("vl_merging_amd._lib")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def assert_close(got, ref, rtol, atol, what=""):
+    got = got.float()
+    ref = ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d bad, max err %.4g (ref max %.4g)" % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), float(ref.abs().max()))
+
+
+def make_ab(M, N, K, ta, tb, gen):
+    # integer-valued asymmetric data first (exact in bf16 and in fp32 accumulation) then random
+    a = torch.randn(M, K, device="cuda", generator=gen)
+    b = torch.randn(N, K, device="cuda", generator=gen)
+    A = bf(a.t().contiguous() if ta else a)
+    B = bf(b.t().contiguous() if tb else b)
+    a32 = (A.float().t() if ta else A.float())
+    b32 = (B.float().t() if tb else B.float())
+    return A, B, a32 @ b32.t()
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (880, 768, 768), (577 * 3, 2304, 768), (333, 3072, 768),
+                                   (130, 72, 128), (1, 8, 64), (2, 2, 768)])
+def test_gemm_layouts(ops, ta, tb, M, N, K):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M * 7 + N * 3 + K)
+    A, B, ref = make_ab(M, N, K, ta, tb, gen)
+    if (ta and (M % 8)) or (tb and (N % 8)):
+        pytest.skip("leading dimension of a K-strided operand must be a multiple of 8")
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm(A, B, out, ta, tb)
+    assert_close(out, ref, 1e-3, 2e-3 * math.sqrt(K), "gemm f32")
+    outb = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, outb, ta, tb)
+    assert_close(outb, ref, 1e-2, 2e-3 * math.sqrt(K), "gemm bf16")
+
+
+def test_gemm_exact_integers_asymmetric(ops):
+    """A = I-like / small integers with an ASYMMETRIC B: catches row/col swaps and k-order permutations."""
+    M, N, K = 256, 256, 128
+    a = torch.zeros(M, K, device="cuda")
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    a[:, 0] += (torch.arange(M, device="cuda") % 3).float()
+    b = (torch.arange(N, device="cuda").view(N, 1) * 2 + torch.arange(K, device="cuda").view(1, K) * 5) % 17
+    b = b.float() - 8
+    for ta in (False, True):
+        for tb in (False, True):
+            A = bf(a.t().contiguous() if ta else a)
+            B = bf(b.t().contiguous() if tb else b)
+            out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+            ops.gemm(A, B, out, ta, tb)
+            assert torch.equal(out, a @ b.t()), (ta, tb)
+
+
+def test_gemm_kstrided_ragged_k(ops):
+    """wgrad shape: reduction over tokens (K = 1357, not a multiple of 64), both operands K-strided."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    K, M, N = 1357, 768, 384
+    dy = bf(torch.randn(K, M, device="cuda", generator=gen))
+    x = bf(torch.randn(K, N, device="cuda", generator=gen))
+    ref = dy.float().t() @ x.float()
+    out = torch.full((M, N), 1.0, device="cuda")
+    ops.gemm(dy, x, out, True, True, accumulate=True)
+    assert_close(out, ref + 1.0, 1e-3, 2e-3 * math.sqrt(K), "wgrad accumulate")
+    # a row-range view of a taller matrix: rows beyond the range must not leak in
+    big = bf(torch.randn(K + 300, M, device="cuda", generator=gen))
+    bigx = bf(torch.randn(K + 300, N, device="cuda", generator=gen))
+    out2 = torch.empty(M, N, device="cuda")
+    ops.gemm(big[100:100 + K], bigx[100:100 + K], out2, True, True)
+    assert_close(out2, big[100:100 + K].float().t() @ bigx[100:100 + K].float(), 1e-3, 2e-3 * math.sqrt(K), "range")
+
+
+def test_gemm_epilogues(ops, L):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    M, N, K = 617 * 2, 768, 768
+    A, B, acc = make_ab(M, N, K, False, False, gen)
+    acc = acc * 0.05
+    bias = torch.randn(N, device="cuda", generator=gen)
+    gamma = torch.randn(N, device="cuda", generator=gen) * 0.1
+    rs = (torch.rand(M, device="cuda", generator=gen) > 0.2).float() / 0.8
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    # proj / fc2 epilogue: residual + rs*gamma*(acc+bias), aux = bf16(acc+bias)
+    out = torch.empty(M, N, device="cuda")
+    aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, out, bias=bias, col_scale=gamma, row_scale=rs, residual=res, aux=aux, alpha=0.05)
+    y = acc + bias
+    assert_close(aux, y, 1e-2, 1e-2, "aux")
+    assert_close(out, res + rs[:, None] * gamma[None] * y, 1e-3, 5e-3, "layerscale epilogue")
+    # fc1 epilogue: gelu(acc+bias) in bf16, preact saved
+    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    a = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, a, bias=bias, act=L.ACT_GELU, aux=h, alpha=0.05)
+    assert_close(h, y, 1e-2, 1e-2, "preact")
+    assert_close(a, torch.nn.functional.gelu(y), 1e-2, 1e-2, "gelu")
+    # dgrad with GELU backward: (acc) * gelu'(h)
+    d = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, d, act=L.ACT_GELU_BWD, aux=h, alpha=0.05)
+    hh = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward(acc)
+    assert_close(d, hh.grad, 1e-2, 1e-2, "gelu bwd")
+
+
+def test_gemm_vocab_ragged_n(ops):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    M, N, K, NP = 80, 30522, 768, 30528
+    x = bf(torch.randn(M, K, device="cuda", generator=gen))
+    w = bf(torch.randn(N, K, device="cuda", generator=gen) * 0.05)
+    bias = torch.randn(N, device="cuda", generator=gen)
+    buf = torch.zeros(M, NP, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, w, buf[:, :N], bias=bias)
+    assert_close(buf[:, :N], x.float() @ w.float().t() + bias, 1e-2, 2e-2, "vocab logits")
+    assert float(buf[:, N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,D", [(1, 192), (37, 192), (880, 768), (12694, 768), (5, 1024)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_layernorm(ops, M, D, out_f32):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + D)
+    x = torch.randn(M, D, device="cuda", generator=gen) * 3 + 0.5
+    g = 1 + 0.1 * torch.randn(D, device="cuda", generator=gen)
+    b = 0.1 * torch.randn(D, device="cuda", generator=gen)
+    y = torch.empty(M, D, device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+    stats = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, g, b, 1e-6, y, stats)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    assert_close(y, ref, 1e-2 if not out_f32 else 1e-5, 1e-2 if not out_f32 else 1e-5, "ln fwd")
+    dy = torch.randn(M, D, device="cuda", generator=gen)
+    dres = torch.randn(M, D, device="cuda", generator=gen)
+    dyq = dy if out_f32 else bf(dy)
+    ref.backward(dyq.float())
+    dx = torch.empty(M, D, device="cuda")
+    dg = torch.zeros(D, device="cuda")
+    db = torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dyq, x, stats, g, dx, dres=dres, dgamma=dg, dbeta=db)
+    assert_close(dx, xr.grad + dres, 1e-4, 1e-4, "ln dx")
+    assert_close(dg, gr.grad, 1e-4, 1e-3 * math.sqrt(M), "ln dgamma")
+    assert_close(db, br.grad, 1e-4, 1e-3 * math.sqrt(M), "ln dbeta")
+
+
+def test_layerscale_bwd_and_colsum(ops):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    M, D = 1234, 768
+    dx = torch.randn(M, D, device="cuda", generator=gen)
+    y = bf(torch.randn(M, D, device="cuda", generator=gen))
+    gamma = torch.randn(D, device="cuda", generator=gen) * 0.1
+    rs = (torch.rand(M, device="cuda", generator=gen) > 0.3).float() / 0.7
+    dy = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    dg = torch.zeros(D, device="cuda"); dbias = torch.zeros(D, device="cuda")
+    ops.layerscale_bwd(dx, y, gamma, rs, dy, dg, dbias)
+    ref_dy = rs[:, None] * gamma[None] * dx
+    assert_close(dy, ref_dy, 1e-2, 1e-4, "dy")
+    assert_close(dg, (rs[:, None] * dx * y.float()).sum(0), 1e-4, 1e-2, "dgamma")
+    assert_close(dbias, dy.float().sum(0), 1e-4, 1e-3, "dbias")
+    a = bf(torch.randn(777, 2304, device="cuda", generator=gen))
+    out = torch.ones(2304, device="cuda")
+    ops.colsum(a, out)
+    assert_close(out, a.float().sum(0) + 1, 1e-4, 1e-3, "colsum")
+    out2 = torch.zeros(768, device="cuda")
+    ops.colsum(a[:, 1536:], out2)
+    assert_close(out2, a[:, 1536:].float().sum(0), 1e-4, 1e-3, "colsum slice")
+
+
+def test_adamw_matches_hf4_rule(ops):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    n = 4096 * 3 + 4
+    p = torch.randn(n, device="cuda", generator=gen); g = torch.randn(n, device="cuda", generator=gen)
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    pb = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    pr, mr, vr = p.double().clone(), m.double().clone(), v.double().clone()
+    lr, b1, b2, eps, wd = 2e-4, 0.9, 0.98, 1e-8, 0.01
+    for step in (1, 2, 3):
+        gg = g * (1.0 + 0.1 * step)
+        ops.adamw_step(p, gg.clone(), m, v, pb, lr, b1, b2, eps, wd, step, grad_scale=0.5, zero_grad=False)
+        gd = gg.double() * 0.5
+        mr = b1 * mr + (1 - b1) * gd
+        vr = b2 * vr + (1 - b2) * gd * gd
+        ss = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        pr = pr - ss * mr / (vr.sqrt() + eps)
+        pr = pr - lr * wd * pr
+    assert_close(p, pr.float(), 1e-5, 1e-6, "adamw p")
+    assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def test_im2col_matches_conv(ops):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4)
+    B, H, P, D = 3, 64, 16, 64
+    img = torch.rand(B, 3, H, H, device="cuda", generator=gen) * 2 - 1
+    w = torch.randn(D, 3, P, P, device="cuda", generator=gen) * 0.05
+    bias = torch.randn(D, device="cuda", generator=gen)
+    np_ = (H // P) ** 2
+    patches = torch.empty(B * (np_ + 1), 3 * P * P, device="cuda", dtype=torch.bfloat16)
+    ops.patch_im2col(img, patches, P, 1)
+    out = torch.empty(B * (np_ + 1), D, device="cuda")
+    ops.gemm(patches, bf(w.view(D, -1)), out, bias=bias)
+    ref = torch.nn.functional.conv2d(bf(img).float(), bf(w).float(), bias, stride=P).flatten(2).transpose(1, 2)
+    got = out.view(B, np_ + 1, D)
+    assert_close(got[:, 1:], ref, 1e-3, 2e-3, "patch embed")
+    assert_close(got[:, 0], bias.expand(B, D), 0, 0, "lead row = bias")

@@ -28,6 +28,17 @@ class MergeJob(ctypes.Structure):
     ]
 
 
+class Epilogue(ctypes.Structure):
+    _fields_ = [
+        ("bias", c_void_p), ("col_scale", c_void_p), ("row_scale", c_void_p), ("residual", c_void_p),
+        ("ld_res", ctypes.c_int64), ("aux", c_void_p), ("ld_aux", ctypes.c_int64), ("act", ctypes.c_int32),
+        ("alpha", c_float), ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+
+
 class VlmError(RuntimeError):
     pass
 
@@ -41,6 +52,19 @@ SIGNATURES = {
     "vlm_merge_plan_bytes": (c_size_t, [c_int, c_u64]),
     "vlm_merge_plan_upload": (c_int, [ctypes.POINTER(MergeJob), c_int, c_void_p, c_size_t, c_void_p]),
     "vlm_merge_run": (c_int, [c_void_p, c_void_p]),
+    "vlm_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                              c_int, ctypes.POINTER(Epilogue), c_void_p]),
+    "vlm_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
+                                  c_void_p, c_void_p]),
+    "vlm_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                  c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_layerscale_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
+    "vlm_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_float, c_float, c_float,
+                               c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
+    "vlm_patch_im2col": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 
@@ -52,6 +76,7 @@ def get_lib():
             raise VlmError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+        import torch  # noqa: F401  -- torch's bundled HIP runtime must be the one libvlm_hip.so binds to
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

@@ -1,0 +1,129 @@
+// Flat-buffer elementwise kernels: fused AdamW step (K16), fp32 -> bf16 shadow cast, patch im2col (K1 front end).
+// All HBM-bound; 16-B vector accesses, grid-stride over float4 granules.
+#include "vlm_common.h"
+
+#define EW_THREADS 256
+
+static int ew_grid(size_t n_vec) {
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  size_t want = (n_vec + EW_THREADS - 1) / EW_THREADS;
+  size_t cap = (size_t)cus * 8;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+// HuggingFace-transformers-4.x AdamW (reference vilt_utils.py:314-317 instantiates it; its source is not in
+// /root/reference: "parity unpinned", restated from the published rule):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step_size * m / (sqrt(v) + eps) ; then p -= lr*wd*p
+// with step_size = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host.  grad_scale folds the DDP 1/world average.
+__global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v,
+                                                           bf16_t* __restrict__ pb, size_t n4, float lr, float b1,
+                                                           float b2, float eps, float wd, float step_size,
+                                                           float grad_scale, int zero_grad) {
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * EW_THREADS) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 gg = reinterpret_cast<f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gr = gg[r] * grad_scale;
+      mm[r] = b1 * mm[r] + (1.0f - b1) * gr;
+      vv[r] = b2 * vv[r] + (1.0f - b2) * gr * gr;
+      const float denom = sqrtf(vv[r]) + eps;
+      float x = pp[r] - step_size * (mm[r] / denom);
+      if (wd != 0.0f) x = x - lr * wd * x;
+      pp[r] = x;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pb) {
+      bf16x4 h = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};
+      reinterpret_cast<bf16x4*>(pb)[i] = h;
+    }
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                          size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * EW_THREADS) {
+    const f32x4 s = reinterpret_cast<const f32x4*>(src)[i];
+    bf16x4 h = {(bf16_t)s[0], (bf16_t)s[1], (bf16_t)s[2], (bf16_t)s[3]};
+    reinterpret_cast<bf16x4*>(dst)[i] = h;
+  }
+}
+
+// image [B,3,H,W] fp32 (NCHW) -> patch matrix bf16 [B*rows_per_img, 3*P*P], column = c*P*P + i*P + j
+// (the flattening of nn.Conv2d(3, D, k=P, s=P).weight, vision_transformer.py:714-728).  rows_per_img = lead +
+// (H/P)*(W/P): `lead` zero rows in front of every image leave room for the cls token so that the GEMM output
+// already has the [B, 1+patches, D] row layout of visual_embed (:974-975).
+__global__ __launch_bounds__(EW_THREADS) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
+                                                            int B, int H, int W, int P, int lead) {
+  const int gh = H / P, gw = W / P;
+  const int K = 3 * P * P;
+  const int k8 = K / 8;
+  const int rows = lead + gh * gw;
+  const size_t total = (size_t)B * rows * k8;
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_THREADS) {
+    const int kk = (int)(i % k8) * 8;
+    const size_t rr = i / k8;
+    const int r = (int)(rr % rows);
+    const int b = (int)(rr / rows);
+    bf16x8 h;
+    if (r < lead) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (bf16_t)0.0f;
+    } else {
+      const int pidx = r - lead;
+      const int py = pidx / gw, px = pidx % gw;
+      const int c = kk / (P * P), ij = kk % (P * P);
+      const int ii = ij / P, jj = ij % P;  // jj multiple of 8 (P % 8 == 0)
+      const float* s = img + (((size_t)b * 3 + c) * H + (py * P + ii)) * W + px * P + jj;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+      const f32x4 c2 = *reinterpret_cast<const f32x4*>(s + 4);
+      h = (bf16x8){(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3],
+                   (bf16_t)c2[0], (bf16_t)c2[1], (bf16_t)c2[2], (bf16_t)c2[3]};
+    }
+    *reinterpret_cast<bf16x8*>(out + rr * K + kk) = h;
+  }
+}
+
+extern "C" int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float step_size,
+                              float grad_scale, int zero_grad, void* stream) {
+  if (n == 0) return VLM_OK;
+  if (!p || !g || !m || !v || (n & 3)) return VLM_ERR_ARG;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return VLM_ERR_ARG;
+  if (p_bf16 && ((uintptr_t)p_bf16 & 7)) return VLM_ERR_ARG;
+  const size_t n4 = n >> 2;
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, g, m, v,
+                     (bf16_t*)p_bf16, n4, lr, beta1, beta2, eps, weight_decay, step_size, grad_scale, zero_grad);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_cast_f32_bf16(const float* src, void* dst, uint64_t n, void* stream) {
+  if (n == 0) return VLM_OK;
+  if (!src || !dst || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return VLM_ERR_ARG;
+  const size_t n4 = n >> 2;
+  hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_patch_im2col(const float* image, void* patches, int B, int H, int W, int P, int lead_rows,
+                                void* stream) {
+  if (B == 0) return VLM_OK;
+  if (!image || !patches || B < 0 || P <= 0 || (P & 7) || (H % P) || (W % P) || (W & 3) || lead_rows < 0)
+    return VLM_ERR_ARG;
+  if (((uintptr_t)image & 15) || ((uintptr_t)patches & 15)) return VLM_ERR_ARG;
+  const size_t total = (size_t)B * (lead_rows + (H / P) * (W / P)) * (3 * P * P / 8);
+  hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, image,
+                     (bf16_t*)patches, B, H, W, P, lead_rows);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}

@@ -1,0 +1,323 @@
+// bf16 MFMA GEMM with fused epilogues for the VLMo block (K1/K6/K8/K9/K10 of SURVEY.md 2.3).
+//
+//   C[M,N] = epilogue( op(A)[M,K] . op(B)[K,N] )        fp32 accumulate on v_mfma_f32_16x16x32_bf16
+//
+// Replaces F.linear / nn.Linear at reference vision_transformer.py:335 (qkv), :360 (proj), :291-295 (fc1/fc2),
+// heads.py (pooler / itm / ifm / mlm decoder) and their autograd backward GEMMs.
+//   ta = 0 : A stored [M][K] (K contiguous)           ta = 1 : A stored [K][M] (M contiguous)
+//   tb = 0 : B stored [N][K] (nn.Linear weight, K contiguous)   tb = 1 : B stored [K][N]
+//   forward   y  = x W^T        : ta=0 tb=0
+//   dgrad     dx = dy W         : ta=0 tb=1   (reduction over W's rows)
+//   wgrad     dW = dy^T x       : ta=1 tb=1   (reduction over tokens; fp32 out, accumulate)
+//
+// Tiling (gfx950): 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
+// Operands are staged global -> VGPR -> LDS (buffer_load_dwordx4 with hardware bounds check = free zero fill of
+// ragged M/N/K tails), double-buffered in LDS (2 x 32 KiB), next tile's loads issued before the current tile's
+// MFMAs (async-stage split).  K-contiguous operands live in LDS as [128][64] with a 16-B-chunk XOR swizzle
+// (chunk ^= row & 7) and are read with ds_read_b128; K-strided operands live as [64][128] with a 32-B-chunk XOR
+// swizzle and are read transposed with ds_read_b64_tr_b16, so no operand is ever transposed in memory.
+// The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that each lane ends
+// up with 4 CONSECUTIVE output columns of one row: the epilogue then moves 16-B (fp32) / 8-B (bf16) vectors.
+#include "vlm_common.h"
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_THREADS 256
+#define GEMM_TILE_BYTES (GEMM_BM * GEMM_BK * 2)  // 16 KiB per operand per stage
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- global -> register staging -----------------------------------------------------------------------------
+// K-contiguous operand: tile [128 rows][64 k]; piece p = tid + 256 u : row = p >> 3, chunk = p & 7
+// K-strided   operand: tile [64 k][128 x];    piece p = tid + 256 u : krow = p >> 4, c16 = p & 15
+template <bool KSTRIDED>
+__device__ __forceinline__ void stage_load(u32x4 (&r)[4], __amdgpu_buffer_rsrc_t rsrc, uint32_t row0, uint32_t k0,
+                                           uint32_t ld, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t p = tid + 256 * u;
+    uint32_t off;
+    if (!KSTRIDED) {
+      const uint32_t row = p >> 3, chunk = p & 7;
+      off = ((row0 + row) * ld + k0 + chunk * 8) * 2;
+    } else {
+      const uint32_t krow = p >> 4, c16 = p & 15;
+      off = ((k0 + krow) * ld + row0 + c16 * 8) * 2;
+    }
+    r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+  }
+}
+
+template <bool KSTRIDED>
+__device__ __forceinline__ void stage_store(const u32x4 (&r)[4], unsigned char* lds, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t p = tid + 256 * u;
+    uint32_t byte;
+    if (!KSTRIDED) {
+      const uint32_t row = p >> 3, chunk = p & 7;
+      byte = row * 128 + ((chunk ^ (row & 7)) << 4);
+    } else {
+      const uint32_t krow = p >> 4, c16 = p & 15;
+      const uint32_t c32 = (c16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
+      byte = krow * 256 + c32 * 32 + (c16 & 1) * 16;
+    }
+    *reinterpret_cast<u32x4*>(lds + byte) = r[u];
+  }
+}
+
+// ---- LDS -> MFMA fragment: 16 rows (x) x 32 k, lane l holds row (l&15), k = 8*(l>>4) + j ---------------------
+template <bool KSTRIDED>
+__device__ __forceinline__ bf16x8 frag_load(const unsigned char* lds, int xblk /*16-row block in tile*/, int ksub,
+                                            int lane) {
+  if (!KSTRIDED) {
+    const uint32_t row = xblk * 16 + (lane & 15);
+    const uint32_t chunk = ksub * 4 + (lane >> 4);
+    const uint32_t byte = row * 128 + ((chunk ^ (row & 7)) << 4);
+    return *reinterpret_cast<const bf16x8*>(lds + byte);
+  } else {
+    const uint32_t g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const uint32_t row = ksub * 32 + 8 * g + q;
+    const uint32_t c32 = ((uint32_t)xblk ^ q ^ ((g & 1) << 2));
+    const uint32_t byte = row * 256 + c32 * 32 + 8 * p;
+    // rows +0..3 -> elements 0..3, rows +4..7 -> elements 4..7 (row+4 keeps row&3 and (row>>3)&1)
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + byte));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + byte + 4 * 256));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+struct gemm_params_t {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  vlm_epilogue_t epi;
+  int tiles_m, tiles_n;
+};
+
+template <bool TA, bool TB, bool OUT_F32>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_params_t p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64x64 each
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
+  // run of tiles with n fastest so a 128-row A panel is reused out of that XCD's L2 (bijective for any grid).
+  const uint32_t nblk = gridDim.x;
+  const uint32_t bid = blockIdx.x;
+  const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const uint32_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const uint32_t m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+  // buffer descriptors: byte extent = rows * ld * 2 so that ragged row tails read as zero
+  const uint64_t a_rows = TA ? (uint64_t)p.K : (uint64_t)p.M;
+  const uint64_t b_rows = TB ? (uint64_t)p.K : (uint64_t)p.N;
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(a_rows * p.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)(b_rows * p.ldb * 2), 0x00020000);
+
+  // stage s: A at smem + s*32 KiB, B 16 KiB after it
+#define LDS_A(s) (smem + (s) * 2 * GEMM_TILE_BYTES)
+#define LDS_B(s) (smem + (s) * 2 * GEMM_TILE_BYTES + GEMM_TILE_BYTES)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 sa[4], sb[4];
+  const int nk = (p.K + GEMM_BK - 1) / GEMM_BK;
+  stage_load<TA>(sa, ra, m0, 0, p.lda, tid);
+  stage_load<TB>(sb, rb, n0, 0, p.ldb, tid);
+  stage_store<TA>(sa, LDS_A(0), tid);
+  stage_store<TB>(sb, LDS_B(0), tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {  // issue next tile's global loads before this tile's MFMAs
+      stage_load<TA>(sa, ra, m0, (kt + 1) * GEMM_BK, p.lda, tid);
+      stage_load<TB>(sb, rb, n0, (kt + 1) * GEMM_BK, p.ldb, tid);
+    }
+    const unsigned char* la = LDS_A(cur);
+    const unsigned char* lb = LDS_B(cur);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag_load<TA>(la, wm * 4 + i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag_load<TB>(lb, wn * 4 + j, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // swapped: MFMA-A = weight rows (n), MFMA-B = activation rows (m) => D[n_local][m_local]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      stage_store<TA>(sa, LDS_A(cur ^ 1), tid);
+      stage_store<TB>(sb, LDS_B(cur ^ 1), tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds rows m = ..+(lane&15), columns n = ..+(lane>>4)*4 + r ------------------------------
+  const vlm_epilogue_t& e = p.epi;
+  const bool n_vec_ok = ((p.N & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const float rs = e.row_scale ? e.row_scale[m] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+      const bool full = n_vec_ok || (n + 3 < p.N);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha;
+      if (full) {
+        if (e.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += b[r];
+        }
+        if (e.act == VLM_ACT_GELU_BWD) {
+          const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)h[r]);
+        } else {
+          if (e.aux) {
+            bf16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n) = h;
+          }
+          if (e.act == VLM_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          }
+        }
+        if (e.col_scale) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(e.col_scale + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= g[r];
+        }
+        if (e.row_scale) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= rs;
+        }
+        if (e.residual) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(e.residual + (size_t)m * e.ld_res + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += x[r];
+        }
+        if (OUT_F32) {
+          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          if (e.accumulate) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(c);
+            o += old;
+          }
+          *reinterpret_cast<f32x4*>(c) = o;
+        } else {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = o;
+        }
+      } else {  // ragged N tail: scalar path
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+          float x = v[r];
+          if (e.bias) x += e.bias[n + r];
+          if (e.act == VLM_ACT_GELU_BWD) {
+            x *= gelu_erf_grad((float)reinterpret_cast<const bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r]);
+          } else {
+            if (e.aux) reinterpret_cast<bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r] = (bf16_t)x;
+            if (e.act == VLM_ACT_GELU) x = gelu_erf(x);
+          }
+          if (e.col_scale) x *= e.col_scale[n + r];
+          if (e.row_scale) x *= rs;
+          if (e.residual) x += e.residual[(size_t)m * e.ld_res + n + r];
+          if (OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n + r;
+            *c = e.accumulate ? (*c + x) : x;
+          } else {
+            reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n + r] = (bf16_t)x;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB, bool OUT_F32>
+static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
+  const size_t smem = 4 * GEMM_TILE_BYTES;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_kernel<TA, TB, OUT_F32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return VLM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
+  hipLaunchKernelGGL((vlm_gemm_kernel<TA, TB, OUT_F32>), grid, block, smem, stream, p);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                             void* C, int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || !C) return VLM_ERR_ARG;
+  if (M == 0 || N == 0) return VLM_OK;
+  if (!A || !B || !epi) return VLM_ERR_ARG;
+  // 16-B staging granules: leading dimensions and bases must keep 8-element alignment
+  if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VLM_ERR_ARG;
+  // K-contiguous operands need whole 64-deep K tiles (their ragged tail would alias the next row)
+  if ((!ta || !tb) && (K % GEMM_BK)) return VLM_ERR_UNSUPPORTED;
+  if ((ldc & 3) || ((uintptr_t)C & 15)) return VLM_ERR_ARG;
+  if (epi->accumulate && !c_is_f32) return VLM_ERR_ARG;
+  if (epi->act == VLM_ACT_GELU_BWD && !epi->aux) return VLM_ERR_ARG;
+  if (epi->aux && (epi->ld_aux & 3)) return VLM_ERR_ARG;
+  if (epi->residual && (epi->ld_res & 3)) return VLM_ERR_ARG;
+  const uint64_t a_bytes = (uint64_t)(ta ? K : M) * lda * 2, b_bytes = (uint64_t)(tb ? K : N) * ldb * 2;
+  if (a_bytes >= (1ull << 31) || b_bytes >= (1ull << 31)) return VLM_ERR_UNSUPPORTED;
+  gemm_params_t p;
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.epi = *epi;
+  p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+  p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  hipStream_t s = (hipStream_t)stream;
+  const int key = (ta ? 4 : 0) | (tb ? 2 : 0) | (c_is_f32 ? 1 : 0);
+  switch (key) {
+    case 0: return launch_gemm<false, false, false>(p, s);
+    case 1: return launch_gemm<false, false, true>(p, s);
+    case 2: return launch_gemm<false, true, false>(p, s);
+    case 3: return launch_gemm<false, true, true>(p, s);
+    case 4: return launch_gemm<true, false, false>(p, s);
+    case 5: return launch_gemm<true, false, true>(p, s);
+    case 6: return launch_gemm<true, true, false>(p, s);
+    default: return launch_gemm<true, true, true>(p, s);
+  }
+}

@@ -1,0 +1,331 @@
+// Row-wise bandwidth-bound kernels of the VLMo block: LayerNorm fwd/bwd (K5), LayerScale backward,
+// bias-gradient column sums.  One wave (64 lanes) owns one token row at a time; lane l owns the float4
+// column granules l*4 + 256*u, so per-column reductions over rows (dgamma/dbeta/dbias) stay in registers and
+// cross-lane traffic is only the two row statistics.  All loads/stores are 16-B (fp32) or 8-B (bf16x4) vectors.
+//
+// Reference op sites: nn.LayerNorm(eps=1e-6) vision_transformer.py:831 / apply_ln :495-523; BertEmbeddings
+// LayerNorm(1e-12) vilt_module.py:63; LayerScale `x + drop_path(gamma * branch)` :586,:603; the backward of
+// each is what torch autograd derives for those ops.
+#include "vlm_common.h"
+
+#define ROW_THREADS 256
+#define ROW_WAVES 4
+
+template <int MAXU, bool IN_BF16>
+__device__ __forceinline__ void load_row(const void* base, size_t row, int ld, int D, int lane, f32x4 (&v)[MAXU]) {
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int c = lane * 4 + 256 * u;
+    if (c < D) {
+      if (IN_BF16) {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(base) + row * ld + c);
+        v[u] = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * ld + c);
+      }
+    } else {
+      v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+template <int MAXU>
+__device__ __forceinline__ void load_vec(const float* p, int D, int lane, f32x4 (&v)[MAXU], float fill) {
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int c = lane * 4 + 256 * u;
+    v[u] = (c < D && p) ? *reinterpret_cast<const f32x4*>(p + c) : (f32x4){fill, fill, fill, fill};
+  }
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm forward
+template <int MAXU, bool OUT_F32>
+__global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const float* __restrict__ x, int ldx, int M, int D,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             void* __restrict__ y, int ldy,
+                                                             float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[MAXU], b[MAXU];
+  load_vec<MAXU>(gamma, D, lane, g, 1.0f);
+  load_vec<MAXU>(beta, D, lane, b, 0.0f);
+  const float invD = 1.0f / (float)D;
+  for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
+    f32x4 v[MAXU];
+    load_row<MAXU, false>(x, row, ldx, D, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int c = lane * 4 + 256 * u;
+      if (c < D) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = v[u][r] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float var = wave_sum(q) * invD;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (stats && lane == 0) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = rstd;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int c = lane * 4 + 256 * u;
+      if (c < D) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (v[u][r] - mean) * rstd * g[u][r] + b[u][r];
+        if (OUT_F32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + row * ldy + c) = o;
+        } else {
+          bf16x4 h = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(y) + row * ldy + c) = h;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm backward
+// dx[m,:] = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; dx_out = dx (+ dres) ; column sums by
+// one atomicAdd per column per block (fp32 grads are accumulated across passes anyway).
+template <int MAXU, bool DY_BF16>
+__global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
+                                                             const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, int M, int D,
+                                                             const float* __restrict__ dres, int lddres,
+                                                             float* __restrict__ dx, int lddx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[ROW_WAVES][2][MAXU * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[MAXU], ag[MAXU], ab[MAXU];
+  load_vec<MAXU>(gamma, D, lane, g, 1.0f);
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float invD = 1.0f / (float)D;
+  for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
+    f32x4 v[MAXU], d[MAXU];
+    load_row<MAXU, false>(x, row, ldx, D, lane, v);
+    load_row<MAXU, DY_BF16>(dy, row, lddy, D, lane, d);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int c = lane * 4 + 256 * u;
+      if (c < D) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (v[u][r] - mean) * rstd;
+          const float gg = d[u][r] * g[u][r];
+          s1 += gg;
+          s2 += gg * xh;
+          ag[u][r] += d[u][r] * xh;
+          ab[u][r] += d[u][r];
+          v[u][r] = xh;
+          d[u][r] = gg;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int c = lane * 4 + 256 * u;
+      if (c < D) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = rstd * (d[u][r] - m1 - v[u][r] * m2);
+        if (dres) o += *reinterpret_cast<const f32x4*>(dres + row * lddres + c);
+        *reinterpret_cast<f32x4*>(dx + row * lddx + c) = o;
+      }
+    }
+  }
+  if (dgamma || dbeta) {
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[wave][0][u * 256 + lane * 4 + r] = ag[u][r];
+        red[wave][1][u * 256 + lane * 4 + r] = ab[u][r];
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += ROW_THREADS) {
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < ROW_WAVES; ++w) {
+        sg += red[w][0][c];
+        sb += red[w][1][c];
+      }
+      if (dgamma) atomicAdd(dgamma + c, sg);
+      if (dbeta) atomicAdd(dbeta + c, sb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- LayerScale backward
+// forward was x_new = x + rs[m]*gamma[n]*y[m,n]  (y = branch output incl. its bias, saved in bf16)
+//   dy[m,n]   = rs[m]*gamma[n]*dx[m,n]          (bf16, feeds the dgrad/wgrad GEMMs)
+//   dgamma[n] += sum_m rs[m]*dx[m,n]*y[m,n]  ;  dbias[n] += sum_m dy[m,n]
+template <int MAXU>
+__global__ __launch_bounds__(ROW_THREADS) void scale_bwd_kernel(const float* __restrict__ dx, int lddx,
+                                                                const bf16_t* __restrict__ y, int ldy,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ row_scale, int M, int D,
+                                                                bf16_t* __restrict__ dy, int lddy,
+                                                                float* __restrict__ dgamma,
+                                                                float* __restrict__ dbias) {
+  __shared__ float red[ROW_WAVES][2][MAXU * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 g[MAXU], ag[MAXU], ab[MAXU];
+  load_vec<MAXU>(gamma, D, lane, g, 1.0f);
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
+    f32x4 d[MAXU], yy[MAXU];
+    load_row<MAXU, false>(dx, row, lddx, D, lane, d);
+    load_row<MAXU, true>(y, row, ldy, D, lane, yy);
+    const float rs = row_scale ? row_scale[row] : 1.0f;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int c = lane * 4 + 256 * u;
+      if (c < D) {
+        bf16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sd = rs * d[u][r];
+          const float o = sd * g[u][r];
+          ag[u][r] += sd * yy[u][r];
+          h[r] = (bf16_t)o;
+          ab[u][r] += (float)h[r];  // the bias gradient the GEMMs see is the rounded dy
+        }
+        *reinterpret_cast<bf16x4*>(dy + row * lddy + c) = h;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][0][u * 256 + lane * 4 + r] = ag[u][r];
+      red[wave][1][u * 256 + lane * 4 + r] = ab[u][r];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += ROW_THREADS) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < ROW_WAVES; ++w) {
+      sg += red[w][0][c];
+      sb += red[w][1][c];
+    }
+    if (dgamma) atomicAdd(dgamma + c, sg);
+    if (dbias) atomicAdd(dbias + c, sb);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ column sum
+// out[n] += sum_m a[m, n]  for bf16 a; lane owns 8 columns (16-B loads), the block's 4 waves split the rows.
+__global__ __launch_bounds__(ROW_THREADS) void colsum_kernel(const bf16_t* __restrict__ a, int lda, int M, int N,
+                                                             float* __restrict__ out) {
+  __shared__ float red[ROW_WAVES][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + lane) * 8;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  if (c0 < N) {
+    for (size_t row = (size_t)blockIdx.y * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.y * ROW_WAVES) {
+      const bf16x8 h = *reinterpret_cast<const bf16x8*>(a + row * lda + c0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += (float)h[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) red[wave][lane * 8 + r] = acc[r];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += ROW_THREADS) {
+    const int n = blockIdx.x * 512 + c;
+    if (n < N) atomicAdd(out + n, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
+static int row_grid(int M) {
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  int want = (M + ROW_WAVES - 1) / ROW_WAVES;
+  int cap = cus * 8;
+  return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+extern "C" int vlm_layernorm_fwd(const float* x, int ldx, int M, int D, const float* gamma, const float* beta,
+                                 float eps, void* y, int ldy, int y_is_f32, float* stats, void* stream) {
+  if (M == 0) return VLM_OK;
+  if (!x || !y || M < 0 || D <= 0 || (D & 3) || (ldx & 3) || (ldy & 3)) return VLM_ERR_ARG;
+  if (D > 1024) return VLM_ERR_UNSUPPORTED;
+  dim3 grid(row_grid(M)), block(ROW_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_FWD(U, F) hipLaunchKernelGGL((ln_fwd_kernel<U, F>), grid, block, 0, s, x, ldx, M, D, gamma, beta, eps, y, ldy, stats)
+  if (D <= 256) { if (y_is_f32) LN_FWD(1, true); else LN_FWD(1, false); }
+  else { if (y_is_f32) LN_FWD(4, true); else LN_FWD(4, false); }
+#undef LN_FWD
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx,
+                                 const float* stats, const float* gamma, int M, int D, const float* dres,
+                                 int lddres, float* dx, int lddx, float* dgamma, float* dbeta, void* stream) {
+  if (M == 0) return VLM_OK;
+  if (!dy || !x || !stats || !dx || M < 0 || D <= 0 || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) ||
+      (dres && (lddres & 3)))
+    return VLM_ERR_ARG;
+  if (D > 1024) return VLM_ERR_UNSUPPORTED;
+  int g = row_grid(M);
+  if (g > 512) g = 512;  // bounds the per-column atomics
+  dim3 grid(g), block(ROW_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_BWD(U, B) hipLaunchKernelGGL((ln_bwd_kernel<U, B>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta)
+  if (D <= 256) { if (dy_is_f32) LN_BWD(1, false); else LN_BWD(1, true); }
+  else { if (dy_is_f32) LN_BWD(4, false); else LN_BWD(4, true); }
+#undef LN_BWD
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_layerscale_bwd(const float* dx, int lddx, const void* y, int ldy, const float* gamma,
+                                  const float* row_scale, int M, int D, void* dy, int lddy, float* dgamma,
+                                  float* dbias, void* stream) {
+  if (M == 0) return VLM_OK;
+  if (!dx || !y || !dy || M < 0 || D <= 0 || (D & 3) || (lddx & 3) || (ldy & 3) || (lddy & 3)) return VLM_ERR_ARG;
+  if (D > 1024) return VLM_ERR_UNSUPPORTED;
+  int g = row_grid(M);
+  if (g > 512) g = 512;
+  dim3 grid(g), block(ROW_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (D <= 256)
+    hipLaunchKernelGGL((scale_bwd_kernel<1>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M,
+                       D, (bf16_t*)dy, lddy, dgamma, dbias);
+  else
+    hipLaunchKernelGGL((scale_bwd_kernel<4>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M,
+                       D, (bf16_t*)dy, lddy, dgamma, dbias);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_colsum_bf16(const void* a, int lda, int M, int N, float* out, void* stream) {
+  if (M == 0 || N == 0) return VLM_OK;
+  if (!a || !out || M < 0 || N < 0 || (lda & 7) || (N & 7) || ((uintptr_t)a & 15)) return VLM_ERR_ARG;
+  int gy = (M + ROW_WAVES * 32 - 1) / (ROW_WAVES * 32);
+  if (gy > 128) gy = 128;
+  if (gy < 1) gy = 1;
+  dim3 grid((N + 511) / 512, gy), block(ROW_THREADS);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)a, lda, M, N, out);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}

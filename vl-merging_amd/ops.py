@@ -1,0 +1,122 @@
+"""Thin typed wrappers over the C ABI (one Python function per extern "C" entry point).
+
+Every wrapper takes torch CUDA tensors, checks dtype/contiguity, and launches on torch's current stream.
+No wrapper has a CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _ld(t):
+    """Leading dimension (row stride in elements) of a 2-D row-major view."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise L.VlmError("expected a 2-D tensor with unit inner stride, got shape %s strides %s"
+                         % (tuple(t.shape), t.stride()))
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, col_scale=None, row_scale=None,
+         residual=None, alpha=1.0, accumulate=False):
+    """out[M,N] = epilogue(op(a)[M,K] @ op(b)[K,N]); see include/vlm_hip.h for the epilogue algebra.
+
+    a: bf16 [M,K] (ta=False) or [K,M] (ta=True);  b: bf16 [N,K] (tb=False, nn.Linear layout) or [K,N] (tb=True).
+    """
+    L.require_cuda(a, b, out, bias, aux, col_scale, row_scale, residual)
+    if a.dtype != BF16 or b.dtype != BF16:
+        raise L.VlmError("gemm operands must be bfloat16")
+    M, N = out.shape
+    K = a.shape[0] if ta else a.shape[1]
+    if (a.shape[1] if ta else a.shape[0]) != M:
+        raise L.VlmError("gemm: A rows %s do not match M=%d" % (tuple(a.shape), M))
+    kb, nb = (b.shape[0], b.shape[1]) if tb else (b.shape[1], b.shape[0])
+    if nb != N or kb != K:
+        raise L.VlmError("gemm: B shape %s incompatible with N=%d K=%d" % (tuple(b.shape), N, K))
+    e = L.Epilogue()
+    e.bias = bias.data_ptr() if bias is not None else 0
+    e.col_scale = col_scale.data_ptr() if col_scale is not None else 0
+    e.row_scale = row_scale.data_ptr() if row_scale is not None else 0
+    e.residual = residual.data_ptr() if residual is not None else 0
+    e.ld_res = _ld(residual) if residual is not None else 0
+    e.aux = aux.data_ptr() if aux is not None else 0
+    e.ld_aux = _ld(aux) if aux is not None else 0
+    e.act = act
+    e.alpha = alpha
+    e.accumulate = 1 if accumulate else 0
+    for t, dt in ((bias, F32), (col_scale, F32), (row_scale, F32), (residual, F32), (aux, BF16)):
+        if t is not None and t.dtype != dt:
+            raise L.VlmError("gemm epilogue tensor has dtype %s, expected %s" % (t.dtype, dt))
+    if out.dtype not in (BF16, F32):
+        raise L.VlmError("gemm output must be bf16 or f32")
+    rc = L.get_lib().vlm_gemm_bf16(int(ta), int(tb), M, N, K, L.ptr(a), _ld(a), L.ptr(b), _ld(b), L.ptr(out), _ld(out),
+                                   int(out.dtype == F32), ctypes.byref(e), L.stream_ptr())
+    L.check(rc, "vlm_gemm_bf16")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, out, stats=None):
+    L.require_cuda(x, gamma, beta, out, stats)
+    M, D = x.shape
+    rc = L.get_lib().vlm_layernorm_fwd(L.ptr(x), _ld(x), M, D, L.ptr(gamma), L.ptr(beta), eps, L.ptr(out), _ld(out),
+                                       int(out.dtype == F32), L.ptr(stats), L.stream_ptr())
+    L.check(rc, "vlm_layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(dy, x, stats, gamma, dx, dres=None, dgamma=None, dbeta=None):
+    L.require_cuda(dy, x, stats, gamma, dx, dres, dgamma, dbeta)
+    M, D = x.shape
+    rc = L.get_lib().vlm_layernorm_bwd(L.ptr(dy), _ld(dy), int(dy.dtype == F32), L.ptr(x), _ld(x), L.ptr(stats),
+                                       L.ptr(gamma), M, D, L.ptr(dres), _ld(dres) if dres is not None else 0,
+                                       L.ptr(dx), _ld(dx), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr())
+    L.check(rc, "vlm_layernorm_bwd")
+    return dx
+
+
+def layerscale_bwd(dx, y, gamma, row_scale, dy, dgamma=None, dbias=None):
+    L.require_cuda(dx, y, gamma, row_scale, dy, dgamma, dbias)
+    M, D = dx.shape
+    rc = L.get_lib().vlm_layerscale_bwd(L.ptr(dx), _ld(dx), L.ptr(y), _ld(y), L.ptr(gamma), L.ptr(row_scale), M, D,
+                                        L.ptr(dy), _ld(dy), L.ptr(dgamma), L.ptr(dbias), L.stream_ptr())
+    L.check(rc, "vlm_layerscale_bwd")
+    return dy
+
+
+def colsum(a, out):
+    """out[n] += sum_m a[m,n]  (a bf16)."""
+    L.require_cuda(a, out)
+    M, N = a.shape
+    L.check(L.get_lib().vlm_colsum_bf16(L.ptr(a), _ld(a), M, N, L.ptr(out), L.stream_ptr()), "vlm_colsum_bf16")
+    return out
+
+
+def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, zero_grad=True):
+    """One fused AdamW update over flat fp32 buffers (HF-4.x semantics); `step` is the 1-based step count."""
+    L.require_cuda(p, g, m, v, p_bf16)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    step_size = lr * (bc2 ** 0.5) / bc1
+    rc = L.get_lib().vlm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(p_bf16), p.numel(), lr, beta1, beta2,
+                                    eps, weight_decay, step_size, grad_scale, int(zero_grad), L.stream_ptr())
+    L.check(rc, "vlm_adamw_step")
+
+
+def cast_bf16(src, dst):
+    L.require_cuda(src, dst)
+    L.check(L.get_lib().vlm_cast_f32_bf16(L.ptr(src), L.ptr(dst), src.numel(), L.stream_ptr()), "vlm_cast_f32_bf16")
+    return dst
+
+
+def patch_im2col(image, patches, patch, lead_rows):
+    L.require_cuda(image, patches)
+    B, C, H, W = image.shape
+    if C != 3 or image.dtype != F32 or not image.is_contiguous():
+        raise L.VlmError("patch_im2col expects a contiguous fp32 [B,3,H,W] image")
+    rc = L.get_lib().vlm_patch_im2col(L.ptr(image), L.ptr(patches), B, H, W, patch, lead_rows, L.stream_ptr())
+    L.check(rc, "vlm_patch_im2col")
+    return patches
