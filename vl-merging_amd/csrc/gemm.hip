@@ -180,7 +180,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 
   // ---- epilogue: lane holds rows m = ..+(lane&15), columns n = ..+(lane>>4)*4 + r ------------------------------
   const vlm_epilogue_t& e = p.epi;
-  const bool n_vec_ok = ((p.N & 3) == 0);
+  // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
+  const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
-      const bool full = n_vec_ok || (n + 3 < p.N);
+      const bool full = vec_ok && (n + 3 < p.N);
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha;
@@ -294,11 +295,9 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VLM_ERR_ARG;
   // K-contiguous operands need whole 64-deep K tiles (their ragged tail would alias the next row)
   if ((!ta || !tb) && (K % GEMM_BK)) return VLM_ERR_UNSUPPORTED;
-  if ((ldc & 3) || ((uintptr_t)C & 15)) return VLM_ERR_ARG;
+  if (((ldc & 3) == 0) && ((uintptr_t)C & 15)) return VLM_ERR_ARG;
   if (epi->accumulate && !c_is_f32) return VLM_ERR_ARG;
   if (epi->act == VLM_ACT_GELU_BWD && !epi->aux) return VLM_ERR_ARG;
-  if (epi->aux && (epi->ld_aux & 3)) return VLM_ERR_ARG;
-  if (epi->residual && (epi->ld_res & 3)) return VLM_ERR_ARG;
   const uint64_t a_bytes = (uint64_t)(ta ? K : M) * lda * 2, b_bytes = (uint64_t)(tb ? K : N) * ldb * 2;
   if (a_bytes >= (1ull << 31) || b_bytes >= (1ull << 31)) return VLM_ERR_UNSUPPORTED;
   gemm_params_t p;
