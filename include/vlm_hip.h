@@ -142,6 +142,48 @@ int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_
 int vlm_cast_f32_bf16(const float* src, void* dst_bf16, uint64_t n, void* stream);
 int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W, int P, int lead_rows, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention (K4 + K7 + K7b): softmax(scale*Q K^T + bias[h] + key mask) V, head_dim = 64.
+ * Replaces Attention.forward's core, modules/vision_transformer.py:346-358, the bias materialisation
+ * get_rel_pos_bias modules/vilt_module.py:1061-1064 (never formed here), and the text/image block-diagonal
+ * split of separate_plain_forward / moe_forward (vision_transformer.py:567-584, :619-637).
+ *   qkv       bf16 [rows, 3*H*64] = F.linear output of :335 as is (q | k | v thirds, head-major); the kernel
+ *             applies `scale` (:346) to the scores.
+ *   bias_t    f32 [n_cols, R]: TRANSPOSE of relative_position_bias_table [R, heads*layers]; row head_row0+h
+ *             is head h of this layer.  NULL = no bias.
+ *   rel_index int16 [index_rows, ld_index]: relative-position index in "index coordinates": text token t is
+ *             position t, image token i is position pos1 + i (pos1 % 4 == 0, ld_index % 4 == 0).
+ *   keep0/1   uint8 [B, n0] / [B, n1] key keep flags (text_masks; NULL = keep all), masked_fill(-inf) of :354.
+ *   rows      segment-major: text (b,t) -> base0 + b*n0 + t ; image (b,i) -> base1 + b*n1 + i.
+ *   mode      JOINT: every query sees text then image keys.  SEPARATE: queries see their own segment only.
+ * Forward writes out bf16 [rows, H*64] (the layout :358 reshapes to) and lse f32 [H, total_rows] (log2 domain,
+ * consumed by the backward).  Backward: delta = rowsum(dO*O), then dK/dV (+ the bias-table gradient, accumulated
+ * into dbias_t f32 [n_cols, R]) and dQ, written into dqkv bf16 [rows, 3*H*64] (dq already carries `scale`).
+ */
+#define VLM_ATTN_JOINT 0
+#define VLM_ATTN_SEPARATE 1
+
+typedef struct {
+  const void* qkv;
+  int32_t ld_qkv;
+  int32_t H;
+  int32_t total_rows;
+  int32_t R;
+  const float* bias_t;
+  const int16_t* rel_index;
+  int32_t ld_index;
+  int32_t index_rows;
+  int32_t head_row0;
+  int32_t mode;
+  const uint8_t* keep0;
+  const uint8_t* keep1;
+  int32_t B, n0, n1, base0, base1, pos1;
+  float scale;
+  int32_t reserved;
+} vlm_attn_desc_t;
+
+int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out_bf16, int ld_out, float* lse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,57 @@ def patch_im2col(image, patches, patch, lead_rows):
     rc = L.get_lib().vlm_patch_im2col(L.ptr(image), L.ptr(patches), B, H, W, patch, lead_rows, L.stream_ptr())
     L.check(rc, "vlm_patch_im2col")
     return patches
+
+
+class Seq:
+    """Segment-major token layout of one pass (include/vlm_hip.h): B samples, n0 text + n1 image tokens each."""
+
+    __slots__ = ("B", "n0", "n1", "base0", "base1", "pos1")
+
+    def __init__(self, B, n0, n1, base0=0, base1=None, pos1=None):
+        self.B, self.n0, self.n1 = B, n0, n1
+        self.base0 = base0
+        self.base1 = base0 + B * n0 if base1 is None else base1
+        self.pos1 = (n0 + 3) // 4 * 4 if pos1 is None else pos1
+
+    @property
+    def rows(self):
+        return self.B * (self.n0 + self.n1)
+
+
+def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, scale):
+    L.require_cuda(qkv, bias_t, rel_index, keep0, keep1)
+    if qkv.dtype != BF16:
+        raise L.VlmError("attention expects bf16 qkv")
+    d = L.AttnDesc()
+    d.qkv = qkv.data_ptr()
+    d.ld_qkv = _ld(qkv)
+    d.H = H
+    d.total_rows = qkv.shape[0]
+    if bias_t is not None:
+        if bias_t.dtype != F32 or rel_index.dtype != torch.int16 or not bias_t.is_contiguous():
+            raise L.VlmError("attention bias_t must be contiguous f32 and rel_index int16")
+        d.R = bias_t.shape[1]
+        d.bias_t = bias_t.data_ptr()
+        d.rel_index = rel_index.data_ptr()
+        d.ld_index = _ld(rel_index)
+        d.index_rows = rel_index.shape[0]
+    d.head_row0 = head_row0
+    d.mode = mode
+    for k in (keep0, keep1):
+        if k is not None and (k.dtype != torch.uint8 or not k.is_contiguous()):
+            raise L.VlmError("attention keep masks must be contiguous uint8")
+    d.keep0 = keep0.data_ptr() if keep0 is not None else 0
+    d.keep1 = keep1.data_ptr() if keep1 is not None else 0
+    d.B, d.n0, d.n1, d.base0, d.base1, d.pos1 = seq.B, seq.n0, seq.n1, seq.base0, seq.base1, seq.pos1
+    d.scale = scale
+    return d
+
+
+def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=None, keep0=None, keep1=None,
+                  mode=L.ATTN_JOINT, scale=0.125):
+    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, scale)
+    L.require_cuda(out, lse)
+    rc = L.get_lib().vlm_attention_fwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(lse), L.stream_ptr())
+    L.check(rc, "vlm_attention_fwd")
+    return out
