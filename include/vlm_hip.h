@@ -183,6 +183,12 @@ typedef struct {
 } vlm_attn_desc_t;
 
 int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out_bf16, int ld_out, float* lse, void* stream);
+/* delta_ws: f32 [H, total_rows] scratch.  rel_index_t: the TRANSPOSE of rel_index (int16 [index cols, ld_index_t],
+ * ld_index_t % 4 == 0) so the key-stationary kernel also reads 4 consecutive indices per 8-B load.
+ * dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED. */
+int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out_bf16, int ld_out, const void* dout_bf16, int ld_dout,
+                      const float* lse, float* delta_ws, const int16_t* rel_index_t, int ld_index_t, int index_t_rows,
+                      void* dqkv_bf16, int ld_dqkv, float* dbias_t, void* stream);
 
 #ifdef __cplusplus
 }

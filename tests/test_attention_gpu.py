@@ -118,3 +118,51 @@ def test_attention_fwd(ops, L, ci, sep, with_bias):
     # lse (log2 domain) against the reference's logsumexp
     ref_lse = from_seq(torch.logsumexp(s, -1).permute(0, 2, 1), c).t() * 1.4426950408889634
     assert torch.allclose(lse, ref_lse, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+@pytest.mark.parametrize("sep", [False, True])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_attention_bwd(ops, L, ci, sep, with_bias):
+    """Backward vs torch autograd of the fp32 restatement.  Tolerance: P, dS, dO enter the MFMAs as bf16 and the
+    result is stored as bf16: 3e-2 of the tensor's max magnitude absolute + 3e-2 relative."""
+    c = build_case(seed=100 + ci * 10 + sep, with_bias=with_bias, **CASES[ci])
+    seq = ops.Seq(c["B"], c["n0"], c["n1"])
+    rows, H, D = seq.rows, c["H"], c["D"]
+    layer = 1
+    g = torch.Generator(device="cuda"); g.manual_seed(7 + ci)
+    dout = torch.randn(rows, D, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(H, rows, device="cuda")
+    bias_t = c["table"].t().contiguous() if with_bias else None
+    mode = L.ATTN_SEPARATE if sep else L.ATTN_JOINT
+    kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=c["idx"] if with_bias else None, keep0=c["keep0"], mode=mode)
+    ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
+    dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
+    dbias_t = torch.zeros_like(bias_t) if with_bias else None
+    idx_t = None
+    if with_bias:
+        NP = c["pos1"] + c["n1"]
+        idx_t = torch.zeros(NP, (NP + 3) // 4 * 4, device="cuda", dtype=torch.int16)
+        idx_t[:, :NP] = c["idx"][:NP, :NP].t()
+    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, rel_index_t=idx_t, dbias_t=dbias_t, **kw)
+    torch.cuda.synchronize()
+    # reference
+    q32 = c["qkv"].float().requires_grad_(True)
+    tab = c["table"].clone().requires_grad_(True) if with_bias else None
+    cc = dict(c); cc["table"] = tab
+    ref_o, _, _ = reference(cc, layer, sep, qkv=q32)
+    (ref_o * dout.float()).sum().backward()
+    ref = q32.grad
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        a, b = dqkv[:, sl].float(), ref[:, sl]
+        err = (a - b).abs()
+        tol = 3e-2 * float(b.abs().max()) + 3e-2 * b.abs()
+        assert bool((err <= tol).all()), "%s max err %.4g (ref max %.4g)" % (name, float(err.max()), float(b.abs().max()))
+    if with_bias:
+        gt = tab.grad.t()  # [2H, R]
+        a, b = dbias_t[layer * H:(layer + 1) * H], gt[layer * H:(layer + 1) * H]
+        err = (a - b).abs()
+        tol = 2e-2 * float(b.abs().max()) + 2e-2 * b.abs()
+        assert bool((err <= tol).all()), "dbias max err %.4g (ref max %.4g)" % (float(err.max()), float(b.abs().max()))
+        assert float(dbias_t[:H].abs().max()) == 0.0  # other layer's rows untouched

@@ -1,0 +1,445 @@
+// Fused attention backward: recompute-based (flash style), three launches per (layer, pass):
+//   1. delta[h][row] = sum_d dO*O
+//   2. dQ kernel  (query-stationary, same structure as the forward; lane <-> query)
+//        S^T = K Q^T -> P^T = exp2(S2 - lse2) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ;
+//        dQ^T[d][q] += K^T . dS^T      (A = K^T by ds_read_b64_tr_b16, B = dS^T accumulator regs as bf16)
+//   3. dK/dV/dBias kernel (key-stationary; lane <-> key)
+//        S = Q K^T -> P ; dP = dO V^T ; dS = P o (dP - delta) ;
+//        dV[key][d] += P^T dO ,  dK[key][d] += scale * dS^T Q      (A = accumulator regs, B = dO / Q tr-read)
+//        d(bias table column)[idx[q][key]] += dS   through an LDS histogram (ds_add_f32), wave-reduced first where
+//        the whole 32x32 tile shares one index (all text->image pairs share ONE table row, vilt_module.py:180-181),
+//        flushed with one global atomic per touched bin per workgroup.
+// This is what autograd derives for reference vision_transformer.py:346-358 + F.embedding in get_rel_pos_bias
+// (vilt_module.py:1061-1064); two extra MFMA products (7 instead of 5) buy a deterministic dQ without atomics.
+#include "vlm_common.h"
+#include "attention_common.h"
+
+// ------------------------------------------------------------------------------------------------------- delta
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int ld_o,
+                                                         const bf16_t* __restrict__ d_o, int ld_do, int rows, int H,
+                                                         float* __restrict__ delta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = H * 64;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int c = lane * 8; c < D; c += 512) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + (size_t)row * ld_o + c);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(d_o + (size_t)row * ld_do + c);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if ((lane & 7) == 0) delta[(size_t)(c >> 6) * rows + row] = s;
+    }
+  }
+}
+
+struct attn_bwd_params_t {
+  attn_params_t f;        // forward description (qkv, bias, index, ranges)
+  const bf16_t* d_o;      // [rows, H*64]
+  int ld_do;
+  const float* lse;       // [H, rows] log2 domain
+  const float* delta;     // [H, rows]
+  const int16_t* idx_t;   // transposed relative index [index_cols, ld_idx_t]
+  int ld_idx_t, idx_t_rows;
+  bf16_t* dqkv;           // [rows, 3*H*64]
+  int ld_dqkv;
+  float* dbias_t;         // [n_cols, R] accumulate
+};
+
+// ----------------------------------------------------------------------------------------------------- dQ kernel
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_bwd_params_t bp) {
+  const attn_params_t& p = bp.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsK = smem;                          // [2] row image
+  unsigned char* ldsKt = smem + 2 * ATT_TILE_BYTES;    // [2] tr image
+  unsigned char* ldsV = smem + 4 * ATT_TILE_BYTES;     // [2] row image
+  float* kmask = reinterpret_cast<float*>(smem + 6 * ATT_TILE_BYTES);
+  float* tab = reinterpret_cast<float*>(smem + 6 * ATT_TILE_BYTES + 512);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const attn_seq_t sq = p.seq;
+  const int D = p.H * 64;
+  const int nt0 = (sq.n0 + ATT_BQ - 1) / ATT_BQ;
+  int qt = blockIdx.x;
+  const int seg = qt >= nt0 ? 1 : 0;
+  if (seg) qt -= nt0;
+  const int nq = seg ? sq.n1 : sq.n0;
+  const int q = qt * ATT_BQ + wave * 32 + r;
+  const bool qvalid = q < nq;
+  const int qc = qvalid ? q : nq - 1;
+  const size_t qrow = (size_t)(seg ? sq.base1 + b * sq.n1 : sq.base0 + b * sq.n0) + qc;
+  const int qpos = (seg ? sq.pos1 : 0) + qc;
+  att_ranges_t kr = att_key_ranges(sq, p.mode, seg, b, p.keep0, p.keep1);
+  const int ntiles = kr.nt[0] + kr.nt[1];
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = p.qkv + qrow * p.ld_qkv + h * 64 + 8 * hh;
+    const bf16_t* dp = bp.d_o + qrow * bp.ld_do + h * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+    }
+  }
+  const float lse2 = bp.lse[(size_t)h * p.total_rows + qrow];
+  const float dl = bp.delta[(size_t)h * p.total_rows + qrow];
+  if (HAS_BIAS) {
+    const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
+    for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
+  }
+  const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int16_t*>(p.idx), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
+
+  att_stage_t st;
+  att_stage_load(st, p.qkv, p.ld_qkv, D, h, kr, 0, tid);
+  att_tile_store_rows(st.k, ldsK, tid);
+  att_tile_store_tr(st.k, ldsKt, tid);
+  att_tile_store_rows(st.v, ldsV, tid);
+  if (tid < 64) kmask[tid] = st.mask;
+  __syncthreads();
+
+  const float c1 = p.scale * ATT_LOG2E;
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) att_stage_load(st, p.qkv, p.ld_qkv, D, h, kr, t + 1, tid);
+    const unsigned char* lk = ldsK + cur * ATT_TILE_BYTES;
+    const unsigned char* lkt = ldsKt + cur * ATT_TILE_BYTES;
+    const unsigned char* lv = ldsV + cur * ATT_TILE_BYTES;
+    const float* km = kmask + cur * 64;
+    int rng, k0;
+    att_tile_origin(kr, t, rng, k0);
+    const int kpos0 = kr.pos[rng] + k0;
+
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const bf16x8 a = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ss], s, 0, 0, 0);
+        const bf16x8 va = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ss], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int kl = kb * 32 + 8 * g4 + 4 * hh;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_BIAS) {
+          const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(qpos * p.ld_idx + kpos0 + kl) * 2, 0, 0);
+          bv[0] = tab[w[0] & 0xffff];
+          bv[1] = tab[w[0] >> 16];
+          bv[2] = tab[w[1] & 0xffff];
+          bv[3] = tab[w[1] >> 16];
+        }
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(km + kl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + mk[e];
+          const float pr = exp2f(v - lse2);
+          s[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl) * p.scale;  // dS^T, pre-scaled
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 df;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) df[j] = (bf16_t)s[8 * s2 + j];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 kf = att_tr_frag(lkt, kb * 32 + 16 * s2, db, lane);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, o[db], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntiles) {
+      att_tile_store_rows(st.k, ldsK + (cur ^ 1) * ATT_TILE_BYTES, tid);
+      att_tile_store_tr(st.k, ldsKt + (cur ^ 1) * ATT_TILE_BYTES, tid);
+      att_tile_store_rows(st.v, ldsV + (cur ^ 1) * ATT_TILE_BYTES, tid);
+      if (tid < 64) kmask[(cur ^ 1) * 64 + tid] = st.mask;
+    }
+    __syncthreads();
+  }
+  if (qvalid) {
+    bf16_t* op = bp.dqkv + qrow * bp.ld_dqkv + h * 64 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)o[db][4 * g4 + e];
+        *reinterpret_cast<bf16x4*>(op + db * 32 + 8 * g4) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- dK / dV / dBias kernel
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn_bwd_params_t bp) {
+  const attn_params_t& p = bp.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsQ = smem;                           // row image  [64 q][64 d]
+  unsigned char* ldsQt = smem + ATT_TILE_BYTES;         // tr image
+  unsigned char* ldsO = smem + 2 * ATT_TILE_BYTES;      // dO row image
+  unsigned char* ldsOt = smem + 3 * ATT_TILE_BYTES;     // dO tr image
+  float* qstat = reinterpret_cast<float*>(smem + 4 * ATT_TILE_BYTES);  // [64] lse2 then [64] delta
+  float* tab = qstat + 128;                                             // [R] bias column * log2e
+  float* hist = tab + ((p.R + 3) & ~3);                                 // [R] gradient histogram
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const attn_seq_t sq = p.seq;
+  const int D = p.H * 64;
+  const int nt0 = (sq.n0 + ATT_BQ - 1) / ATT_BQ;
+  int kt = blockIdx.x;
+  const int seg = kt >= nt0 ? 1 : 0;  // segment of this workgroup's keys
+  if (seg) kt -= nt0;
+  const int nk = seg ? sq.n1 : sq.n0;
+  const int key = kt * ATT_BQ + wave * 32 + r;
+  const bool kvalid = key < nk;
+  const int kc = kvalid ? key : nk - 1;
+  const size_t krow = (size_t)(seg ? sq.base1 + b * sq.n1 : sq.base0 + b * sq.n0) + kc;
+  const int kpos = (seg ? sq.pos1 : 0) + kc;
+  const uint8_t* keep = seg ? p.keep1 : p.keep0;
+  const bool kkeep = kvalid && (!keep || keep[(size_t)b * nk + kc] != 0);
+  const float kmaskv = kkeep ? 0.f : -INFINITY;
+  // query ranges that see this key segment (same rule as the forward, by symmetry of the block structure)
+  att_ranges_t qr = att_key_ranges(sq, p.mode, seg, b, nullptr, nullptr);
+  const int ntiles = qr.nt[0] + qr.nt[1];
+
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = p.qkv + krow * p.ld_qkv + D + h * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+    }
+  }
+  if (HAS_BIAS) {
+    const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
+    for (int i = tid; i < p.R; i += ATT_THREADS) {
+      tab[i] = col[i] * ATT_LOG2E;
+      hist[i] = 0.f;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int16_t*>(bp.idx_t), 0, HAS_BIAS ? bp.idx_t_rows * bp.ld_idx_t * 2 : 0, 0x00020000);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
+
+  u32x4 sq_[2], so_[2];
+  float s_lse = 0.f, s_dl = 0.f;
+  auto stage_load = [&](int t) {
+    int rng, q0;
+    att_tile_origin(qr, t, rng, q0);
+    att_tile_load(sq_, p.qkv, p.ld_qkv, h * 64, qr.rowbase[rng], q0, qr.n[rng], tid);
+    att_tile_load(so_, bp.d_o, bp.ld_do, h * 64, qr.rowbase[rng], q0, qr.n[rng], tid);
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      const bool ok = qq < qr.n[rng];
+      const size_t row = (size_t)qr.rowbase[rng] + (ok ? qq : 0);
+      s_lse = ok ? bp.lse[(size_t)h * p.total_rows + row] : INFINITY;  // exp2(x - inf) = 0 for padded queries
+      s_dl = ok ? bp.delta[(size_t)h * p.total_rows + row] : 0.f;
+    }
+  };
+  auto stage_store = [&]() {
+    att_tile_store_rows(sq_, ldsQ, tid);
+    att_tile_store_tr(sq_, ldsQt, tid);
+    att_tile_store_rows(so_, ldsO, tid);
+    att_tile_store_tr(so_, ldsOt, tid);
+    if (tid < 64) {
+      qstat[tid] = s_lse;
+      qstat[64 + tid] = s_dl;
+    }
+  };
+  stage_load(0);
+  stage_store();
+  __syncthreads();
+
+  const float c1 = p.scale * ATT_LOG2E;
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) stage_load(t + 1);
+    int rng, q0;
+    att_tile_origin(qr, t, rng, q0);
+    const int qpos0 = qr.pos[rng] + q0;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const bf16x8 a = att_k_rowfrag(ldsQ, qb * 32 + r, 2 * ss + hh);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ss], s, 0, 0, 0);     // S[q][key]
+        const bf16x8 oa = att_k_rowfrag(ldsO, qb * 32 + r, 2 * ss + hh);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);  // dP[q][key]
+      }
+      uint32_t ids[8];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int ql = qb * 32 + 8 * g4 + 4 * hh;  // local query row of element 0 of this group
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_BIAS) {
+          const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(kpos * bp.ld_idx_t + qpos0 + ql) * 2, 0, 0);
+          ids[2 * g4] = w[0];
+          ids[2 * g4 + 1] = w[1];
+          bv[0] = tab[w[0] & 0xffff];
+          bv[1] = tab[w[0] >> 16];
+          bv[2] = tab[w[1] & 0xffff];
+          bv[3] = tab[w[1] >> 16];
+        }
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(qstat + ql);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(qstat + 64 + ql);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + kmaskv;
+          const float pr = exp2f(v - ls[e]);
+          s[4 * g4 + e] = pr;                               // P
+          dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl[e]);   // dS (natural units, w.r.t. the biased score)
+        }
+      }
+      if (HAS_BIAS) {
+        // bias-table gradient: LDS histogram; a tile whose 16x64 indices all coincide is reduced in registers
+        bool same = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) same = same && (ids[i] == ids[0]) && ((ids[i] >> 16) == (ids[i] & 0xffff));
+        const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
+        same = same && (ids[0] == first);
+        if (__all(same)) {
+          float tsum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tsum += dp[i];
+          tsum = wave_sum(tsum);
+          if (lane == 0) atomicAdd(hist + (first & 0xffff), tsum);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t w = ids[i >> 1];
+            atomicAdd(hist + ((i & 1) ? (w >> 16) : (w & 0xffff)), dp[i]);
+          }
+        }
+      }
+      // dV += P^T dO ; dK += scale * dS^T Q   (A = accumulator regs as bf16, B = tr-read tiles)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf, df;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pf[j] = (bf16_t)s[8 * s2 + j];
+          df[j] = (bf16_t)(dp[8 * s2 + j] * p.scale);
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 ob = att_tr_frag(ldsOt, qb * 32 + 16 * s2, db, lane);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ob, dv[db], 0, 0, 0);
+          const bf16x8 qb_ = att_tr_frag(ldsQt, qb * 32 + 16 * s2, db, lane);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb_, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      stage_store();
+      __syncthreads();
+    }
+  }
+
+  // ---- store dK, dV: accumulator rows = keys (regs), column = d (lane & 31) ----------------------------------------
+  {
+    const int kbase = kt * ATT_BQ + wave * 32;
+    const size_t row0 = (size_t)(seg ? sq.base1 + b * sq.n1 : sq.base0 + b * sq.n0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kl = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (kbase + kl < nk) {
+        bf16_t* dst = bp.dqkv + (row0 + kbase + kl) * bp.ld_dqkv + D + h * 64 + r;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dst[db * 32] = (bf16_t)dk[db][i];
+          dst[D + db * 32] = (bf16_t)dv[db][i];
+        }
+      }
+    }
+  }
+  if (HAS_BIAS && bp.dbias_t) {
+    __syncthreads();
+    float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
+    for (int i = tid; i < p.R; i += ATT_THREADS) {
+      const float v = hist[i];
+      if (v != 0.f) atomicAdd(g + i, v);
+    }
+  }
+}
+
+extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int ld_out, const void* d_out,
+                                 int ld_dout, const float* lse, float* delta_ws, const int16_t* rel_index_t,
+                                 int ld_index_t, int index_t_rows, void* dqkv, int ld_dqkv, float* dbias_t,
+                                 void* stream) {
+  attn_bwd_params_t bp;
+  int rc = att_fill_params(d, bp.f);
+  if (rc != VLM_OK) return rc;
+  if (!out || !d_out || !lse || !delta_ws || !dqkv) return VLM_ERR_ARG;
+  if ((ld_out & 7) || (ld_dout & 7) || (ld_dqkv & 3) || ((uintptr_t)out & 15) || ((uintptr_t)d_out & 15))
+    return VLM_ERR_ARG;
+  if (bp.f.bias_t && (!rel_index_t || (ld_index_t & 3) || ((uintptr_t)rel_index_t & 7))) return VLM_ERR_ARG;
+  attn_params_t& p = bp.f;
+  const int nt0 = (p.seq.n0 + ATT_BQ - 1) / ATT_BQ, nt1 = (p.seq.n1 + ATT_BQ - 1) / ATT_BQ;
+  if (nt0 + nt1 == 0 || p.seq.B == 0) return VLM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bp.d_o = reinterpret_cast<const bf16_t*>(d_out);
+  bp.ld_do = ld_dout;
+  bp.lse = lse;
+  bp.delta = delta_ws;
+  bp.idx_t = rel_index_t;
+  bp.ld_idx_t = ld_index_t;
+  bp.idx_t_rows = index_t_rows;
+  bp.dqkv = reinterpret_cast<bf16_t*>(dqkv);
+  bp.ld_dqkv = ld_dqkv;
+  bp.dbias_t = dbias_t;
+
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  int dg = (p.total_rows + 3) / 4;
+  if (dg > cus * 8) dg = cus * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(dg), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(out), ld_out, bp.d_o,
+                     ld_dout, p.total_rows, p.H, delta_ws);
+  VLM_CHECK_LAUNCH();
+
+  dim3 grid(nt0 + nt1, p.H, p.seq.B), block(ATT_THREADS);
+  const size_t Rp = (size_t)((p.R + 3) & ~3);
+  const size_t smem_dq = 6 * ATT_TILE_BYTES + 512 + Rp * 4;
+  const size_t smem_dkv = 4 * ATT_TILE_BYTES + 512 + 2 * Rp * 4;
+  if (smem_dq > 160 * 1024 || smem_dkv > 160 * 1024) return VLM_ERR_UNSUPPORTED;
+  if (p.bias_t) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv) != hipSuccess)
+      return VLM_ERR_LAUNCH;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, smem_dq, s, bp);
+    VLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, smem_dkv, s, bp);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, smem_dq, s, bp);
+    VLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, block, smem_dkv, s, bp);
+  }
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}

@@ -174,3 +174,20 @@ def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=
     rc = L.get_lib().vlm_attention_fwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(lse), L.stream_ptr())
     L.check(rc, "vlm_attention_fwd")
     return out
+
+
+def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None,
+                  keep0=None, keep1=None, mode=L.ATTN_JOINT, scale=0.125, dbias_t=None, delta_ws=None):
+    """dqkv <- d(loss)/d(qkv) (bf16, same layout as qkv); dbias_t += d(loss)/d(bias_t)."""
+    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, scale)
+    L.require_cuda(out, dout, lse, dqkv, rel_index_t, dbias_t, delta_ws)
+    if delta_ws is None:
+        delta_ws = torch.empty(H, qkv.shape[0], device=qkv.device, dtype=F32)
+    if bias_t is not None and (rel_index_t is None or rel_index_t.dtype != torch.int16):
+        raise L.VlmError("attention_bwd needs the transposed int16 relative index")
+    rc = L.get_lib().vlm_attention_bwd(
+        ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(dout), _ld(dout), L.ptr(lse), L.ptr(delta_ws), L.ptr(rel_index_t),
+        _ld(rel_index_t) if rel_index_t is not None else 0, rel_index_t.shape[0] if rel_index_t is not None else 0,
+        L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t), L.stream_ptr())
+    L.check(rc, "vlm_attention_bwd")
+    return dqkv
