@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py -- VL samples/sec (fwd+bwd+optimizer) of the VLMo hot path on MI355X, plus the merge kernel's GB/s.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): base_vl `ufo`, 384x384 patch 16, text length 40, per-GPU batch 22,
+task_mlm_itm_ifm (one training_step = mlm joint pass + ifm image/text passes + 3 itm joint passes, backward, fused
+AdamW step), train mode (DropPath / dropout live), synthetic batch, random-init weights, bf16 MFMA
+GEMMs with fp32 accumulation and an fp32 residual stream.  N > 1: weak scaling, gradient all-reduce over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+FLOP_PER_SAMPLE_384 = 1835.1e9  # fwd 611.7 GFLOP x 3
+MFMA_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0
+
+
+def synthetic_batch(B, image_size, T, vocab, seed, device, mlm_prob=0.25):
+    """image ~ U(-1,1); ids: [CLS]=101, length ~ U{8..40}, ids ~ U{1000..vocab-1}, [SEP]=102, pad 0;
+    25 % of the non-special positions -> [MASK]=103 with the original id as label."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    image = torch.rand(B, 3, image_size, image_size, generator=g) * 2 - 1
+    ids = torch.zeros(B, T, dtype=torch.long)
+    masks = torch.zeros(B, T, dtype=torch.long)
+    ids_mlm = torch.zeros(B, T, dtype=torch.long)
+    labels_mlm = torch.full((B, T), -100, dtype=torch.long)
+    for b in range(B):
+        ln = int(torch.randint(8, T + 1, (1,), generator=g))
+        ids[b, 0] = 101
+        ids[b, 1:ln - 1] = torch.randint(1000, vocab, (ln - 2,), generator=g)
+        ids[b, ln - 1] = 102
+        masks[b, :ln] = 1
+        ids_mlm[b] = ids[b]
+        pick = torch.rand(ln - 2, generator=g) < mlm_prob
+        if not pick.any():
+            pick[0] = True
+        pos = pick.nonzero().squeeze(1) + 1
+        labels_mlm[b, pos] = ids[b, pos]
+        ids_mlm[b, pos] = 103
+    batch = {"image": [image.to(device)], "text_ids": ids.to(device), "text_masks": masks.to(device),
+             "text_labels": torch.full((B, T), -100, dtype=torch.long, device=device),
+             "text_ids_mlm": ids_mlm.to(device), "text_labels_mlm": labels_mlm.to(device)}
+    return {"vl": batch}
+
+
+class GemmTimer:
+    """HIP-event timing of every GEMM launch on the launching (= torch current) stream during the timed region."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.orig = ops.gemm
+        self.records = []
+        self.on = False
+
+    def install(self):
+        def timed(a, b, out, ta=False, tb=False, **kw):
+            if not self.on:
+                return self.orig(a, b, out, ta, tb, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(a, b, out, ta, tb, **kw)
+            e1.record()
+            M, N = out.shape
+            K = a.shape[0] if ta else a.shape[1]
+            self.records.append((e0, e1, 2.0 * M * N * K))
+            return r
+        self.ops.gemm = timed
+
+    def summary(self):
+        if not self.records:
+            return None
+        torch.cuda.synchronize()
+        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        return {"launches": n, "seconds": t, "flop": fl, "avg_us": t / n * 1e6, "tflops": fl / t / 1e12}
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (parity-pinned CPU restatement of the reference) on this host: base_vl ufo, 224x224, B=2,
+    mlm+itm+ifm fwd+bwd (BASELINE configs[0]); bounded sample."""
+    from oracle import vlmo_ref as R
+    pkg_vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
+    torch.manual_seed(0)
+    idx, nrel, _, allrel = pkg_vm.build_relative_position_indices((14, 14), 40, 196, 40)
+    D, Fd, V = 768, 3072, 30522
+    g = torch.Generator().manual_seed(0)
+
+    def rn(*s, std=0.02):
+        return (torch.randn(*s, generator=g) * std).requires_grad_(True)
+
+    sd = {"relative_position_bias_table": rn(allrel, 144), "logit_scale": torch.tensor(2.659).requires_grad_(True),
+          "logit_vl_scale": torch.tensor(2.659).requires_grad_(True),
+          "text_embeddings.word_embeddings.weight": rn(V, D), "text_embeddings.token_type_embeddings.weight": rn(2, D),
+          "text_embeddings.LayerNorm.weight": torch.ones(D, requires_grad=True),
+          "text_embeddings.LayerNorm.bias": torch.zeros(D, requires_grad=True), "token_type_embeddings.weight": rn(2, D),
+          "transformer.cls_token": rn(1, 1, D), "transformer.patch_embed.proj.weight": rn(D, 3, 16, 16),
+          "transformer.patch_embed.proj.bias": torch.zeros(D, requires_grad=True),
+          "transformer.norm.weight": torch.ones(D, requires_grad=True),
+          "transformer.norm.bias": torch.zeros(D, requires_grad=True), "pooler.dense.weight": rn(D, D),
+          "pooler.dense.bias": torch.zeros(D, requires_grad=True), "mlm_score.transform.dense.weight": rn(D, D),
+          "mlm_score.transform.dense.bias": torch.zeros(D, requires_grad=True),
+          "mlm_score.transform.LayerNorm.weight": torch.ones(D, requires_grad=True),
+          "mlm_score.transform.LayerNorm.bias": torch.zeros(D, requires_grad=True),
+          "mlm_score.decoder.weight": rn(V, D), "mlm_score.bias": torch.zeros(V, requires_grad=True),
+          "itm_score.fc.weight": rn(2, D), "itm_score.fc.bias": torch.zeros(2, requires_grad=True)}
+    for n in ("ifm_text_proj", "ifm_image_proj", "ifm_vl_text_proj", "ifm_vl_image_proj"):
+        sd[n + ".fc.weight"] = rn(D, D)
+    for i in range(12):
+        p = f"transformer.blocks.{i}."
+        sd[p + "gamma_1"] = torch.full((D,), 0.1, requires_grad=True)
+        sd[p + "gamma_2"] = torch.full((D,), 0.1, requires_grad=True)
+        sd[p + "attn.q_bias"] = torch.zeros(D, requires_grad=True)
+        sd[p + "attn.v_bias"] = torch.zeros(D, requires_grad=True)
+        sd[p + "attn.qkv.weight"] = rn(3 * D, D)
+        sd[p + "attn.proj.weight"] = rn(D, D)
+        sd[p + "attn.proj.bias"] = torch.zeros(D, requires_grad=True)
+        sd[p + "mlp.fc1.weight"] = rn(Fd, D)
+        sd[p + "mlp.fc1.bias"] = torch.zeros(Fd, requires_grad=True)
+        sd[p + "mlp.fc2.weight"] = rn(D, Fd)
+        sd[p + "mlp.fc2.bias"] = torch.zeros(D, requires_grad=True)
+        for nm in ("norm1", "norm2"):
+            sd[p + nm + ".weight"] = torch.ones(D, requires_grad=True)
+            sd[p + nm + ".bias"] = torch.zeros(D, requires_grad=True)
+    a = R.Arch("ufo")
+    b = synthetic_batch(2, 224, 40, V, 1234, "cpu")["vl"]
+    batch = dict(b)
+    batch["image"] = b["image"][0]
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        out = R.pretrain_step(sd, a, idx, batch)
+        out["total_loss"].backward()
+        times.append(time.time() - t0)
+        if time.time() - t_all > seconds_budget:
+            break
+    use = times[1:] if len(times) > 1 else times
+    per_iter = sorted(use)[len(use) // 2]
+    return {"value": 2.0 / per_iter, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/vlmo_ref.py pretrain_step fwd+bwd, base_vl ufo 224^2 T=40 B=2 (BASELINE configs[0]), "
+                      "%d iteration(s) after 1 warm-up, fp32" % len(use)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arch", default="ufo", choices=["ufo", "all_moe"])
+    ap.add_argument("--batch", type=int, default=22)
+    ap.add_argument("--image-size", type=int, default=384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-merge", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ge.import_package()
+    cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
+    vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
+    vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
+    ops = importlib.import_module("vl_merging_amd.ops")
+    ddp = importlib.import_module("vl_merging_amd.ddp")
+
+    cfg = cfgmod.make_config("task_mlm_itm_ifm_square_randaug_base_vl", "step200k", args.arch,
+                             image_size=args.image_size, vit="vit_base_patch16_%d" % args.image_size,
+                             per_gpu_batchsize=args.batch, num_gpus=world, vl_mlm_prob=0.25)
+    torch.manual_seed(0)
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).to(dev)
+    model.train()
+    model.setup_engine()
+    (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"])
+    reducer = ddp.FlatGradReducer(model)
+    opt.grad_scale = reducer.grad_scale
+    batch = synthetic_batch(args.batch, args.image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
+    timer = GemmTimer(ops)
+    timer.install()
+
+    def step():
+        reducer.begin_step()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        reducer.finish_backward()
+        opt.step()
+        sch["scheduler"].step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    timer.on = rank == 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    total_samples = args.batch * world * args.steps
+    value = total_samples / dt
+
+    if rank == 0:
+        gs = timer.summary()
+        out = {
+            "metric": "VL samples/sec (fwd+bwd) base_vl 384^2 at 1/2/4/8 GPUs; merge GB/s vs HBM peak",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "base_vl %s %d^2 patch16 T=40 per_gpu_batchsize=%d task_mlm_itm_ifm fwd+bwd+AdamW, "
+                                   "train mode (BASELINE configs[%d])" % (args.arch, args.image_size, args.batch,
+                                                                          1 if args.arch == "ufo" else 2),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss_val},
+        }
+        flop_per_sample = FLOP_PER_SAMPLE_384 if args.image_size == 384 else 657.5e9
+        out["model_tflops"] = value * flop_per_sample / 1e12 / world
+        if gs:
+            out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "vlm_gemm_kernel",
+                               "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
+                               "gemm_share_of_step": gs["seconds"] / dt}
+        if not args.no_merge:
+            bm = importlib.import_module("vl_merging_amd.bench_merge")
+            del model, opt
+            torch.cuda.empty_cache()
+            m = bm.run()
+            out["merge"] = {"metric": "all_moe->ufo interpolation merge, base size, fp32", "GBps": m["GBps"],
+                            "seconds_median": m["seconds_median"], "algorithmic_bytes": m["algorithmic_bytes"],
+                            "roofline": {"bound": "hbm", "achieved": m["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": m["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                                         "kernel": "vlm_merge_kernel"}}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

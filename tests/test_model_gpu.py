@@ -1,0 +1,167 @@
+"""The MI355X model (HIP kernels, bf16 GEMMs / fp32 accumulation) against the reference's golden outputs and the
+fp32 oracle on the same deterministic weights and batch.
+
+Stated tolerance (north star: "fp within a stated tol for attention/FFN"): activations are rounded to bf16 between
+kernels (8 significant bits, like the reference's fp16 AMP path rounds to 11), so
+   features after 12 blocks : max |err| <= 3e-2 * max|ref|
+   logits / losses          : |err| <= 3e-2 (absolute, values are O(1..10))
+   parameter-gradient norms : relative error <= 6e-2 per tensor (bf16 operands of the wgrad GEMMs)
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.detweights import det_array, det_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods(pkg):
+    return (importlib.import_module("vl_merging_amd.vilt.config"),
+            importlib.import_module("vl_merging_amd.vilt.modules.vilt_module"))
+
+
+def build(mods, arch, tag, golden_dir, losses, max_vl=40, train=False):
+    cfgmod, vm = mods
+    cfg = cfgmod.make_config(arch, vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, vocab_size=1024,
+                             max_text_len=40, patch_size=16, vlffn_start_layer_index=10, image_size=224,
+                             max_vl_text_len=max_vl, tasks=["vl"] if max_vl else None,
+                             loss_names=cfgmod._loss_names(losses))
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    meta = json.load(open(os.path.join(golden_dir, f"keys_{tag}.json")))
+    sd = {k: torch.from_numpy(det_array(k, s)) for k, (s, dt) in meta.items()
+          if dt.startswith("float") and "index" not in k and "mask_for" not in k and not k.startswith(("train_", "val_"))}
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    model = model.cuda()
+    model.train(train)
+    model.setup_engine()
+    return model
+
+
+def gpu_batch(nb):
+    b = {k: torch.from_numpy(v).cuda() for k, v in nb.items()}
+    b["image"] = [b["image"]]
+    return b
+
+
+def grad_norm_ok(got, ref):
+    """6 % per tensor; tensors whose whole gradient is tiny (norm <= 0.012: fed only by the B=2 contrastive loss,
+    i.e. by the DIFFERENCE of two nearly identical L2-normalised features, ill-conditioned in any 8-bit-mantissa
+    format) get 15 %."""
+    rel = abs(got - ref) / (ref + 1e-12)
+    return rel <= 6e-2 or (ref <= 0.012 and rel <= 0.15)
+
+
+def feat_close(got, ref, what, tol=3e-2):
+    got = got.float().cpu()
+    ref = torch.as_tensor(ref)
+    err = float((got - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert err <= tol * scale, "%s: max err %.4g vs scale %.4g" % (what, err, scale)
+
+
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_infer_matches_reference_golden(mods, golden_dir, arch):
+    gold = np.load(os.path.join(golden_dir, f"model_tiny_{arch}.npz"))
+    model = build(mods, arch, f"tiny_{arch}", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})
+    batch = gpu_batch(det_batch(2, 224, 40, 1024, seed=1234))
+    with torch.no_grad():
+        r = model.infer(batch, mask_text=False)
+        for k in ("text_feats", "image_feats", "cls_feats", "raw_cls_feats"):
+            feat_close(r[k], gold["infer/" + k], k)
+        r = model.infer(batch, mask_text=True)
+        feat_close(r["text_feats"], gold["infer_mlm/text_feats"], "mlm text_feats")
+        r = model.infer_image(batch)
+        for k in ("image_feats", "cls_feats", "cls_vlffn_feats"):
+            feat_close(r[k], gold["infer_image/" + k], "image " + k)
+        r = model.infer_text(batch)
+        for k in ("text_feats", "cls_feats", "cls_vlffn_feats"):
+            feat_close(r[k], gold["infer_text/" + k], "text " + k)
+        # operator-level entry: Block.forward on a fixed hidden state (reference-shaped call)
+        x = (torch.from_numpy(det_array("probe.x", (2, 237, 192))) * 10).cuda()
+        mask = torch.cat([batch["text_masks"], torch.ones(2, 197, dtype=torch.long, device="cuda")], 1)
+        rp = model.get_rel_pos_bias(model.text_imag_relative_position_index)
+        for li in (0, 11):
+            y, _ = model.transformer.blocks[li](x, mask=mask, type_id=2, relative_position_bias=rp)
+            feat_close(y, gold[f"block{li}/joint"], f"block{li}", tol=1e-2)
+
+
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_training_step_matches_reference_golden(mods, golden_dir, arch):
+    gold = np.load(os.path.join(golden_dir, f"model_tiny_{arch}.npz"))
+    model = build(mods, arch, f"tiny_{arch}", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})  # eval mode = golden's mode
+    batch = gpu_batch(det_batch(2, 224, 40, 1024, seed=1234))
+    model.zero_grad()
+    mods[1].vilt_utils.set_task(model)
+    ret = model({"vl": batch})
+    total = sum(v for k, v in ret.items() if "loss" in k)
+    total.backward()
+    torch.cuda.synchronize()
+    for k in ("mlm_loss", "ifm_loss", "itm_loss"):
+        assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
+    assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
+    feat_close(ret["mlm_logits"], gold["step/mlm_logits"], "mlm logits")
+    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
+    gs = json.loads(str(gold["step/grad_summary"]))
+    named = dict(model.named_parameters())
+    bad = []
+    for n, v in gs.items():
+        g = named[n].grad
+        if v is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        nrm = float(g.double().norm())
+        if abs(nrm - v[0]) > 6e-2 * v[0] + 1e-6:
+            bad.append((n, nrm, v[0]))
+    assert not bad, bad[:10]
+    for key in gold.files:
+        if key.startswith("step/grad/"):
+            n = key[len("step/grad/"):]
+            ref = torch.from_numpy(gold[key])
+            got = named[n].grad.float().cpu()
+            err = float((got - ref).abs().max())
+            assert err <= 8e-2 * float(ref.abs().max()) + 1e-6, (n, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_irtr_matches_reference_golden(mods, golden_dir, arch):
+    gold = np.load(os.path.join(golden_dir, f"irtr_tiny_{arch}.npz"))
+    model = build(mods, arch, f"tiny_irtr_{arch}", golden_dir, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0}, max_vl=None)
+    batch = gpu_batch(det_batch(3, 224, 40, 1024, seed=77))
+    model.zero_grad()
+    mods[1].vilt_utils.set_task(model)
+    ret = model(batch)
+    ret["irtr_loss"].backward()
+    assert abs(float(ret["irtr_loss"]) - float(gold["irtr_loss"])) <= 2e-2
+    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits")
+    gs = json.loads(str(gold["grad_summary"]))
+    named = dict(model.named_parameters())
+    bad = [(n, float(named[n].grad.double().norm()), v[0]) for n, v in gs.items()
+           if v is not None and not grad_norm_ok(float(named[n].grad.double().norm()), v[0])]
+    assert not bad, bad[:10]
+
+
+def test_train_mode_step_and_optimizer(mods, golden_dir):
+    """Train mode (DropPath + dropout live), two fused AdamW steps: loss finite, weights and bf16 shadows move."""
+    model = build(mods, "all_moe", "tiny_all_moe", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1}, train=True)
+    batch = gpu_batch(det_batch(4, 224, 40, 1024, seed=5))
+    (opt,), (sch,) = model.configure_optimizers() if False else mods[1].vilt_utils.set_schedule(model, max_steps=100)
+    w0 = model.transformer.blocks[0].attn["v"].qkv.weight.detach().clone()
+    losses = []
+    for it in range(2):
+        loss = model.training_step({"vl": batch})
+        loss.backward()
+        opt.step()
+        sch["scheduler"].step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)), losses
+    w1 = model.transformer.blocks[0].attn["v"].qkv.weight.detach()
+    assert float((w1 - w0).abs().max()) > 0
+    assert torch.equal(model._flat.flat_b[:model._flat.numel], model._flat.flat_p[:model._flat.numel].to(torch.bfloat16))
+    assert float(model._flat.flat_g.abs().max()) == 0.0  # fused zero_grad

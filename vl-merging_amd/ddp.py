@@ -1,0 +1,96 @@
+"""Data-parallel gradient exchange for the flat gradient buffer: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference gets this from pytorch_lightning's DDP wrapper (run.py:263-288).  Here a bucket is a
+contiguous slice of engine.FlatParams.flat_g: {heads}, {block 11} ... {block 0}, {embeddings + bias table}.  A block's
+slice is final once every pass that used the block has run its backward (weights are shared by up to six passes per
+step); the fused block function reports each backward through `on_block_backward`, and the slice's all-reduce is
+launched on a side stream as soon as the count is complete, overlapping the remaining backward.  Parameters that get
+no gradient in a step (position_embeddings, mask_token, ...) stay zero in the flat buffer: no
+unused-parameter discovery is needed.  The 1/world average is folded into the fused AdamW kernel (grad_scale).
+"""
+import re
+
+import torch
+import torch.distributed as dist
+
+_BLOCK = re.compile(r"transformer\.blocks\.(\d+)\.")
+
+
+class FlatGradReducer:
+    def __init__(self, model, process_group=None):
+        self.model = model
+        self.flat = model._flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        names_by_block = {}
+        early, late = [], []
+        for n in self.flat.names:
+            m = _BLOCK.search(n)
+            if m:
+                names_by_block.setdefault(int(m.group(1)), []).append(n)
+            elif n.startswith(("text_embeddings", "token_type_embeddings", "transformer.patch_embed",
+                               "transformer.cls_token", "transformer.mask_token", "relative_position_bias_table",
+                               "temporal_relative_position_bias_table")):
+                early.append(n)
+            else:
+                late.append(n)
+        self.block_slices = {i: self.flat.slice_of(ns) for i, ns in names_by_block.items()}
+        self.tail_slices = [self.flat.slice_of(ns) for ns in (late, early) if ns]
+        self.expected = {i: 0 for i in self.block_slices}
+        self.seen = {i: 0 for i in self.block_slices}
+        self.handles = []
+        self.comm_stream = torch.cuda.Stream() if self.flat.flat_g.is_cuda else None
+        self.counting = True
+        model._grad_hook = self.on_block_backward
+        self.exposed_wait_s = 0.0
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def begin_step(self):
+        for i in self.seen:
+            self.seen[i] = 0
+        self.handles = []
+
+    def note_forward(self, layer):
+        """Called by the first (counting) step for every block evaluation to learn the static use counts."""
+        self.expected[layer] += 1
+
+    def _launch(self, lo, hi):
+        if self.world == 1:
+            return
+        buf = self.flat.flat_g[lo:hi]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.handles.append(dist.all_reduce(buf, group=self.group, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(buf, group=self.group, async_op=True))
+
+    def on_block_backward(self, layer):
+        self.seen[layer] += 1
+        if self.counting:
+            return
+        if self.seen[layer] == self.expected[layer]:
+            self._launch(*self.block_slices[layer])
+
+    def finish_backward(self):
+        """After loss.backward(): reduce what is left, then make the compute stream wait for all buckets."""
+        if self.counting:
+            # first step: use counts were unknown during backward -> reduce every block now, remember the counts
+            self.expected = dict(self.seen)
+            self.counting = False
+            for i in sorted(self.block_slices, reverse=True):
+                self._launch(*self.block_slices[i])
+        else:
+            for i, n in self.seen.items():
+                if n != self.expected[i]:
+                    raise RuntimeError("block %d ran %d backward passes, expected %d: static use counts changed"
+                                       % (i, n, self.expected[i]))
+        for lo, hi in self.tail_slices:
+            self._launch(lo, hi)
+        for h in self.handles:
+            h.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)

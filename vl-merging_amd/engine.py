@@ -1,0 +1,418 @@
+"""Execution engine of the VLMo hot path on MI355X: flat parameter storage, the fused transformer-block
+autograd function (hand-written forward AND backward over the HIP kernels), and small autograd wrappers for the
+remaining GEMM / LayerNorm / patch-embed op sites.
+
+Design (MI355X-first, not a port of the reference's module-by-module autograd):
+  * every parameter is a view into ONE flat fp32 buffer; gradients, the bf16 GEMM shadows and the AdamW state
+    live in parallel flat buffers with the same offsets -> zero_grad is one memset, the optimizer is one kernel
+    per parameter group, a DDP bucket is a contiguous slice;
+  * activations use the segment-major token layout of include/vlm_hip.h, so modality experts act on contiguous
+    row ranges (no torch.cat / slicing copies per layer as in vision_transformer.py:554-603);
+  * weight gradients are accumulated straight into the flat gradient buffer by the wgrad GEMM epilogue
+    (weights are shared by up to six passes per training step).
+"""
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+ALIGN = 64  # elements: keeps every parameter 256-B aligned in the fp32 and 128-B in the bf16 buffer
+
+
+class FlatParams:
+    """Flat fp32 master / grad / bf16-shadow storage for a module's parameters."""
+
+    def __init__(self, module: torch.nn.Module, order_key=None):
+        named = [(n, p) for n, p in module.named_parameters()]
+        if order_key is not None:
+            named.sort(key=lambda np_: order_key(np_[0]))
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        self.offsets = {}
+        off = 0
+        for n, p in named:
+            self.offsets[n] = (off, p.numel())
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        dev = self.params[0].device
+        pad = 64 * 4096  # tail slack: K-strided GEMM operands may be addressed a few rows past a ragged weight
+        self.flat_p = torch.zeros(off + pad, device=dev, dtype=F32)
+        self.flat_g = torch.zeros(off + pad, device=dev, dtype=F32)
+        self.flat_b = torch.zeros(off + pad, device=dev, dtype=BF16) if dev.type == "cuda" else None
+        for n, p in named:
+            o, k = self.offsets[n]
+            self.flat_p[o:o + k].view_as(p).copy_(p.data)
+            p.data = self.flat_p[o:o + k].view_as(p)
+            p.grad = self.flat_g[o:o + k].view_as(p)
+            p._vlm_name = n
+            p._vlm_bf16 = self.flat_b[o:o + k].view_as(p) if self.flat_b is not None else None
+        self.dirty = True
+
+    def refresh_shadow(self):
+        """fp32 master -> bf16 GEMM operands (one cast kernel).  Called after load_state_dict / optimizer steps."""
+        if self.flat_b is None:
+            raise L.VlmError("the bf16 shadow lives on the GPU; move the model to cuda before flattening")
+        ops.cast_bf16(self.flat_p[:self.numel], self.flat_b[:self.numel])
+        self.dirty = False
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def slice_of(self, names):
+        """(start, end) of the contiguous flat range covering `names` (a DDP bucket)."""
+        lo = min(self.offsets[n][0] for n in names)
+        hi = max(self.offsets[n][0] + (self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
+        return lo, hi
+
+
+def w16(p):
+    """bf16 shadow of a parameter (fails loudly if the model was not flattened onto the GPU)."""
+    s = getattr(p, "_vlm_bf16", None)
+    if s is None:
+        raise L.VlmError("parameter has no bf16 shadow: call model.setup_engine() on a CUDA model first")
+    return s
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# relative-position bias handle
+class RelPos:
+    """What the attention kernel needs instead of the reference's dense [H*L, N, N] bias (vilt_module.py:1061):
+    the transposed table (autograd-connected), the int16 index in index coordinates and its transpose."""
+
+    def __init__(self, bias_t, index16, index16_t, holder):
+        self.bias_t = bias_t          # [H*L, R] fp32, requires grad in training
+        self.index = index16          # int16 [NP, ld]
+        self.index_t = index16_t
+        self.holder = holder          # _TableT ctx holder: accumulates d(bias_t)
+
+    @property
+    def dbias_t(self):
+        return self.holder["dbias_t"]
+
+
+class _TableT(torch.autograd.Function):
+    """bias_t = table^T (contiguous).  Backward hands back the gradient the attention kernels accumulated."""
+
+    @staticmethod
+    def forward(ctx, table, holder):
+        ctx.holder = holder
+        return table.detach().t().contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        acc = ctx.holder.pop("dbias_t", None)
+        if acc is None:
+            return g.t(), None
+        return (acc + g).t(), None
+
+
+def make_relpos(table, index16, index16_t):
+    holder = {}
+    bias_t = _TableT.apply(table, holder)
+    if torch.is_grad_enabled() and table.requires_grad:
+        holder["dbias_t"] = torch.zeros_like(bias_t)
+    return RelPos(bias_t, index16, index16_t, holder)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class PassCtx:
+    """Static description of one pass (one `infer*` call) shared by its 12(+2) block evaluations."""
+
+    def __init__(self, seq: ops.Seq, num_heads: int, relpos: Optional[RelPos], keep0=None, keep1=None):
+        self.seq = seq
+        self.H = num_heads
+        self.relpos = relpos
+        self.keep0 = keep0
+        self.keep1 = keep1
+        self._row2sample = None
+
+    def row2sample(self, device):
+        if self._row2sample is None:
+            s = self.seq
+            a = torch.arange(s.B, device=device).repeat_interleave(s.n0)
+            b = torch.arange(s.B, device=device).repeat_interleave(s.n1)
+            self._row2sample = torch.cat([a, b])
+        return self._row2sample
+
+    def drop_path_rows(self, prob, training, device):
+        """Per-row scale of timm's DropPath (per-sample bernoulli(keep)/keep), or None when inactive."""
+        if not training or prob <= 0.0:
+            return None
+        keep = 1.0 - prob
+        per_sample = torch.empty(self.seq.B, device=device, dtype=F32).bernoulli_(keep).div_(keep)
+        return per_sample[self.row2sample(device)].contiguous()
+
+
+class ExpertWeights:
+    """Pointers one modality expert contributes to a block evaluation (all tensors are parameters)."""
+
+    __slots__ = ("n1w", "n1b", "qkvw", "qb", "vb", "projw", "projb", "n2w", "n2b", "fc1w", "fc1b", "fc2w", "fc2b")
+
+
+class BlockPlan:
+    """Routing of one block evaluation: row ranges -> experts, attention mode.  Built by Block.plan()."""
+
+    def __init__(self, ranges, mode, gamma1, gamma2, layer, drop_prob, eps):
+        self.ranges = ranges      # list of (r0, r1, ExpertWeights)
+        self.mode = mode
+        self.gamma1, self.gamma2 = gamma1, gamma2
+        self.layer = layer
+        self.drop_prob = drop_prob
+        self.eps = eps
+
+
+def _qkv_bias(e):
+    # vision_transformer.py:335: cat(q_bias, zeros_like(v_bias), v_bias)
+    if e.qb is None:
+        return None
+    return torch.cat((e.qb.detach(), torch.zeros_like(e.vb), e.vb.detach()))
+
+
+class _BlockFn(torch.autograd.Function):
+    """One transformer block evaluation (LayerNorm -> QKV -> attention -> proj+LayerScale+residual -> LayerNorm ->
+    fc1+GELU -> fc2+LayerScale+residual), forward and hand-written backward over the HIP kernels.
+    Reference: Block.plain_forward / separate_plain_forward / moe_forward, vision_transformer.py:525-681."""
+
+    @staticmethod
+    def forward(ctx, x, bias_t, plan: BlockPlan, pc: PassCtx, training: bool, hook):
+        M, D = x.shape
+        dev = x.device
+        H = pc.H
+        Fdim = plan.ranges[0][2].fc1w.shape[0]
+        x = x.contiguous()
+        ln1 = torch.empty(M, D, device=dev, dtype=BF16)
+        st1 = torch.empty(M, 2, device=dev, dtype=F32)
+        qkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
+        rs1 = pc.drop_path_rows(plan.drop_prob, training, dev)
+        rs2 = pc.drop_path_rows(plan.drop_prob, training, dev)
+        for r0, r1, e in plan.ranges:
+            ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, ln1[r0:r1], st1[r0:r1])
+            ops.gemm(ln1[r0:r1], w16(e.qkvw), qkv[r0:r1], bias=_qkv_bias(e))
+        o = torch.empty(M, D, device=dev, dtype=BF16)
+        lse = torch.empty(H, M, device=dev, dtype=F32)
+        rp = pc.relpos
+        ops.attention_fwd(qkv, o, lse, pc.seq, H, bias_t=bias_t, head_row0=plan.layer * H,
+                          rel_index=rp.index if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
+                          mode=plan.mode)
+        x1 = torch.empty(M, D, device=dev, dtype=F32)
+        y1 = torch.empty(M, D, device=dev, dtype=BF16)
+        for r0, r1, e in plan.ranges:
+            ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
+                     row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
+        ln2 = torch.empty(M, D, device=dev, dtype=BF16)
+        st2 = torch.empty(M, 2, device=dev, dtype=F32)
+        h = torch.empty(M, Fdim, device=dev, dtype=BF16)
+        a = torch.empty(M, Fdim, device=dev, dtype=BF16)
+        x2 = torch.empty(M, D, device=dev, dtype=F32)
+        y2 = torch.empty(M, D, device=dev, dtype=BF16)
+        for r0, r1, e in plan.ranges:
+            ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
+            ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b, act=L.ACT_GELU, aux=h[r0:r1])
+            ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
+                     row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
+        ctx.plan, ctx.pc, ctx.hook = plan, pc, hook
+        ctx.has_bias = bias_t is not None
+        ctx.save_for_backward(x, st1, ln1, qkv, o, lse, y1, x1, st2, ln2, h, a, y2,
+                              rs1 if rs1 is not None else x.new_empty(0), rs2 if rs2 is not None else x.new_empty(0),
+                              bias_t if bias_t is not None else x.new_empty(0))
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        plan, pc = ctx.plan, ctx.pc
+        x, st1, ln1, qkv, o, lse, y1, x1, st2, ln2, h, a, y2, rs1, rs2, bias_t = ctx.saved_tensors
+        rs1 = rs1 if rs1.numel() else None
+        rs2 = rs2 if rs2.numel() else None
+        bias_t = bias_t if ctx.has_bias else None
+        M, D = x.shape
+        dev = x.device
+        H = pc.H
+        Fdim = h.shape[1]
+        dx2 = dx2.contiguous()
+        g1, g2 = plan.gamma1, plan.gamma2
+        dy = torch.empty(M, D, device=dev, dtype=BF16)
+        dh = torch.empty(M, Fdim, device=dev, dtype=BF16)
+        dln = torch.empty(M, D, device=dev, dtype=BF16)
+        dx1 = torch.empty(M, D, device=dev, dtype=F32)
+        # ---- FFN branch ----
+        for r0, r1, e in plan.ranges:
+            rr = slice(r0, r1)
+            ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy[rr], g2.grad, e.fc2b.grad)
+            ops.gemm(dy[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr])
+            ops.gemm(dy[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
+            ops.colsum(dh[rr], e.fc1b.grad)
+            ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
+            ops.gemm(dh[rr], w16(e.fc1w), dln[rr], tb=True)
+            ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
+                              dbeta=e.n2b.grad)
+        # ---- attention branch ----
+        do = torch.empty(M, D, device=dev, dtype=BF16)
+        for r0, r1, e in plan.ranges:
+            rr = slice(r0, r1)
+            ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy[rr], g1.grad, e.projb.grad)
+            ops.gemm(dy[rr], w16(e.projw), do[rr], tb=True)
+            ops.gemm(dy[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
+        dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
+        rp = pc.relpos
+        ops.attention_bwd(qkv, o, do, lse, dqkv, pc.seq, H, bias_t=bias_t, head_row0=plan.layer * H,
+                          rel_index=rp.index if rp is not None else None,
+                          rel_index_t=rp.index_t if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
+                          mode=plan.mode, dbias_t=rp.holder.get("dbias_t") if rp is not None else None)
+        dx = torch.empty(M, D, device=dev, dtype=F32)
+        for r0, r1, e in plan.ranges:
+            rr = slice(r0, r1)
+            if e.qb is not None:
+                ops.colsum(dqkv[rr, :D], e.qb.grad)
+                ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
+            ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
+            ops.gemm(dqkv[rr], w16(e.qkvw), dln[rr], tb=True)
+            ops.layernorm_bwd(dln[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad)
+        if ctx.hook is not None:
+            ctx.hook(plan.layer)
+        dbias = None
+        if bias_t is not None and ctx.needs_input_grad[1]:
+            # the real gradient sits in relpos.holder["dbias_t"]; autograd only needs a defined tensor to route
+            dbias = torch.zeros((), device=dev, dtype=F32).expand_as(bias_t)
+        return dx, dbias, None, None, None, None
+
+
+def run_block(x, plan: BlockPlan, pc: PassCtx, training: bool, hook=None):
+    bias_t = pc.relpos.bias_t if pc.relpos is not None else None
+    return _BlockFn.apply(x, bias_t, plan, pc, training, hook)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) through the MFMA GEMM; bf16 in/out, wgrad accumulated into W.grad in place.
+    Covers heads.py (Pooler.dense, ITMHead.fc, IFMHead.fc, MLMHead.transform.dense / decoder)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != BF16:
+            x2 = x2.to(BF16)
+        x2 = x2.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        Np = (N + 63) // 64 * 64
+        buf = torch.empty(M, Np, device=x.device, dtype=BF16)
+        pre = torch.empty(M, Np, device=x.device, dtype=BF16) if gelu else None
+        ops.gemm(x2, w16(weight), buf[:, :N], bias=bias, act=L.ACT_GELU if gelu else L.ACT_NONE,
+                 aux=pre[:, :N] if gelu else None)
+        ctx.save_for_backward(x2, pre if gelu else x2.new_empty(0))
+        ctx.weight, ctx.bias, ctx.gelu, ctx.shape, ctx.N, ctx.Np = weight, bias, gelu, x.shape, N, Np
+        return buf[:, :N].view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, pre = ctx.saved_tensors
+        weight, bias, N, Np = ctx.weight, ctx.bias, ctx.N, ctx.Np
+        M, K = x2.shape
+        dy = torch.zeros(M, Np, device=x2.device, dtype=BF16)
+        gy2 = gy.reshape(M, N)
+        if ctx.gelu:
+            hh = pre[:, :N].float().requires_grad_(True)
+            with torch.enable_grad():
+                act = torch.nn.functional.gelu(hh)
+            gy2 = torch.autograd.grad(act, hh, gy2.float())[0]
+        dy[:, :N].copy_(gy2)
+        if bias is not None and bias.requires_grad:
+            if N % 8 == 0:
+                ops.colsum(dy[:, :N], bias.grad)
+            else:
+                bias.grad.add_(dy[:, :N].float().sum(0))
+        if weight.requires_grad:
+            ops.gemm(dy[:, :N], x2, weight.grad, ta=True, tb=True, accumulate=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=x2.device, dtype=BF16)
+            if Np == N:
+                ops.gemm(dy, w16(weight), dx, tb=True)
+            else:
+                # ragged N (vocab 30522): the reduction runs over the zero-padded Np columns of dy; the weight rows
+                # past N are whatever follows in the flat buffer (finite), multiplied by those zeros
+                wpad = torch.as_strided(w16(weight), (Np, K), (K, 1))
+                ops.gemm(dy, wpad, dx, tb=True)
+            dx = dx.view(ctx.shape)
+        return dx, None, None, None
+
+
+def linear(x, weight, bias=None, gelu=False):
+    return _LinearFn.apply(x, weight, bias, gelu)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dim of a fp32 [rows, D] matrix, bf16 or fp32 out (transformer.norm, MLM transform)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_f32):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).float().contiguous()
+        M, D = x2.shape
+        y = torch.empty(M, D, device=x.device, dtype=F32 if out_f32 else BF16)
+        st = torch.empty(M, 2, device=x.device, dtype=F32)
+        ops.layernorm_fwd(x2, weight, bias, eps, y, st)
+        ctx.save_for_backward(x2, st)
+        ctx.weight, ctx.bias, ctx.shape, ctx.in_dtype = weight, bias, shape, x.dtype
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, st = ctx.saved_tensors
+        M, D = x2.shape
+        g2 = gy.reshape(M, D).contiguous()
+        if g2.dtype not in (BF16, F32):
+            g2 = g2.float()
+        dx = torch.empty(M, D, device=x2.device, dtype=F32)
+        ops.layernorm_bwd(g2, x2, st, ctx.weight, dx, dgamma=ctx.weight.grad if ctx.weight.requires_grad else None,
+                          dbeta=ctx.bias.grad if ctx.bias.requires_grad else None)
+        return dx.view(ctx.shape).to(ctx.in_dtype), None, None, None, None
+
+
+def layer_norm(x, weight, bias, eps, out_f32=False):
+    return _LayerNormFn.apply(x, weight, bias, eps, out_f32)
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    """PatchEmbed (vision_transformer.py:714-728) as im2col + MFMA GEMM; row 0 of every image is left for the cls
+    token (the GEMM writes `bias` there).  The image is a leaf: no dX."""
+
+    @staticmethod
+    def forward(ctx, image, weight, bias, patch):
+        B, C, Hh, Ww = image.shape
+        Dm = weight.shape[0]
+        rows = 1 + (Hh // patch) * (Ww // patch)
+        K = C * patch * patch
+        cols = torch.empty(B * rows, K, device=image.device, dtype=BF16)
+        ops.patch_im2col(image.contiguous().float(), cols, patch, 1)
+        out = torch.empty(B * rows, Dm, device=image.device, dtype=F32)
+        ops.gemm(cols, w16(weight).view(Dm, K), out, bias=bias)
+        ctx.save_for_backward(cols)
+        ctx.weight, ctx.bias, ctx.B, ctx.rows = weight, bias, B, rows
+        return out.view(B, rows, Dm)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (cols,) = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        Dm = weight.shape[0]
+        g = gy.reshape(-1, Dm)
+        g16 = torch.empty(g.shape, device=g.device, dtype=BF16)
+        g16.copy_(g)
+        # rows 0 of every image carry no patch (zero im2col row): they add nothing to dW; their bias share is
+        # excluded because the reference's conv never produced that row
+        gv = g16.view(ctx.B, ctx.rows, Dm)
+        gv[:, 0].zero_()
+        if weight.requires_grad:
+            ops.gemm(g16, cols, weight.grad.view(Dm, -1), ta=True, tb=True, accumulate=True)
+        if bias is not None and bias.requires_grad:
+            ops.colsum(g16, bias.grad)
+        return None, None, None, None
+
+
+def patch_embed(image, weight, bias, patch):
+    return _PatchEmbedFn.apply(image, weight, bias, patch)

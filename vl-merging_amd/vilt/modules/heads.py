@@ -1,0 +1,56 @@
+"""Heads of the hot-path losses (reference src/vilt/modules/heads.py:8-53), GEMMs on the MFMA kernel."""
+import torch
+import torch.nn as nn
+
+from ... import engine
+
+
+class Pooler(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.dense = nn.Linear(hidden_size, hidden_size)
+
+    def forward(self, hidden_states):
+        return torch.tanh(engine.linear(hidden_states[:, 0], self.dense.weight, self.dense.bias).float())
+
+
+class ITMHead(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.fc = nn.Linear(hidden_size, 2)
+
+    def forward(self, x):
+        return engine.linear(x, self.fc.weight, self.fc.bias)
+
+
+class IFMHead(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.fc = nn.Linear(hidden_size, hidden_size, bias=False)
+
+    def forward(self, x):
+        return engine.linear(x, self.fc.weight, None)
+
+
+class _PredictionHeadTransform(nn.Module):
+    """HF BertPredictionHeadTransform: dense -> gelu -> LayerNorm(eps=1e-12) (same parameter names)."""
+
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.dense = nn.Linear(hidden_size, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size, eps=eps)
+
+    def forward(self, x):
+        h = engine.linear(x, self.dense.weight, self.dense.bias, gelu=True)
+        return engine.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class MLMHead(nn.Module):
+    def __init__(self, hidden_size, vocab_size):
+        super().__init__()
+        self.transform = _PredictionHeadTransform(hidden_size)
+        self.decoder = nn.Linear(hidden_size, vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(vocab_size))
+
+    def forward(self, x):
+        return engine.linear(self.transform(x), self.decoder.weight, self.bias)

@@ -1,0 +1,123 @@
+"""Losses of the hot path (reference src/vilt/modules/objectives.py): compute_mlm :88, compute_ifm :248,
+compute_itm_hardneg :146, compute_irtr :372, init_weights :713.  The transformer passes and every GEMM run on the
+HIP kernels; the scalar loss algebra on [B, *] logits stays in torch.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def _gather_first_own(t):
+    """all_gather without autograd, own slice re-inserted at index 0 (objectives.py:269-286): gradients flow only
+    through the local features."""
+    world, rank = _world()
+    if world == 1:
+        return t
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t.detach().contiguous())
+    return torch.cat([t] + gathered[:rank] + gathered[rank + 1:])
+
+
+def init_weights(module):
+    if isinstance(module, (nn.Linear, nn.Embedding)):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+    if isinstance(module, nn.Linear) and module.bias is not None:
+        module.bias.data.zero_()
+
+
+def compute_mlm(pl_module, batch):
+    infer = pl_module.infer(batch, mask_text=True, mask_image=False)
+    mlm_logits = pl_module.mlm_score(infer["text_feats"])
+    mlm_labels = infer["text_labels"]
+    mlm_loss = F.cross_entropy(mlm_logits.float().view(-1, pl_module.hparams.config["vocab_size"]),
+                               mlm_labels.view(-1), ignore_index=-100)
+    return {"mlm_loss": mlm_loss * pl_module.hparams.config["vl_mlm_weight"], "mlm_logits": mlm_logits,
+            "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
+
+
+def _contrastive(image_features, text_features, logit_scale):
+    all_img = _gather_first_own(image_features)
+    all_txt = _gather_first_own(text_features)
+    logits_per_image = logit_scale * all_img @ all_txt.t()
+    return logits_per_image, logits_per_image.t()
+
+
+def _sym_ce(li, lt):
+    gt = torch.arange(len(li), device=li.device)
+    return (F.cross_entropy(li.float(), gt) + F.cross_entropy(lt.float(), gt)) / 2, gt
+
+
+def compute_ifm(pl_module, batch, aggregate=True):
+    infer_imag = pl_module.infer_image(batch, mask_image=False)
+    infer_text = pl_module.infer_text(batch, mask_text=False)
+    logit_scale = pl_module.logit_scale.exp().mean()
+    logit_vl_scale = pl_module.logit_vl_scale.exp().mean()
+    li, lt = _contrastive(infer_imag["cls_feats"], infer_text["cls_feats"], logit_scale)
+    lvi, lvt = _contrastive(infer_imag["cls_vlffn_feats"], infer_text["cls_vlffn_feats"], logit_vl_scale)
+    ifm_loss, gt = _sym_ce(li, lt)
+    ifm_vlffn_loss, _ = _sym_ce(lvi, lvt)
+    total = (pl_module.hparams.config["ifm_weight"] * ifm_loss + ifm_vlffn_loss) * 0.5
+    return {"ifm_loss": total, "ifm_i2t_logits": li, "ifm_t2i_logits": lt, "ifm_labels": gt,
+            "ifm_logit_scale": logit_scale, "ifm_logit_vl_scale": logit_vl_scale}
+
+
+def compute_irtr(pl_module, batch, aggregate=True):
+    infer_imag = pl_module.infer_image_ft(batch, mask_image=False)
+    infer_text = pl_module.infer_text_ft(batch, mask_text=False)
+    logit_scale = pl_module.logit_scale.exp().mean()
+    li, lt = _contrastive(infer_imag["cls_feats"], infer_text["cls_feats"], logit_scale)
+    loss, gt = _sym_ce(li, lt)
+    return {"irtr_loss": loss, "irtr_i2t_logits": li, "irtr_t2i_logits": lt, "irtr_labels": gt,
+            "irtr_logit_scale": logit_scale}
+
+
+def _gather_cat(t):
+    world, rank = _world()
+    if world == 1:
+        return t
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t.contiguous())
+    return torch.cat([t] + gathered[:rank] + gathered[rank + 1:])
+
+
+def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
+    """Hard-negative ITM (:146-245).  The reference draws each negative with a per-row torch.multinomial(...).item()
+    (2B host syncs); here ONE batched multinomial per direction and device-side gathers: same distribution, no
+    host round trip."""
+    bsz = batch["text_ids_mlm"].size(0)
+    dev = batch["text_ids"].device
+    itm_labels = torch.cat([torch.ones(bsz), torch.zeros(bsz), torch.zeros(bsz)]).to(dev)
+    infer_pos = pl_module.infer(batch, mask_text=False, mask_image=False)
+    with torch.no_grad():
+        all_text_ids = _gather_cat(infer_pos["text_ids"])
+        all_text_masks = _gather_cat(infer_pos["text_masks"])
+        all_image = _gather_cat(infer_pos["image"])
+        weights_i2t = F.softmax(sim_i2t[:bsz, :].float(), dim=1)
+        weights_t2i = F.softmax(sim_t2i[:bsz, :].float(), dim=1)
+        weights_i2t.fill_diagonal_(0)
+        weights_t2i.fill_diagonal_(0)
+        neg_img = torch.multinomial(weights_t2i, 1).squeeze(1)
+        neg_txt = torch.multinomial(weights_i2t, 1).squeeze(1)
+        images_neg = all_image[neg_img]
+        text_ids_neg = all_text_ids[neg_txt]
+        text_masks_neg = all_text_masks[neg_txt]
+    batch_imgs_neg = {"image": [images_neg], "text_ids": batch["text_ids"], "text_labels": batch["text_labels"],
+                      "text_masks": batch["text_masks"]}
+    infer_imags_neg = pl_module.infer(batch_imgs_neg, mask_text=False, mask_image=False)
+    batch_text_neg = {"image": batch["image"], "text_ids": text_ids_neg, "text_labels": batch["text_labels"],
+                      "text_masks": text_masks_neg}
+    infer_text_neg = pl_module.infer(batch_text_neg, mask_text=False, mask_image=False)
+    all_cls_feats = torch.cat([infer_pos["cls_feats"], infer_imags_neg["cls_feats"], infer_text_neg["cls_feats"]], dim=0)
+    itm_logits = pl_module.itm_score(all_cls_feats)
+    itm_loss = F.cross_entropy(itm_logits.float(), itm_labels.long())
+    return {"itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}

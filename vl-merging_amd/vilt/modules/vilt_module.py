@@ -1,0 +1,464 @@
+"""ViLTransformerSS: the reference's LightningModule surface (src/vilt/modules/vilt_module.py) on the MI355X engine.
+
+Same constructor signature, parameter / buffer names and shapes (reference checkpoints load with strict=False exactly
+as at vilt_module.py:293), same `infer*` / `forward` / `training_step` / merge method contracts.  pytorch_lightning is
+not required: the class is a plain nn.Module exposing the hooks the reference's Trainer calls.
+"""
+import math
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _lib as L
+from ... import engine
+from ... import merge as merge_ops
+from ... import ops
+from ... import regmean as regmean_ops
+from . import heads, objectives, vilt_utils
+from . import vision_transformer as vit
+
+
+class BertEmbeddings(nn.Module):
+    """Parameter layout of HF BertEmbeddings; forward = transformers-4.x semantics for
+    position_embedding_type="rel_pos" (vilt_module.py:51-63): word + bert-token-type(0) -> LayerNorm(1e-12) ->
+    dropout.  position_embeddings / position_ids are carried for checkpoint compatibility only."""
+
+    def __init__(self, vocab_size, hidden_size, max_position_embeddings, dropout, eps=1e-12):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab_size, hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(max_position_embeddings, hidden_size)
+        self.token_type_embeddings = nn.Embedding(2, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size, eps=eps)
+        self.dropout = nn.Dropout(dropout)
+        self.register_buffer("position_ids", torch.arange(max_position_embeddings).expand((1, -1)).clone())
+
+    def forward(self, input_ids):
+        emb = self.word_embeddings(input_ids) + self.token_type_embeddings.weight[0]
+        emb = engine.layer_norm(emb, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, out_f32=True)
+        return self.dropout(emb)
+
+
+def build_relative_position_indices(window, max_text_len, max_text_len_of_initckpt, max_vl_text_len=None):
+    """The integer index tables of vilt_module.py:123-206, bit-exact (int64 / float32 dtypes as in the reference)."""
+    gh, gw = window
+    num_rel = (2 * gh - 1) * (2 * gw - 1) + 3
+    text_num_rel = 2 * max_text_len_of_initckpt
+    all_num_rel = num_rel + text_num_rel + 2
+    coords = torch.stack(torch.meshgrid([torch.arange(gh), torch.arange(gw)], indexing="ij"))
+    flat = torch.flatten(coords, 1)
+    rel = (flat[:, :, None] - flat[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += gh - 1
+    rel[:, :, 1] += gw - 1
+    rel[:, :, 0] *= 2 * gw - 1
+    n_img = gh * gw + 1
+    rpi = torch.zeros((n_img, n_img), dtype=rel.dtype)
+    rpi[1:, 1:] = rel.sum(-1)
+    rpi[0, 0:] = num_rel - 3
+    rpi[0:, 0] = num_rel - 2
+    rpi[0, 0] = num_rel - 1
+    ids = torch.arange(max_text_len - 1)
+    trel = ids.unsqueeze(-2) - ids.unsqueeze(-1)
+    trel = trel - int(2 - max_text_len_of_initckpt) + (num_rel + 2)
+    tpi = torch.zeros((max_text_len, max_text_len), dtype=rel.dtype)
+    tpi[1:, 1:] = trel
+    tpi[0, 0:] = all_num_rel - 3
+    tpi[0:, 0] = all_num_rel - 2
+    tpi[0, 0] = all_num_rel - 1
+    t2i = torch.ones(max_text_len, n_img) * num_rel
+    i2t = torch.ones(n_img, max_text_len) * (num_rel + 1)
+    joint = torch.cat((torch.cat((tpi, t2i), 1), torch.cat((i2t, rpi), 1)), 0)
+    out = {"relative_position_index": rpi, "text_relative_position_index": tpi,
+           "text_imag_relative_position_index": joint}
+    if max_vl_text_len is not None:
+        v = max_vl_text_len
+        out["vl_text_imag_relative_position_index"] = torch.cat(
+            (torch.cat((tpi[:v, :v], t2i[:v]), 1), torch.cat((i2t[:, :v], rpi), 1)), 0)
+    return out, num_rel, text_num_rel, all_num_rel
+
+
+def _index16(index, n0):
+    """int16 index in kernel coordinates: text positions [0,n0), image positions start at pos1 = roundup(n0,4);
+    leading dimension padded to a multiple of 4.  Returns (index, transpose)."""
+    index = index.long()
+    n = index.shape[0]
+    n1 = n - n0
+    pos1 = (n0 + 3) // 4 * 4
+    NP = pos1 + n1
+    ld = (NP + 3) // 4 * 4
+    pos = torch.cat([torch.arange(n0), pos1 + torch.arange(n1)]).to(index.device)
+    m = torch.zeros(NP, ld, dtype=torch.int16, device=index.device)
+    mt = torch.zeros(NP, ld, dtype=torch.int16, device=index.device)
+    m[pos[:, None], pos[None, :]] = index.to(torch.int16)
+    mt[pos[:, None], pos[None, :]] = index.t().to(torch.int16)
+    return m.contiguous(), mt.contiguous()
+
+
+class ViLTransformerSS(nn.Module):
+    def __init__(self, config, ufo_config=None, ln_config=None, moe_config=None):
+        super().__init__()
+        import copy
+        self.hparams = types.SimpleNamespace(config=copy.deepcopy(config), ufo_config=ufo_config, ln_config=ln_config,
+                                             moe_config=moe_config)
+        config = self.hparams.config
+        hs = config["hidden_size"]
+        self.text_embeddings = BertEmbeddings(config["vocab_size"], hs, config["max_text_len"], config["drop_rate"])
+        self.text_embeddings.apply(objectives.init_weights)
+        self.token_type_embeddings = nn.Embedding(2, hs)
+        self.token_type_embeddings.apply(objectives.init_weights)
+        self.moe_config = moe_config
+        self.transformer = vit.create_vit(config["vit"], config=config, ufo_config=ufo_config, ln_config=ln_config,
+                                          moe_config=moe_config)
+        self.pooler = heads.Pooler(hs)
+        self.pooler.apply(objectives.init_weights)
+        ln_ = config["loss_names"]
+        if ln_["mlm"] > 0 or ln_["text_only_mlm"] > 0:
+            self.mlm_score = heads.MLMHead(hs, config["vocab_size"])
+            self.mlm_score.apply(objectives.init_weights)
+        if ln_["itm"] > 0:
+            self.itm_score = heads.ITMHead(hs)
+            self.itm_score.apply(objectives.init_weights)
+        if ln_["ifm"] > 0:
+            for nm in ("ifm_text_proj", "ifm_image_proj", "ifm_vl_text_proj", "ifm_vl_image_proj"):
+                setattr(self, nm, heads.IFMHead(hs))
+                getattr(self, nm).apply(objectives.init_weights)
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+            self.logit_vl_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        if ln_["irtr"] > 0:
+            for nm in ("ifm_text_proj", "ifm_image_proj"):
+                setattr(self, nm, heads.IFMHead(hs))
+                getattr(self, nm).apply(objectives.init_weights)
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        for k in ("mim", "image_only_mim", "vqa", "nlvr2", "img_cls"):
+            if ln_.get(k, 0) > 0:
+                raise NotImplementedError("loss %r is outside the MI355X hot path (SURVEY.md 2.1 #3/#13)" % k)
+
+        g = int(config["image_size"] / config["patch_size"])
+        self.window_size = (g, g)
+        self.max_text_len = config["max_text_len"]
+        self.max_vl_text_len = config["max_vl_text_len"]
+        self.max_imag_len = g * g + 1
+        idx, self.num_relative_distance, self.text_num_relative_distance, self.all_num_relative_distance = \
+            build_relative_position_indices(self.window_size, self.max_text_len, config["max_text_len_of_initckpt"],
+                                            self.max_vl_text_len)
+        self.relative_position_bias_table = nn.Parameter(
+            torch.zeros(self.all_num_relative_distance, config["num_heads"] * config["num_layers"]))
+        for k, v in idx.items():
+            self.register_buffer(k, v)
+        # "temporal" leftovers the reference keeps because its checkpoints contain them (vilt_module.py:189-265)
+        self.num_frames = config["num_frames"]
+        if self.num_frames >= 1:
+            nf, ni, T = self.num_frames, self.max_imag_len, self.max_text_len
+            t2i = torch.ones(T, ni * nf) * self.num_relative_distance
+            i2t = torch.ones(ni * nf, T) * (self.num_relative_distance + 1)
+            video = self.relative_position_index.repeat(nf, nf)
+            self.register_buffer("video_relative_position_index", video)
+            self.register_buffer("text_video_relative_position_index", torch.cat(
+                (torch.cat((self.text_relative_position_index, t2i), 1), torch.cat((i2t, video), 1)), 0))
+            self.temporal_relative_position_bias_table = nn.Parameter(
+                torch.zeros(2 * nf, config["num_heads"] * config["num_layers"]))
+            tid = torch.arange(nf)
+            trel = tid.unsqueeze(-2) - tid.unsqueeze(-1)
+            self.register_buffer("temporal_relative_position_index", (trel - trel.min()).repeat(ni, ni))
+            m = torch.eye(nf).repeat_interleave(ni, dim=1).repeat_interleave(ni, dim=0).unsqueeze(0)
+            self.register_buffer("mask_for_combining_temporal", m)
+            if self.max_vl_text_len is not None:
+                v = self.max_vl_text_len
+                self.register_buffer("vl_text_video_relative_position_index", torch.cat(
+                    (torch.cat((self.text_relative_position_index[:v, :v], t2i[:v]), 1),
+                     torch.cat((i2t[:, :v], video), 1)), 0))
+
+        self.vlffn_start_layer_index = config["vlffn_start_layer_index"]
+        self.num_layers = config["num_layers"]
+        self.current_tasks = []
+        self._flat = None
+        self._idx_cache = {}
+        self._grad_hook = None
+        self.trainer = None
+
+        # ---- checkpoint load / merge (vilt_module.py:270-295 and :345-364) -------------------------------------------
+        if config["load_path"] != "":
+            ckpt = torch.load(config["load_path"], map_location="cpu")
+            eval_only = config["test_only"] or config["validation_only"]
+            if config["use_beit_weight"] or config["use_self_weight"]:
+                raise NotImplementedError("BEiT / self checkpoint adaptation is a 'next' row (SURVEY.md 8f-2)")
+            state_dict = ckpt["state_dict"] if eval_only else self.modify_checkpoint_vlmo(ckpt)
+            if config["merge_weights"]:
+                state_dict = self.merge_weights(state_dict)
+            elif config["sum_task_vectors"]:
+                state_dict = self.sum_task_vectors(state_dict)
+            elif config["regmean"] and not eval_only:
+                state_dict = self.regmean(state_dict)
+            self.load_info = self.load_state_dict(state_dict, strict=False)
+
+    # ---- engine plumbing -----------------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.relative_position_bias_table.device
+
+    def setup_engine(self, grad_hook=None):
+        """Flatten parameters into the engine's fp32 / grad / bf16 buffers (GPU only) and build the bf16 shadows."""
+        if self.device.type != "cuda":
+            raise L.VlmError("ViLTransformerSS runs on the GPU only: call .cuda() before setup_engine()")
+        L.get_lib()
+        self._flat = engine.FlatParams(self, order_key=vilt_utils.flat_order_key)
+        self._flat.refresh_shadow()
+        self._grad_hook = grad_hook
+        return self._flat
+
+    def _ensure_engine(self):
+        if self._flat is None or self._flat.flat_p.device != self.device:
+            self.setup_engine(self._grad_hook)
+        elif self._flat.dirty:
+            self._flat.refresh_shadow()
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {k: (v.float() if torch.is_tensor(v) and v.dtype == torch.float64 else v) for k, v in state_dict.items()}
+        res = super().load_state_dict(sd, strict=strict)
+        if self._flat is not None:
+            self._flat.dirty = True
+        return res
+
+    def zero_grad(self, set_to_none=False):
+        if self._flat is not None:
+            self._flat.zero_grad()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    def mark_weights_changed(self):
+        if self._flat is not None:
+            self._flat.dirty = True
+
+    # ---- merging: same method contracts as the reference -----------------------------------------------------------------
+    def merge_weights(self, state_dict):
+        return merge_ops.merge_weights(state_dict, self.hparams.config, device=self._merge_device())
+
+    def sum_task_vectors(self, state_dict):
+        return merge_ops.sum_task_vectors(state_dict, self.hparams.config, device=self._merge_device())
+
+    def regmean(self, state_dict):
+        return regmean_ops.regmean(state_dict, self.hparams.config, device=self._merge_device())
+
+    def _merge_device(self):
+        return self.device if self.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+
+    def modify_checkpoint_vlmo(self, ckpt):
+        """vilt_module.py:749-806: text position truncation, index-buffer pruning, bicubic resize of the image part
+        of the relative-position table (27x27 -> 47x47 for 224 -> 384)."""
+        state_dict = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        key = "text_embeddings.position_embeddings.weight"
+        if state_dict[key].size(0) != self.max_text_len:
+            state_dict[key] = state_dict[key][: self.max_text_len, :]
+            if "text_embeddings.position_ids" in state_dict:
+                state_dict["text_embeddings.position_ids"] = state_dict["text_embeddings.position_ids"][:, : self.max_text_len]
+            for k in ("relative_position_index", "text_relative_position_index", "text_imag_relative_position_index"):
+                state_dict.pop(k)
+        rel = state_dict["relative_position_bias_table"]
+        src_num_pos = rel.size(0)
+        dst_num_pos = self.relative_position_bias_table.size(0)
+        non_image = self.text_num_relative_distance + 2 + 3
+        src_size = int((src_num_pos - non_image) ** 0.5)
+        dst_size = int((dst_num_pos - non_image) ** 0.5)
+        for k in ("relative_position_index", "text_relative_position_index", "text_imag_relative_position_index",
+                  "video_relative_position_index", "text_video_relative_position_index",
+                  "temporal_relative_position_index", "mask_for_combining_temporal"):
+            state_dict.pop(k, None)
+        if src_size != dst_size:
+            extra = rel[-non_image:, :]
+            body = rel[:-non_image, :]
+            embed = body.transpose(0, 1).reshape(-1, src_size, src_size)
+            embed = F.interpolate(embed.unsqueeze(0), size=(dst_size, dst_size), mode="bicubic")
+            embed = embed.squeeze(0).permute((1, 2, 0)).contiguous().view(-1, embed.size(1))
+            state_dict["relative_position_bias_table"] = torch.cat((embed, extra), dim=0)
+        return state_dict
+
+    # ---- relative position bias --------------------------------------------------------------------------------------------
+    def get_rel_pos_bias(self, relative_position_index, n_text=None):
+        """Reference :1061-1064 returns a dense [H*L, N, N] tensor; here: an engine.RelPos handle for the attention
+        kernel (the table's transpose + int16 index).  n_text = number of leading text positions of the index."""
+        name = None
+        for k in ("relative_position_index", "text_relative_position_index", "text_imag_relative_position_index",
+                  "vl_text_imag_relative_position_index"):
+            if hasattr(self, k) and getattr(self, k) is relative_position_index:
+                name = k
+        n = relative_position_index.shape[0]
+        if n_text is None:
+            n_text = {"relative_position_index": 0, "text_relative_position_index": n}.get(name, self.max_text_len)
+        key = (name, n, n_text, str(relative_position_index.device))
+        if name is None or key not in self._idx_cache:
+            pair = _index16(relative_position_index, n_text)
+            if name is None:
+                return engine.make_relpos(self.relative_position_bias_table, *pair)
+            self._idx_cache[key] = pair
+        return engine.make_relpos(self.relative_position_bias_table, *self._idx_cache[key])
+
+    # ---- embeddings ----------------------------------------------------------------------------------------------------
+    def _text_rows(self, text_ids, text_masks):
+        e = self.text_embeddings(text_ids)
+        e = e + self.token_type_embeddings(torch.zeros_like(text_masks))
+        return e.reshape(-1, e.shape[-1])
+
+    def _image_rows(self, img, image_token_type_idx=1, mask_image=False, bool_masked_pos=None):
+        x, x_mask, _, _ = self.transformer.visual_embed(img, max_image_len=self.hparams.config["max_image_len"],
+                                                        mask_it=mask_image, bool_masked_pos=bool_masked_pos)
+        x = x + self.token_type_embeddings.weight[image_token_type_idx]
+        return x.reshape(-1, x.shape[-1]), x_mask, x.shape[1]
+
+    def _final_norm(self, x):
+        n = self.transformer.norm
+        return engine.layer_norm(x, n.weight, n.bias, n.eps)
+
+    def _hook(self):
+        return self._grad_hook
+
+    # ---- passes ----------------------------------------------------------------------------------------------------------
+    def infer(self, batch, mask_text=False, mask_image=False, bool_masked_pos=None, image_token_type_idx=1,
+              image_embeds=None, image_masks=None):
+        """Joint text+image pass, reference :1071-1156."""
+        self._ensure_engine()
+        imgkey = f"image_{image_token_type_idx - 1}" if f"image_{image_token_type_idx - 1}" in batch else "image"
+        do_mlm = "_mlm" if mask_text else ""
+        text_ids = batch[f"text_ids{do_mlm}"]
+        text_labels = batch[f"text_labels{do_mlm}"]
+        text_masks = batch["text_masks"]
+        if image_embeds is not None or image_masks is not None:
+            raise NotImplementedError("precomputed image_embeds are not on the hot path")
+        img = batch[imgkey][0]
+        B, T = text_ids.shape
+        trows = self._text_rows(text_ids, text_masks)
+        irows, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+        image_masks = image_masks.type_as(text_masks)
+        x = torch.cat([trows, irows], 0)
+        index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
+            else self.text_imag_relative_position_index
+        pc = engine.PassCtx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
+                            keep0=text_masks.to(torch.uint8).contiguous())
+        for blk in self.transformer.blocks:
+            x = blk.run(x, pc, 2, self._hook())
+        x = self._final_norm(x)
+        D = x.shape[-1]
+        text_feats = x[: B * T].view(B, T, D)
+        image_feats = x[B * T:].view(B, I, D)
+        cls_feats = self.pooler(text_feats)
+        return {"text_feats": text_feats, "image_feats": image_feats, "cls_feats": cls_feats,
+                "raw_cls_feats": text_feats[:, 0], "image_labels": None, "image_masks": image_masks, "image": img,
+                "text_labels": text_labels, "text_ids": text_ids, "text_masks": text_masks, "patch_index": None}
+
+    def _unimodal(self, x, pc, type_id, with_vlffn):
+        hs = None
+        for i, blk in enumerate(self.transformer.blocks):
+            x = blk.run(x, pc, type_id, self._hook())
+            if i == self.vlffn_start_layer_index - 1:
+                hs = x
+        v = None
+        if with_vlffn:
+            v = hs
+            for i in range(self.vlffn_start_layer_index, self.num_layers):
+                v = self.transformer.blocks[i].run(v, pc, 2, self._hook())
+            v = self._final_norm(v)
+        return self._final_norm(x), v
+
+    @staticmethod
+    def _l2(x):
+        x = x.float()
+        return x / x.norm(dim=-1, keepdim=True)
+
+    def _infer_text(self, batch, mask_text, with_vlffn):
+        self._ensure_engine()
+        do_mlm = "_mlm" if mask_text else ""
+        text_ids = batch[f"text_ids{do_mlm}"]
+        text_labels = batch[f"text_labels{do_mlm}"]
+        text_masks = batch["text_masks"]
+        B, T = text_ids.shape
+        x = self._text_rows(text_ids, text_masks)
+        index = self.text_relative_position_index
+        if self.max_vl_text_len is not None and T != index.shape[0]:
+            index = index[:T, :T]
+        pc = engine.PassCtx(ops.Seq(B, T, 0), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
+                            keep0=text_masks.to(torch.uint8).contiguous())
+        l, v = self._unimodal(x, pc, 1, with_vlffn)
+        D = l.shape[-1]
+        l = l.view(B, T, D)
+        cls = self._l2(self.ifm_text_proj(l[:, 0])) if getattr(self, "ifm_text_proj", None) is not None else None
+        cls_v = None
+        if with_vlffn:
+            cls_v = self._l2(self.ifm_vl_text_proj(v.view(B, T, D)[:, 0]))
+        return {"text_feats": l, "image_feats": None, "cls_feats": cls, "cls_vlffn_feats": cls_v,
+                "raw_cls_feats": l[:, 0], "image_labels": None, "image_masks": None, "text_labels": text_labels,
+                "text_ids": text_ids, "text_masks": text_masks, "patch_index": None}
+
+    def infer_text(self, batch, mask_text=False):  # :1159-1223
+        return self._infer_text(batch, mask_text, True)
+
+    def infer_text_ft(self, batch, mask_text=False):  # :1226-1285
+        return self._infer_text(batch, mask_text, False)
+
+    def _infer_image(self, batch, mask_image, image_token_type_idx, bool_masked_pos, with_vlffn):
+        self._ensure_engine()
+        imgkey = f"image_{image_token_type_idx - 1}" if f"image_{image_token_type_idx - 1}" in batch else "image"
+        text_masks = batch["text_masks"]
+        img = batch[imgkey][0]
+        B = img.shape[0]
+        x, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+        image_masks = image_masks.type_as(text_masks)
+        pc = engine.PassCtx(ops.Seq(B, 0, I), self.hparams.config["num_heads"],
+                            self.get_rel_pos_bias(self.relative_position_index, 0))
+        vf, v = self._unimodal(x, pc, 0, with_vlffn)
+        D = vf.shape[-1]
+        vf = vf.view(B, I, D)
+        if getattr(self, "ifm_image_proj", None) is not None:
+            cls = self._l2(self.ifm_image_proj(vf[:, 0]))
+        else:
+            cls = self.pooler(vf)
+        cls_v = None
+        if with_vlffn:
+            cls_v = self._l2(self.ifm_vl_image_proj(v.view(B, I, D)[:, 0]))
+        return {"text_feats": None, "image_feats": vf, "cls_feats": cls, "cls_vlffn_feats": cls_v,
+                "raw_cls_feats": vf[:, 0], "image_labels": None, "image_masks": image_masks, "text_labels": None,
+                "text_ids": None, "text_masks": text_masks, "patch_index": None}
+
+    def infer_image(self, batch, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None,
+                    bool_masked_pos=None):  # :1287-1375
+        return self._infer_image(batch, mask_image, image_token_type_idx, bool_masked_pos, True)
+
+    def infer_image_ft(self, batch, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None,
+                       bool_masked_pos=None):  # :1378-1464
+        return self._infer_image(batch, mask_image, image_token_type_idx, bool_masked_pos, False)
+
+    # ---- task dispatch (vilt_module.py:1467-1530) ----------------------------------------------------------------------
+    def forward(self, batch):
+        ret = dict()
+        if len(self.current_tasks) == 0:
+            ret.update(self.infer(batch))
+            return ret
+        if self.hparams.config["tasks"] is not None:
+            if "vl" in batch:
+                batch = batch["vl"]
+            else:
+                return ret
+        if "mlm" in self.current_tasks:
+            ret.update(objectives.compute_mlm(self, batch))
+        if "ifm" in self.current_tasks:
+            ret.update(objectives.compute_ifm(self, batch))
+        if "irtr" in self.current_tasks:
+            ret.update(objectives.compute_irtr(self, batch))
+        if "itm" in self.current_tasks:
+            ret.update(objectives.compute_itm_hardneg(self, batch, ret["ifm_i2t_logits"], ret["ifm_t2i_logits"]))
+        return ret
+
+    def training_step(self, batch, batch_idx=0):
+        vilt_utils.set_task(self)
+        output = self(batch)
+        return sum([v for k, v in output.items() if "loss" in k])
+
+    def validation_step(self, batch, batch_idx=0):
+        vilt_utils.set_task(self)
+        return self(batch)
+
+    def log(self, *a, **k):  # LightningModule.log: observability, not on the hot path
+        pass
+
+    def configure_optimizers(self):
+        return vilt_utils.set_schedule(self)

@@ -1,0 +1,148 @@
+"""Optimizer / schedule of the hot path (reference src/vilt/modules/vilt_utils.py:218-359): set_task, the four
+parameter groups of set_schedule, HF-4.x AdamW and the polynomial-decay-with-warmup schedule, executed as ONE fused
+HIP AdamW launch per parameter group over the engine's flat buffers.
+"""
+import re
+
+import torch
+
+from ... import ops
+
+NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
+            "norm2.bias", "norm2.weight", "norm.v.bias", "norm.v.weight", "norm.l.bias", "norm.l.weight",
+            "norm.vl.bias", "norm.vl.weight"]  # vilt_utils.py:230-246
+
+
+def set_task(pl_module):
+    pl_module.current_tasks = [k for k, v in pl_module.hparams.config["loss_names"].items() if v >= 1]
+
+
+def head_names(config):
+    names = ["vqa_classifier", "nlvr2_classifier", "img_cls_classifier"]
+    if config["all_mlp_mult"]:
+        names.append("mlp")
+    if config["all_vl_mult"]:
+        names += ["attn.vl", "mlp.vl", "mlp_vl"]
+    if config["all_v_mult"]:
+        names += ["attn.v", "mlp.v"]
+    if config["all_l_mult"]:
+        names += ["attn.l", "mlp.l"]
+    return names
+
+
+def param_group_of(name, heads):
+    """0: decay/body, 1: no-decay/body, 2: decay/head, 3: no-decay/head (vilt_utils.py:272-312)."""
+    nd = any(s in name for s in NO_DECAY)
+    hd = any(s in name for s in heads)
+    return (2 if hd else 0) + (1 if nd else 0)
+
+
+_BLOCK = re.compile(r"transformer\.blocks\.(\d+)\.")
+
+
+def flat_order_key(name):
+    """Flat-buffer order: (optimizer group is resolved later) embeddings/table first, then blocks 0..L-1, then heads:
+    the reverse of the order in which backward finishes them, so DDP buckets are contiguous slices."""
+    m = _BLOCK.search(name)
+    if m:
+        # inside a block: decay group first, then no-decay -> two AdamW ranges per block instead of one per tensor
+        return (1, int(m.group(1)), param_group_of(name, ["vqa_classifier", "nlvr2_classifier", "img_cls_classifier"]),
+                name)
+    early = ("text_embeddings", "token_type_embeddings", "transformer.patch_embed", "transformer.cls_token",
+             "transformer.mask_token", "relative_position_bias_table", "temporal_relative_position_bias_table")
+    g = param_group_of(name, ["vqa_classifier", "nlvr2_classifier", "img_cls_classifier"])
+    if any(name.startswith(e) for e in early):
+        return (0, 0, g, name)
+    return (2, 0, g, name)
+
+
+def polynomial_decay_lambda(step, warmup, total, lr_init, lr_end=0.0, power=1.0):
+    """transformers.get_polynomial_decay_schedule_with_warmup's lr_lambda."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    if step > total:
+        return lr_end / lr_init
+    rem = 1 - (step - warmup) / (total - warmup)
+    return ((lr_init - lr_end) * rem ** power + lr_end) / lr_init
+
+
+class FusedAdamW:
+    """HF-4.x AdamW semantics (vilt_utils.py:314-317) over the flat buffers; param_groups mirrors torch optimizers."""
+
+    def __init__(self, pl_module, lr, betas, eps, groups):
+        self.flat = pl_module._flat
+        self.model = pl_module
+        self.betas, self.eps = betas, eps
+        self.param_groups = groups  # dicts: lr, weight_decay, initial_lr, ranges [(start, end)]
+        self.step_count = 0
+        self.m = torch.zeros_like(self.flat.flat_p)
+        self.v = torch.zeros_like(self.flat.flat_p)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self):
+        self.step_count += 1
+        f = self.flat
+        for g in self.param_groups:
+            for lo, hi in g["ranges"]:
+                ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], f.flat_b[lo:hi],
+                               g["lr"], self.betas[0], self.betas[1], self.eps, g["weight_decay"], self.step_count,
+                               grad_scale=self.grad_scale, zero_grad=True)
+        f.dirty = False  # the kernel refreshed the bf16 shadows
+
+
+class LambdaSchedule:
+    def __init__(self, optimizer, fn):
+        self.opt, self.fn, self.last = optimizer, fn, 0
+        for g in optimizer.param_groups:
+            g["lr"] = g["initial_lr"] * fn(0)
+
+    def step(self):
+        self.last += 1
+        for g in self.opt.param_groups:
+            g["lr"] = g["initial_lr"] * self.fn(self.last)
+
+
+def _merge_ranges(ranges):
+    ranges = sorted(ranges)
+    out = []
+    for lo, hi in ranges:
+        if out and out[-1][1] == lo:
+            out[-1] = (out[-1][0], hi)
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def set_schedule(pl_module, max_steps=None):
+    cfg = pl_module.hparams.config
+    pl_module._ensure_engine()
+    lr, wd = cfg["learning_rate"], cfg["weight_decay"]
+    heads = head_names(cfg)
+    spec = [(wd, lr), (0.0, lr), (cfg["weight_decay_custom_modules"], lr * cfg["lr_mult"]), (0.0, lr * cfg["lr_mult"])]
+    flat = pl_module._flat
+    buckets = [[] for _ in range(4)]
+    for n in flat.names:
+        o, k = flat.offsets[n]
+        buckets[param_group_of(n, heads)].append((o, o + (k + 63) // 64 * 64))
+    groups = [dict(lr=l_, initial_lr=l_, weight_decay=w_, ranges=_merge_ranges(b)) for (w_, l_), b in zip(spec, buckets)]
+    if cfg["optim_type"] != "adamw":
+        raise NotImplementedError("only optim_type='adamw' is on the hot path")
+    optimizer = FusedAdamW(pl_module, lr, (0.9, cfg["beta_2"]), 1e-8, groups)
+    if max_steps is None:
+        trainer = getattr(pl_module, "trainer", None)
+        max_steps = getattr(trainer, "max_steps", None) if trainer is not None else None
+        if max_steps is None or max_steps == -1:
+            max_steps = cfg["max_steps"]
+        if max_steps is None:
+            raise ValueError("max_steps must be given when the config leaves it to the dataloader length")
+    warmup = cfg["warmup_steps"]
+    if isinstance(warmup, float):
+        warmup = int(max_steps * warmup)
+    if cfg["decay_power"] == "cosine":
+        raise NotImplementedError("cosine schedule is not used by the hot-path configs")
+    sched = LambdaSchedule(optimizer, lambda s: polynomial_decay_lambda(s, warmup, max_steps, lr, cfg["end_lr"],
+                                                                        cfg["decay_power"]))
+    return [optimizer], [{"scheduler": sched, "interval": "step"}]
