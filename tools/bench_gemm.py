@@ -1,0 +1,49 @@
+"""GEMM micro-benchmark at the training shapes (M = 22*617 tokens)."""
+import importlib
+import sys
+
+import torch
+
+sys.path.insert(0, "/root/repo")
+import __graft_entry__ as ge
+
+ge.import_package()
+ops = importlib.import_module("vl_merging_amd.ops")
+L = importlib.import_module("vl_merging_amd._lib")
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    M = 22 * 617
+    shapes = [("qkv fwd", False, False, M, 2304, 768), ("proj fwd", False, False, M, 768, 768),
+              ("fc1 fwd", False, False, M, 3072, 768), ("fc2 fwd", False, False, M, 768, 3072),
+              ("fc1 dgrad", False, True, M, 768, 3072), ("fc2 dgrad", False, True, M, 3072, 768),
+              ("fc1 wgrad", True, True, 3072, 768, M), ("fc2 wgrad", True, True, 768, 3072, M),
+              ("qkv wgrad", True, True, 2304, 768, M), ("square 4096", False, False, 4096, 4096, 4096),
+              ("text qkv", False, False, 880, 2304, 768)]
+    tot_t = tot_f = 0
+    for name, ta, tb, m, n, k in shapes:
+        a = torch.randn((k, m) if ta else (m, k), device="cuda").to(torch.bfloat16)
+        b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
+        out = torch.empty(m, n, device="cuda", dtype=torch.float32 if ta else torch.bfloat16)
+        t = timeit(lambda: ops.gemm(a, b, out, ta, tb))
+        fl = 2.0 * m * n * k
+        print("%-12s M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s" % (name, m, n, k, t, fl / t / 1e6))
+        if "square" not in name:
+            tot_t += t; tot_f += fl
+    print("weighted over training shapes: %.1f TFLOP/s" % (tot_f / tot_t / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,16 +1,15 @@
-// Fused attention backward: recompute-based (flash style), three launches per (layer, pass):
+// Fused attention backward: recompute-based (flash style), four launches per (layer, pass):
 //   1. delta[h][row] = sum_d dO*O
 //   2. dQ kernel  (query-stationary, same structure as the forward; lane <-> query)
 //        S^T = K Q^T -> P^T = exp2(S2 - lse2) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ;
 //        dQ^T[d][q] += K^T . dS^T      (A = K^T by ds_read_b64_tr_b16, B = dS^T accumulator regs as bf16)
-//   3. dK/dV/dBias kernel (key-stationary; lane <-> key)
+//   3. dK/dV kernel (key-stationary; lane <-> key)
 //        S = Q K^T -> P ; dP = dO V^T ; dS = P o (dP - delta) ;
 //        dV[key][d] += P^T dO ,  dK[key][d] += scale * dS^T Q      (A = accumulator regs, B = dO / Q tr-read)
-//        d(bias table column)[idx[q][key]] += dS   through an LDS histogram (ds_add_f32), wave-reduced first where
-//        the whole 32x32 tile shares one index (all text->image pairs share ONE table row, vilt_module.py:180-181),
-//        flushed with one global atomic per touched bin per workgroup.
+//   4. dBias kernel (only when the bias table needs a gradient): batch-summed dS -> LDS histogram -> global atomics
 // This is what autograd derives for reference vision_transformer.py:346-358 + F.embedding in get_rel_pos_bias
-// (vilt_module.py:1061-1064); two extra MFMA products (7 instead of 5) buy a deterministic dQ without atomics.
+// (vilt_module.py:1061-1064); the extra MFMA products (9 instead of 5) buy a deterministic dQ without atomics and a
+// bias gradient whose (slow) LDS atomics are amortised over the batch.
 #include "vlm_common.h"
 #include "attention_common.h"
 
@@ -196,7 +195,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   unsigned char* ldsOt = smem + 3 * ATT_TILE_BYTES;     // dO tr image
   float* qstat = reinterpret_cast<float*>(smem + 4 * ATT_TILE_BYTES);  // [64] lse2 then [64] delta
   float* tab = qstat + 128;                                             // [R] bias column * log2e
-  float* hist = tab + ((p.R + 3) & ~3);                                 // [R] gradient histogram
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -231,10 +229,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   }
   if (HAS_BIAS) {
     const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
-    for (int i = tid; i < p.R; i += ATT_THREADS) {
-      tab[i] = col[i] * ATT_LOG2E;
-      hist[i] = 0.f;
-    }
+    for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
   }
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int16_t*>(bp.idx_t), 0, HAS_BIAS ? bp.idx_t_rows * bp.ld_idx_t * 2 : 0, 0x00020000);
@@ -290,15 +285,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
         const bf16x8 oa = att_k_rowfrag(ldsO, qb * 32 + r, 2 * ss + hh);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);  // dP[q][key]
       }
-      uint32_t ids[8];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int ql = qb * 32 + 8 * g4 + 4 * hh;  // local query row of element 0 of this group
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (HAS_BIAS) {
           const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(kpos * bp.ld_idx_t + qpos0 + ql) * 2, 0, 0);
-          ids[2 * g4] = w[0];
-          ids[2 * g4 + 1] = w[1];
           bv[0] = tab[w[0] & 0xffff];
           bv[1] = tab[w[0] >> 16];
           bv[2] = tab[w[1] & 0xffff];
@@ -312,27 +304,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
           const float pr = exp2f(v - ls[e]);
           s[4 * g4 + e] = pr;                               // P
           dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl[e]);   // dS (natural units, w.r.t. the biased score)
-        }
-      }
-      if (HAS_BIAS) {
-        // bias-table gradient: LDS histogram; a tile whose 16x64 indices all coincide is reduced in registers
-        bool same = true;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) same = same && (ids[i] == ids[0]) && ((ids[i] >> 16) == (ids[i] & 0xffff));
-        const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
-        same = same && (ids[0] == first);
-        if (__all(same)) {
-          float tsum = 0.f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) tsum += dp[i];
-          tsum = wave_sum(tsum);
-          if (lane == 0) atomicAdd(hist + (first & 0xffff), tsum);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const uint32_t w = ids[i >> 1];
-            atomicAdd(hist + ((i & 1) ? (w >> 16) : (w & 0xffff)), dp[i]);
-          }
         }
       }
       // dV += P^T dO ; dK += scale * dS^T Q   (A = accumulator regs as bf16, B = tr-read tiles)
@@ -377,13 +348,173 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       }
     }
   }
-  if (HAS_BIAS && bp.dbias_t) {
-    __syncthreads();
-    float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
+}
+
+// ---------------------------------------------------------------------------------------------- dBias kernel
+// d(bias table column)[idx[q][key]] += sum_b dS[b,h,q,key].  LDS float atomics cost ~300 cycles per wave instruction
+// on gfx950 (measured: the histogram inside the dK/dV kernel took 4x the rest of the backward), so the batch sum is
+// taken FIRST, in registers: one workgroup owns a (128-key, 64-query) tile pair of one head, loops over the B
+// samples recomputing S and dP (2 of the 7 MFMA products), and only then feeds the 8192 summed dS values through
+// the LDS histogram (B-fold fewer atomics), with the all-indices-equal tiles (text->image pairs share ONE table
+// row, vilt_module.py:180-181) reduced in registers instead.
+__global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const attn_bwd_params_t bp) {
+  const attn_params_t& p = bp.f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsQ = smem;              // [2][32 q][64 d] row image (4 KiB each)
+  unsigned char* ldsO = smem + 2 * 4096;   // [2] dO row image
+  float* qstat = reinterpret_cast<float*>(smem + 4 * 4096);  // [2][64]: lse2[32], delta[32]
+  float* tab = qstat + 128;
+  float* hist = tab + ((p.R + 3) & ~3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int h = blockIdx.y;
+  const attn_seq_t sq = p.seq;
+  const int D = p.H * 64;
+  const int nt0 = (sq.n0 + ATT_BQ - 1) / ATT_BQ;
+  int kt = blockIdx.x;
+  const int seg = kt >= nt0 ? 1 : 0;
+  if (seg) kt -= nt0;
+  const int nk = seg ? sq.n1 : sq.n0;
+  att_ranges_t qr = att_key_ranges(sq, p.mode, seg, 0, nullptr, nullptr);
+  // 32-row query tiles of the interacting ranges
+  const int ntq0 = (qr.n[0] + 31) >> 5, ntq1 = (qr.n[1] + 31) >> 5;
+  if ((int)blockIdx.z >= ntq0 + ntq1) return;  // block-uniform, before any barrier
+  const int rng = (int)blockIdx.z >= ntq0 ? 1 : 0;
+  const int q0 = (rng ? (int)blockIdx.z - ntq0 : (int)blockIdx.z) << 5;
+  const int qpos0 = qr.pos[rng] + q0;
+  const int qn = qr.n[rng];
+  const int qbase = qr.rowbase[rng];  // b = 0
+  const int key = kt * ATT_BQ + wave * 32 + r;
+  const bool kvalid = key < nk;
+  const int kc = kvalid ? key : nk - 1;
+  const int kpos = (seg ? sq.pos1 : 0) + kc;
+  const uint8_t* keep = seg ? p.keep1 : p.keep0;
+  const int kbase = seg ? sq.base1 : sq.base0;
+
+  {
+    const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
     for (int i = tid; i < p.R; i += ATT_THREADS) {
-      const float v = hist[i];
-      if (v != 0.f) atomicAdd(g + i, v);
+      tab[i] = col[i] * ATT_LOG2E;
+      hist[i] = 0.f;
     }
+  }
+  const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int16_t*>(bp.idx_t), 0, bp.idx_t_rows * bp.ld_idx_t * 2, 0x00020000);
+  // relative-position indices of this lane's 16 (q, key) pairs: independent of the sample
+  uint32_t ids[8];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(kpos * bp.ld_idx_t + qpos0 + 8 * g4 + 4 * hh) * 2, 0, 0);
+    ids[2 * g4] = w[0];
+    ids[2 * g4 + 1] = w[1];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  // staging: 32 rows x 128 B = 256 16-B pieces per tile -> one piece per thread per tile
+  u32x4 sq_, so_;
+  float s_st = 0.f;
+  const int srow = tid >> 3, schunk = tid & 7;
+  auto stage_load = [&](int b) {
+    const int rowbase = qbase + b * qn;
+    const int qq = q0 + srow;
+    if (qq < qn) {
+      sq_ = *reinterpret_cast<const u32x4*>(p.qkv + (size_t)(rowbase + qq) * p.ld_qkv + h * 64 + schunk * 8);
+      so_ = *reinterpret_cast<const u32x4*>(bp.d_o + (size_t)(rowbase + qq) * bp.ld_do + h * 64 + schunk * 8);
+    } else {
+      sq_ = so_ = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if (tid < 64) {  // threads 0..31: lse2, 32..63: delta
+      const int q2 = q0 + (tid & 31);
+      const bool ok = q2 < qn;
+      const size_t row = (size_t)rowbase + (ok ? q2 : 0);
+      const float* src = (tid < 32) ? bp.lse : bp.delta;
+      s_st = ok ? src[(size_t)h * p.total_rows + row] : (tid < 32 ? INFINITY : 0.f);
+    }
+  };
+  auto stage_store = [&](int buf) {
+    const int byte = srow * 128 + ((schunk ^ (srow & 7)) << 4);
+    *reinterpret_cast<u32x4*>(ldsQ + buf * 4096 + byte) = sq_;
+    *reinterpret_cast<u32x4*>(ldsO + buf * 4096 + byte) = so_;
+    if (tid < 64) qstat[buf * 64 + tid] = s_st;
+  };
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  const float c1 = p.scale * ATT_LOG2E;
+  for (int b = 0; b < sq.B; ++b) {
+    const int cur = b & 1;
+    bf16x8 kf[4], vf[4];
+    {
+      const size_t krow = (size_t)kbase + (size_t)b * nk + kc;
+      const bf16_t* kp = p.qkv + krow * p.ld_qkv + D + h * 64 + 8 * hh;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+        vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+      }
+    }
+    const bool kkeep = kvalid && (!keep || keep[(size_t)b * nk + kc] != 0);
+    const float kmaskv = kkeep ? 0.f : -INFINITY;
+    if (b + 1 < sq.B) stage_load(b + 1);
+    const unsigned char* lq = ldsQ + cur * 4096;
+    const unsigned char* lo = ldsO + cur * 4096;
+    const float* qs = qstat + cur * 64;
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      const bf16x8 a = att_k_rowfrag(lq, r, 2 * ss + hh);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ss], s, 0, 0, 0);
+      const bf16x8 oa = att_k_rowfrag(lo, r, 2 * ss + hh);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int ql = 8 * g4 + 4 * hh;
+      const uint32_t w0 = ids[2 * g4], w1 = ids[2 * g4 + 1];
+      const float bv[4] = {tab[w0 & 0xffff], tab[w0 >> 16], tab[w1 & 0xffff], tab[w1 >> 16]};
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(qs + ql);
+      const f32x4 dl = *reinterpret_cast<const f32x4*>(qs + 32 + ql);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + kmaskv;
+        const float pr = exp2f(v - ls[e]);
+        acc[4 * g4 + e] += pr * (dp[4 * g4 + e] - dl[e]);
+      }
+    }
+    if (b + 1 < sq.B) stage_store(cur ^ 1);
+    __syncthreads();
+  }
+  // ---- histogram of the batch-summed dS --------------------------------------------------------------------------
+  {
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) same = same && (ids[i] == ids[0]) && ((ids[i] >> 16) == (ids[i] & 0xffff));
+    const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
+    same = same && (ids[0] == first);
+    if (__all(same)) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tsum += acc[i];
+      tsum = wave_sum(tsum);
+      if (lane == 0) atomicAdd(hist + (first & 0xffff), tsum);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t w = ids[i >> 1];
+        atomicAdd(hist + ((i & 1) ? (w >> 16) : (w & 0xffff)), acc[i]);
+      }
+    }
+  }
+  __syncthreads();
+  float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
+  for (int i = tid; i < p.R; i += ATT_THREADS) {
+    const float v = hist[i];
+    if (v != 0.f) atomicAdd(g + i, v);
   }
 }
 
@@ -424,7 +555,8 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   dim3 grid(nt0 + nt1, p.H, p.seq.B), block(ATT_THREADS);
   const size_t Rp = (size_t)((p.R + 3) & ~3);
   const size_t smem_dq = 6 * ATT_TILE_BYTES + 512 + Rp * 4;
-  const size_t smem_dkv = 4 * ATT_TILE_BYTES + 512 + 2 * Rp * 4;
+  const size_t smem_dkv = 4 * ATT_TILE_BYTES + 512 + Rp * 4;
+  const size_t smem_db = 4 * 4096 + 512 + 2 * Rp * 4;
   if (smem_dq > 160 * 1024 || smem_dkv > 160 * 1024) return VLM_ERR_UNSUPPORTED;
   if (p.bias_t) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>),
@@ -435,6 +567,14 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, smem_dq, s, bp);
     VLM_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, smem_dkv, s, bp);
+    if (dbias_t) {
+      VLM_CHECK_LAUNCH();
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dbias_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_db) != hipSuccess)
+        return VLM_ERR_LAUNCH;
+      const int ntq = (p.seq.n0 + 31) / 32 + (p.seq.n1 + 31) / 32;  // upper bound of 32-row query tiles per key tile
+      hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(nt0 + nt1, p.H, ntq), block, smem_db, s, bp);
+    }
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, smem_dq, s, bp);
     VLM_CHECK_LAUNCH();

@@ -11,9 +11,8 @@
 //   wgrad     dW = dy^T x       : ta=1 tb=1   (reduction over tokens; fp32 out, accumulate)
 //
 // Tiling (gfx950): 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
-// Operands are staged global -> VGPR -> LDS (buffer_load_dwordx4 with hardware bounds check = free zero fill of
-// ragged M/N/K tails), double-buffered in LDS (2 x 32 KiB), next tile's loads issued before the current tile's
-// MFMAs (async-stage split).  K-contiguous operands live in LDS as [128][64] with a 16-B-chunk XOR swizzle
+// Operands are staged global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds; the descriptor's bounds check zero-fills
+// ragged M/N/K tails), double-buffered in LDS (2 x 32 KiB), next tile's DMA in flight during the current tile's MFMAs.  K-contiguous operands live in LDS as [128][64] with a 16-B-chunk XOR swizzle
 // (chunk ^= row & 7) and are read with ds_read_b128; K-strided operands live as [64][128] with a 32-B-chunk XOR
 // swizzle and are read transposed with ds_read_b64_tr_b16, so no operand is ever transposed in memory.
 // The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that each lane ends
@@ -35,42 +34,32 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-// ---- global -> register staging -----------------------------------------------------------------------------
-// K-contiguous operand: tile [128 rows][64 k]; piece p = tid + 256 u : row = p >> 3, chunk = p & 7
-// K-strided   operand: tile [64 k][128 x];    piece p = tid + 256 u : krow = p >> 4, c16 = p & 15
+// ---- global -> LDS staging by LDS-DMA (buffer_load_dwordx4 ... lds) ------------------------------------------------
+// ds_write_b128 moves only ~79 B/clk/CU (MI355X_MICROARCH.md, LDS table): register staging made the LDS pipe, not the
+// MFMAs, the bound (measured 311 TFLOP/s).  One wave instruction writes 1 KiB of LDS linearly (wave-uniform base +
+// lane*16 B) from a PER-LANE source address, so the XOR swizzles live on the source side (guide rule 21):
+//   K-contiguous tile [128 rows][64 k]: instruction j covers rows 8j..8j+7; lane -> row 8j + (lane>>3), LDS slot
+//     (lane&7) holds global chunk (lane&7) ^ (row&7)
+//   K-strided tile [64 k][128 x]: instruction j covers k-rows 4j..4j+3; lane -> krow 4j + (lane>>4), LDS 16-B slot
+//     (lane&15) holds global 32-B chunk ((lane&15)>>1) ^ (krow&3) ^ (((krow>>3)&1)<<2), same half
+// The buffer descriptor's bounds check zero-fills ragged M/N/K tails in flight.
+typedef __attribute__((address_space(3))) void lds_void;
 template <bool KSTRIDED>
-__device__ __forceinline__ void stage_load(u32x4 (&r)[4], __amdgpu_buffer_rsrc_t rsrc, uint32_t row0, uint32_t k0,
-                                           uint32_t ld, int tid) {
+__device__ __forceinline__ void stage_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* tile, uint32_t row0, uint32_t k0,
+                                          uint32_t ld, int wave, int lane) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const uint32_t p = tid + 256 * u;
+    const int j = wave + 4 * u;  // wave-uniform
     uint32_t off;
     if (!KSTRIDED) {
-      const uint32_t row = p >> 3, chunk = p & 7;
+      const uint32_t row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
       off = ((row0 + row) * ld + k0 + chunk * 8) * 2;
     } else {
-      const uint32_t krow = p >> 4, c16 = p & 15;
-      off = ((k0 + krow) * ld + row0 + c16 * 8) * 2;
+      const uint32_t krow = j * 4 + (lane >> 4), s16 = lane & 15;
+      const uint32_t c32 = (s16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
+      off = ((k0 + krow) * ld + row0 + (c32 * 2 + (s16 & 1)) * 8) * 2;
     }
-    r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-  }
-}
-
-template <bool KSTRIDED>
-__device__ __forceinline__ void stage_store(const u32x4 (&r)[4], unsigned char* lds, int tid) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t p = tid + 256 * u;
-    uint32_t byte;
-    if (!KSTRIDED) {
-      const uint32_t row = p >> 3, chunk = p & 7;
-      byte = row * 128 + ((chunk ^ (row & 7)) << 4);
-    } else {
-      const uint32_t krow = p >> 4, c16 = p & 15;
-      const uint32_t c32 = (c16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
-      byte = krow * 256 + c32 * 32 + (c16 & 1) * 16;
-    }
-    *reinterpret_cast<u32x4*>(lds + byte) = r[u];
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(tile + j * 1024), 16, off, 0, 0, 0);
   }
 }
 
@@ -141,19 +130,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 sa[4], sb[4];
   const int nk = (p.K + GEMM_BK - 1) / GEMM_BK;
-  stage_load<TA>(sa, ra, m0, 0, p.lda, tid);
-  stage_load<TB>(sb, rb, n0, 0, p.ldb, tid);
-  stage_store<TA>(sa, LDS_A(0), tid);
-  stage_store<TB>(sb, LDS_B(0), tid);
-  __syncthreads();
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  stage_dma<TA>(ra, LDS_A(0), m0, 0, p.lda, wave_u, lane);
+  stage_dma<TB>(rb, LDS_B(0), n0, 0, p.ldb, wave_u, lane);
+  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {  // issue next tile's global loads before this tile's MFMAs
-      stage_load<TA>(sa, ra, m0, (kt + 1) * GEMM_BK, p.lda, tid);
-      stage_load<TB>(sb, rb, n0, (kt + 1) * GEMM_BK, p.ldb, tid);
+    if (kt + 1 < nk) {  // next tile's DMA flies during this tile's MFMAs
+      stage_dma<TA>(ra, LDS_A(cur ^ 1), m0, (kt + 1) * GEMM_BK, p.lda, wave_u, lane);
+      stage_dma<TB>(rb, LDS_B(cur ^ 1), n0, (kt + 1) * GEMM_BK, p.ldb, wave_u, lane);
     }
     const unsigned char* la = LDS_A(cur);
     const unsigned char* lb = LDS_B(cur);
@@ -170,10 +157,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
         for (int j = 0; j < 4; ++j)
           // swapped: MFMA-A = weight rows (n), MFMA-B = activation rows (m) => D[n_local][m_local]
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      stage_store<TA>(sa, LDS_A(cur ^ 1), tid);
-      stage_store<TB>(sb, LDS_B(cur ^ 1), tid);
     }
     __syncthreads();
   }

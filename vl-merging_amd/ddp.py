@@ -13,6 +13,8 @@ import re
 import torch
 import torch.distributed as dist
 
+from . import engine
+
 _BLOCK = re.compile(r"transformer\.blocks\.(\d+)\.")
 
 
@@ -63,6 +65,9 @@ class FlatGradReducer:
         buf = self.flat.flat_g[lo:hi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            ws = engine.wgrad_stream()
+            if ws is not None:
+                self.comm_stream.wait_stream(ws)  # the slice's weight gradients are produced on the side stream
             with torch.cuda.stream(self.comm_stream):
                 self.handles.append(dist.all_reduce(buf, group=self.group, async_op=True))
         else:

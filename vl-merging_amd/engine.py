@@ -12,6 +12,7 @@ Design (MI355X-first, not a port of the reference's module-by-module autograd):
     (weights are shared by up to six passes per training step).
 """
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -67,6 +68,59 @@ class FlatParams:
         lo = min(self.offsets[n][0] for n in names)
         hi = max(self.offsets[n][0] + (self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
         return lo, hi
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# weight-gradient side stream: wgrad GEMMs (reduction over tokens, only 100-150 output tiles) are off the critical
+# path of backward and under-fill 256 CUs on their own; they run on a second HIP stream so the hardware co-schedules
+# them with the dgrad / attention kernels of the main stream.  The main stream re-joins at the end of backward.
+_WGRAD = {"stream": None, "enabled": os.environ.get("VLM_WGRAD_STREAM", "1") != "0", "pending": False}
+
+
+def wgrad_stream():
+    if not _WGRAD["enabled"]:
+        return None
+    if _WGRAD["stream"] is None:
+        _WGRAD["stream"] = torch.cuda.Stream()
+    return _WGRAD["stream"]
+
+
+def sync_wgrad():
+    """Make the current stream wait for every weight-gradient GEMM issued so far."""
+    if _WGRAD["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_WGRAD["stream"])
+    _WGRAD["pending"] = False
+
+
+def _arm_wgrad_join():
+    if not _WGRAD["pending"]:
+        _WGRAD["pending"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(sync_wgrad)
+
+
+class _Side:
+    """with _Side(tensors...): run the enclosed launches on the wgrad stream after everything issued so far."""
+
+    def __init__(self, *tensors):
+        self.s = wgrad_stream()
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if self.s is None:
+            return self
+        self.s.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(self.s)
+        _arm_wgrad_join()
+        self.ctx = torch.cuda.stream(self.s)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
 
 
 def w16(p):
@@ -234,18 +288,20 @@ class _BlockFn(torch.autograd.Function):
         Fdim = h.shape[1]
         dx2 = dx2.contiguous()
         g1, g2 = plan.gamma1, plan.gamma2
-        dy = torch.empty(M, D, device=dev, dtype=BF16)
+        dy2 = torch.empty(M, D, device=dev, dtype=BF16)
+        dy1 = torch.empty(M, D, device=dev, dtype=BF16)
         dh = torch.empty(M, Fdim, device=dev, dtype=BF16)
         dln = torch.empty(M, D, device=dev, dtype=BF16)
         dx1 = torch.empty(M, D, device=dev, dtype=F32)
         # ---- FFN branch ----
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
-            ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy[rr], g2.grad, e.fc2b.grad)
-            ops.gemm(dy[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr])
-            ops.gemm(dy[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
+            ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad)
+            ops.gemm(dy2[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr])
             ops.colsum(dh[rr], e.fc1b.grad)
-            ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
+            with _Side(dy2, a, dh, ln2):
+                ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
+                ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
             ops.gemm(dh[rr], w16(e.fc1w), dln[rr], tb=True)
             ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
                               dbeta=e.n2b.grad)
@@ -253,10 +309,12 @@ class _BlockFn(torch.autograd.Function):
         do = torch.empty(M, D, device=dev, dtype=BF16)
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
-            ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy[rr], g1.grad, e.projb.grad)
-            ops.gemm(dy[rr], w16(e.projw), do[rr], tb=True)
-            ops.gemm(dy[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
+            ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad)
+            ops.gemm(dy1[rr], w16(e.projw), do[rr], tb=True)
+            with _Side(dy1, o):
+                ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
+        dln1 = torch.empty(M, D, device=dev, dtype=BF16)
         rp = pc.relpos
         ops.attention_bwd(qkv, o, do, lse, dqkv, pc.seq, H, bias_t=bias_t, head_row0=plan.layer * H,
                           rel_index=rp.index if rp is not None else None,
@@ -268,9 +326,10 @@ class _BlockFn(torch.autograd.Function):
             if e.qb is not None:
                 ops.colsum(dqkv[rr, :D], e.qb.grad)
                 ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
-            ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
-            ops.gemm(dqkv[rr], w16(e.qkvw), dln[rr], tb=True)
-            ops.layernorm_bwd(dln[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad)
+            with _Side(dqkv, ln1):
+                ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
+            ops.gemm(dqkv[rr], w16(e.qkvw), dln1[rr], tb=True)
+            ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad)
         if ctx.hook is not None:
             ctx.hook(plan.layer)
         dbias = None

@@ -6,6 +6,7 @@ import re
 
 import torch
 
+from ... import engine
 from ... import ops
 
 NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
@@ -84,6 +85,7 @@ class FusedAdamW:
 
     def step(self):
         self.step_count += 1
+        engine.sync_wgrad()
         f = self.flat
         for g in self.param_groups:
             for lo, hi in g["ranges"]:
