@@ -99,6 +99,22 @@ def test_gemm_kstrided_ragged_k(ops):
     assert_close(out2, big[100:100 + K].float().t() @ bigx[100:100 + K].float(), 1e-3, 2e-3 * math.sqrt(K), "range")
 
 
+def test_gemm_wgrad_splitk(ops):
+    """wgrad at the training shape: reduction over 13 574 tokens into 6 x 24 output tiles -> split-K with fp32 atomic
+    accumulation (order-dependent rounding: tolerance as for any fp32 sum of ~13.5k terms)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(17)
+    K, M, N = 13574, 768, 3072
+    dy = bf(torch.randn(K, M, device="cuda", generator=gen))
+    x = bf(torch.randn(K, N, device="cuda", generator=gen))
+    ref = dy.float().t() @ x.float()
+    out = torch.full((M, N), 2.0, device="cuda")
+    ops.gemm(dy, x, out, True, True, accumulate=True)
+    assert_close(out, ref + 2.0, 1e-3, 2e-3 * math.sqrt(K), "split-K wgrad")
+    out2 = torch.zeros(M, 264, device="cuda")  # ragged N tile, narrow output
+    ops.gemm(dy, x[:, :264], out2, True, True, accumulate=True, alpha=0.5)
+    assert_close(out2, 0.5 * ref[:, :264], 1e-3, 2e-3 * math.sqrt(K), "split-K ragged")
+
+
 def test_gemm_epilogues(ops, L):
     gen = torch.Generator(device="cuda"); gen.manual_seed(11)
     M, N, K = 617 * 2, 768, 768

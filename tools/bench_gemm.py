@@ -37,7 +37,7 @@ def main():
         a = torch.randn((k, m) if ta else (m, k), device="cuda").to(torch.bfloat16)
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.float32 if ta else torch.bfloat16)
-        t = timeit(lambda: ops.gemm(a, b, out, ta, tb))
+        t = timeit(lambda: ops.gemm(a, b, out, ta, tb, accumulate=bool(ta)))
         fl = 2.0 * m * n * k
         print("%-12s M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s" % (name, m, n, k, t, fl / t / 1e6))
         if "square" not in name:

@@ -18,6 +18,7 @@
 // The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that each lane ends
 // up with 4 CONSECUTIVE output columns of one row: the epilogue then moves 16-B (fp32) / 8-B (bf16) vectors.
 #include "vlm_common.h"
+#include <stdlib.h>
 
 #define GEMM_BM 128
 #define GEMM_BN 128
@@ -27,11 +28,65 @@
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output's 2^-9): 1 rcp + 1 exp + 5 fma
+// instead of libm erff's ~40 instructions -- the epilogue of a K=768 GEMM is as long as its main loop otherwise.
+// ez2 returns exp(-z*z), which is also the Gaussian factor of gelu'.
+__device__ __forceinline__ float erf_as(float z, float& ez2) {
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  ez2 = __expf(-z * z);
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  const float e = fmaf(-poly * t, ez2, 1.0f);
+  return copysignf(e, z);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float ez2;
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float ez2;
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
+  return fmaf(x * 0.39894228040143267794f, ez2, cdf);
+}
+
+// ---- global -> register -> LDS staging (kept for K-strided operands, where it measured faster than LDS-DMA) ------
+template <bool KSTRIDED>
+__device__ __forceinline__ void stage_load(u32x4 (&r)[4], __amdgpu_buffer_rsrc_t rsrc, uint32_t row0, uint32_t k0,
+                                           uint32_t ld, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t p = tid + 256 * u;
+    uint32_t off;
+    if (!KSTRIDED) {
+      const uint32_t row = p >> 3, chunk = p & 7;
+      off = ((row0 + row) * ld + k0 + chunk * 8) * 2;
+    } else {
+      const uint32_t krow = p >> 4, c16 = p & 15;
+      off = ((k0 + krow) * ld + row0 + c16 * 8) * 2;
+    }
+    r[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+  }
+}
+
+template <bool KSTRIDED>
+__device__ __forceinline__ void stage_store(const u32x4 (&r)[4], unsigned char* lds, int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t p = tid + 256 * u;
+    uint32_t byte;
+    if (!KSTRIDED) {
+      const uint32_t row = p >> 3, chunk = p & 7;
+      byte = row * 128 + ((chunk ^ (row & 7)) << 4);
+    } else {
+      const uint32_t krow = p >> 4, c16 = p & 15;
+      const uint32_t c32 = (c16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
+      byte = krow * 256 + c32 * 32 + (c16 & 1) * 16;
+    }
+    *reinterpret_cast<u32x4*>(lds + byte) = r[u];
+  }
 }
 
 // ---- global -> LDS staging by LDS-DMA (buffer_load_dwordx4 ... lds) ------------------------------------------------
@@ -93,9 +148,14 @@ struct gemm_params_t {
   int lda, ldb, ldc;
   vlm_epilogue_t epi;
   int tiles_m, tiles_n;
+  int splits, ksteps_per_split;  // split-K (wgrad): block -> (tile, K slice), fp32 atomic accumulation
 };
 
-template <bool TA, bool TB, bool OUT_F32>
+// DMA_A / DMA_B: stage that operand by LDS-DMA (else through registers).  SPLITK: K is cut over gridDim.x / tiles
+// slices, the MFMA is issued un-swapped so that 16 consecutive lanes hold 16 consecutive output columns, and the
+// epilogue is a plain fp32 atomicAdd (C += alpha*acc): wgrad reduces over ~13.5k tokens into only 36-144 output
+// tiles, a single-pass grid leaves most of the 256 CUs idle and every resident workgroup latency-bound.
+template <bool TA, bool TB, bool OUT_F32, bool DMA_A, bool DMA_B, bool SPLITK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_params_t p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -105,10 +165,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
   // run of tiles with n fastest so a 128-row A panel is reused out of that XCD's L2 (bijective for any grid).
-  const uint32_t nblk = gridDim.x;
-  const uint32_t bid = blockIdx.x;
-  const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const uint32_t ntile = p.tiles_m * p.tiles_n;
+  uint32_t tile, split = 0;
+  if (SPLITK) {
+    tile = blockIdx.x % ntile;
+    split = blockIdx.x / ntile;
+  } else {
+    const uint32_t nblk = gridDim.x;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
   const uint32_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const uint32_t m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
@@ -130,17 +197,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + GEMM_BK - 1) / GEMM_BK;
+  const int nk_all = (p.K + GEMM_BK - 1) / GEMM_BK;
+  const int kt0 = SPLITK ? (int)split * p.ksteps_per_split : 0;
+  const int kt1 = SPLITK ? min(nk_all, kt0 + p.ksteps_per_split) : nk_all;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  stage_dma<TA>(ra, LDS_A(0), m0, 0, p.lda, wave_u, lane);
-  stage_dma<TB>(rb, LDS_B(0), n0, 0, p.ldb, wave_u, lane);
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  u32x4 sa[4], sb[4];
+  if (kt0 < kt1) {
+    if (DMA_A) stage_dma<TA>(ra, LDS_A(0), m0, kt0 * GEMM_BK, p.lda, wave_u, lane);
+    else { stage_load<TA>(sa, ra, m0, kt0 * GEMM_BK, p.lda, tid); stage_store<TA>(sa, LDS_A(0), tid); }
+    if (DMA_B) stage_dma<TB>(rb, LDS_B(0), n0, kt0 * GEMM_BK, p.ldb, wave_u, lane);
+    else { stage_load<TB>(sb, rb, n0, kt0 * GEMM_BK, p.ldb, tid); stage_store<TB>(sb, LDS_B(0), tid); }
+  }
+  __syncthreads();  // hipcc drains a pending LDS-DMA (vmcnt(0)) in front of the barrier
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {  // next tile's DMA flies during this tile's MFMAs
-      stage_dma<TA>(ra, LDS_A(cur ^ 1), m0, (kt + 1) * GEMM_BK, p.lda, wave_u, lane);
-      stage_dma<TB>(rb, LDS_B(cur ^ 1), n0, (kt + 1) * GEMM_BK, p.ldb, wave_u, lane);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) {  // next tile's loads fly during this tile's MFMAs
+      if (DMA_A) stage_dma<TA>(ra, LDS_A(cur ^ 1), m0, (kt + 1) * GEMM_BK, p.lda, wave_u, lane);
+      else stage_load<TA>(sa, ra, m0, (kt + 1) * GEMM_BK, p.lda, tid);
+      if (DMA_B) stage_dma<TB>(rb, LDS_B(cur ^ 1), n0, (kt + 1) * GEMM_BK, p.ldb, wave_u, lane);
+      else stage_load<TB>(sb, rb, n0, (kt + 1) * GEMM_BK, p.ldb, tid);
     }
     const unsigned char* la = LDS_A(cur);
     const unsigned char* lb = LDS_B(cur);
@@ -154,11 +230,34 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // swapped: MFMA-A = weight rows (n), MFMA-B = activation rows (m) => D[n_local][m_local]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          if (SPLITK)  // un-swapped: D[m_local = 4*(lane>>4)+r][n_local = lane&15]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          else  // swapped: MFMA-A = weight rows (n), MFMA-B = activation rows (m) => D[n_local][m_local]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < kt1) {
+      if (!DMA_A) stage_store<TA>(sa, LDS_A(cur ^ 1), tid);
+      if (!DMA_B) stage_store<TB>(sb, LDS_B(cur ^ 1), tid);
     }
     __syncthreads();
+  }
+
+  if (SPLITK) {
+    float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+          if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.epi.alpha);
+        }
+      }
+    return;
   }
 
   // ---- epilogue: lane holds rows m = ..+(lane&15), columns n = ..+(lane>>4)*4 + r ------------------------------
@@ -253,20 +352,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
   }
 }
 
-template <bool TA, bool TB, bool OUT_F32>
+template <bool TA, bool TB, bool OUT_F32, bool DMA_A, bool DMA_B, bool SPLITK>
 static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
   const size_t smem = 4 * GEMM_TILE_BYTES;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_kernel<TA, TB, OUT_F32>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_kernel<TA, TB, OUT_F32, DMA_A, DMA_B, SPLITK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return VLM_ERR_LAUNCH;
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
-  hipLaunchKernelGGL((vlm_gemm_kernel<TA, TB, OUT_F32>), grid, block, smem, stream, p);
+  dim3 grid(p.tiles_m * p.tiles_n * (SPLITK ? p.splits : 1)), block(GEMM_THREADS);
+  hipLaunchKernelGGL((vlm_gemm_kernel<TA, TB, OUT_F32, DMA_A, DMA_B, SPLITK>), grid, block, smem, stream, p);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
+}
+
+// staging policy: K-contiguous operands by LDS-DMA, K-strided operands through registers (VLM_GEMM_STAGE: 0 = all
+// registers, 1 = all DMA, 2 = hybrid [default]); VLM_GEMM_SPLITK=0 disables split-K
+static int gemm_stage_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("VLM_GEMM_STAGE");
+    mode = e ? atoi(e) : 2;
+  }
+  return mode;
+}
+static int gemm_splitk_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VLM_GEMM_SPLITK");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+template <bool TA, bool TB, bool OUT_F32>
+static int dispatch_stage(const gemm_params_t& p, hipStream_t s) {
+  const int mode = gemm_stage_mode();
+  const bool da = mode == 1 || (mode == 2 && !TA), db = mode == 1 || (mode == 2 && !TB);
+  if (da && db) return launch_gemm<TA, TB, OUT_F32, true, true, false>(p, s);
+  if (da) return launch_gemm<TA, TB, OUT_F32, true, false, false>(p, s);
+  if (db) return launch_gemm<TA, TB, OUT_F32, false, true, false>(p, s);
+  return launch_gemm<TA, TB, OUT_F32, false, false, false>(p, s);
 }
 
 extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
@@ -290,16 +418,33 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   p.epi = *epi;
   p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  p.splits = 1;
+  p.ksteps_per_split = 0;
   hipStream_t s = (hipStream_t)stream;
+  // split-K: pure accumulation into fp32 (wgrad), few output tiles, long reduction
+  const int ntile = p.tiles_m * p.tiles_n, nk = (K + GEMM_BK - 1) / GEMM_BK;
+  const bool plain_acc = epi->accumulate && c_is_f32 && !epi->bias && !epi->col_scale && !epi->row_scale &&
+                         !epi->residual && !epi->aux && epi->act == VLM_ACT_NONE;
+  if (gemm_splitk_enabled() && ta && tb && plain_acc && ntile < 512 && nk >= 32) {
+    int cus = vlm_device_cus();
+    if (cus <= 0) cus = 256;
+    int splits = (3 * cus + ntile - 1) / ntile;          // ~3 workgroups per CU in flight
+    if (splits > nk / 8) splits = nk / 8;                // keep >= 8 K-steps per slice
+    if (splits > 1) {
+      p.ksteps_per_split = (nk + splits - 1) / splits;
+      p.splits = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
+      return launch_gemm<true, true, true, false, false, true>(p, s);
+    }
+  }
   const int key = (ta ? 4 : 0) | (tb ? 2 : 0) | (c_is_f32 ? 1 : 0);
   switch (key) {
-    case 0: return launch_gemm<false, false, false>(p, s);
-    case 1: return launch_gemm<false, false, true>(p, s);
-    case 2: return launch_gemm<false, true, false>(p, s);
-    case 3: return launch_gemm<false, true, true>(p, s);
-    case 4: return launch_gemm<true, false, false>(p, s);
-    case 5: return launch_gemm<true, false, true>(p, s);
-    case 6: return launch_gemm<true, true, false>(p, s);
-    default: return launch_gemm<true, true, true>(p, s);
+    case 0: return dispatch_stage<false, false, false>(p, s);
+    case 1: return dispatch_stage<false, false, true>(p, s);
+    case 2: return dispatch_stage<false, true, false>(p, s);
+    case 3: return dispatch_stage<false, true, true>(p, s);
+    case 4: return dispatch_stage<true, false, false>(p, s);
+    case 5: return dispatch_stage<true, false, true>(p, s);
+    case 6: return dispatch_stage<true, true, false>(p, s);
+    default: return dispatch_stage<true, true, true>(p, s);
   }
 }
