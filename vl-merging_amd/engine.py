@@ -74,7 +74,7 @@ class FlatParams:
 # weight-gradient side stream: wgrad GEMMs (reduction over tokens, only 100-150 output tiles) are off the critical
 # path of backward and under-fill 256 CUs on their own; they run on a second HIP stream so the hardware co-schedules
 # them with the dgrad / attention kernels of the main stream.  The main stream re-joins at the end of backward.
-_WGRAD = {"stream": None, "enabled": os.environ.get("VLM_WGRAD_STREAM", "1") != "0", "pending": False}
+_WGRAD = {"stream": None, "enabled": os.environ.get("VLM_WGRAD_STREAM", "0") != "0", "pending": False}
 
 
 def wgrad_stream():

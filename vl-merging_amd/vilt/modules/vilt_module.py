@@ -173,6 +173,7 @@ class ViLTransformerSS(nn.Module):
         self.vlffn_start_layer_index = config["vlffn_start_layer_index"]
         self.num_layers = config["num_layers"]
         self.current_tasks = []
+        self.fuse_joint_passes = True  # engine option, not a reference config key
         self._flat = None
         self._idx_cache = {}
         self._grad_hook = None
@@ -438,13 +439,17 @@ class ViLTransformerSS(nn.Module):
                 batch = batch["vl"]
             else:
                 return ret
-        if "mlm" in self.current_tasks:
+        fuse = self.fuse_joint_passes and all(t in self.current_tasks for t in ("mlm", "itm", "ifm"))
+        if "mlm" in self.current_tasks and not fuse:
             ret.update(objectives.compute_mlm(self, batch))
         if "ifm" in self.current_tasks:
             ret.update(objectives.compute_ifm(self, batch))
         if "irtr" in self.current_tasks:
             ret.update(objectives.compute_irtr(self, batch))
-        if "itm" in self.current_tasks:
+        if fuse:
+            # the four joint passes of mlm + itm as one 4B-sample pass (same losses, see compute_mlm_itm_fused)
+            ret.update(objectives.compute_mlm_itm_fused(self, batch, ret["ifm_i2t_logits"], ret["ifm_t2i_logits"]))
+        elif "itm" in self.current_tasks:
             ret.update(objectives.compute_itm_hardneg(self, batch, ret["ifm_i2t_logits"], ret["ifm_t2i_logits"]))
         return ret
 
