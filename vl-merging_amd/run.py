@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""`python run.py with <named configs> key=value ...` -- the reference's entry point (src/run.py:141-295) for the
+hot path: builds the model from the sacred-style config and runs training steps on synthetic batches
+(the data modules of the reference are outside the hot path).
+
+Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 run.py with ...`.
+"""
+import importlib
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+
+def main(argv):
+    ge.import_package()
+    cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
+    vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
+    vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
+    ddp = importlib.import_module("vl_merging_amd.ddp")
+    sys.path.insert(0, ROOT)
+    from bench import synthetic_batch
+    steps = 10
+    rest = []
+    for a in argv:
+        if a.startswith("steps="):
+            steps = int(a.split("=", 1)[1])
+        else:
+            rest.append(a)
+    cfg = cfgmod.parse_cli(rest)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.manual_seed(cfg["seed"])
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).cuda()
+    model.train()
+    model.setup_engine()
+    (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"] or 100000)
+    red = ddp.FlatGradReducer(model)
+    opt.grad_scale = red.grad_scale
+    B = cfg["per_gpu_batchsize"] or 2
+    batch = synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, "cuda")
+    if cfg["tasks"] is None:
+        batch = batch["vl"]
+    for it in range(steps):
+        t0 = time.time()
+        red.begin_step()
+        loss = model.training_step(batch, it)
+        loss.backward()
+        red.finish_backward()
+        opt.step()
+        sch["scheduler"].step()
+        if rank == 0:
+            print("step %d loss %.4f  %.1f ms" % (it, float(loss.detach()), (time.time() - t0) * 1e3), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
