@@ -99,6 +99,26 @@ def test_gemm_kstrided_ragged_k(ops):
     assert_close(out2, big[100:100 + K].float().t() @ bigx[100:100 + K].float(), 1e-3, 2e-3 * math.sqrt(K), "range")
 
 
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("M,N,K", [(13574, 3072, 768), (13574, 2304, 768), (54296, 768, 3072), (13574 * 2, 1536, 64)])
+def test_gemm_big_tile_kernel(ops, L, tb, M, N, K):
+    """Shapes with >= 512 tiles of 256x128 take the three-stage LDS-ring kernel (ragged M: 13574 = 53*256 + 6)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N + K + tb)
+    A, B, ref = make_ab(M, N, K, False, tb, gen)
+    ref = ref * 0.05
+    bias = torch.randn(N, device="cuda", generator=gen)
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    gamma = torch.randn(N, device="cuda", generator=gen) * 0.1
+    out = torch.empty(M, N, device="cuda")
+    aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, out, False, tb, bias=bias, col_scale=gamma, residual=res, aux=aux, alpha=0.05)
+    assert_close(aux, ref + bias, 1e-2, 1e-2, "big aux")
+    assert_close(out, res + gamma[None] * (ref + bias), 1e-3, 5e-3, "big epilogue")
+    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, h, False, tb, bias=bias, act=L.ACT_GELU, alpha=0.05)
+    assert_close(h, torch.nn.functional.gelu(ref + bias), 1e-2, 1e-2, "big gelu")
+
+
 def test_gemm_wgrad_splitk(ops):
     """wgrad at the training shape: reduction over 13 574 tokens into 6 x 24 output tiles -> split-K with fp32 atomic
     accumulation (order-dependent rounding: tolerance as for any fp32 sum of ~13.5k terms)."""

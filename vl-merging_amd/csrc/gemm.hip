@@ -151,6 +151,101 @@ struct gemm_params_t {
   int splits, ksteps_per_split;  // split-K (wgrad): block -> (tile, K slice), fp32 atomic accumulation
 };
 
+// ---- fused epilogue of one wave's 64x64 sub-tile (swapped layout: lane holds row m = mw0 + 16i + (lane&15) and the
+// 4 consecutive columns n = nw0 + 16j + 4*(lane>>4) + r) -----------------------------------------------------------
+template <bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x4 (&acc)[4][4], int mw0, int nw0, int lane) {
+  const vlm_epilogue_t& e = p.epi;
+  // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
+  const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mw0 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const float rs = e.row_scale ? e.row_scale[m] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nw0 + j * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+      const bool full = vec_ok && (n + 3 < p.N);
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha;
+      if (full) {
+        if (e.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += b[r];
+        }
+        if (e.act == VLM_ACT_GELU_BWD) {
+          const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)h[r]);
+        } else {
+          if (e.aux) {
+            bf16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n) = h;
+          }
+          if (e.act == VLM_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          }
+        }
+        if (e.col_scale) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(e.col_scale + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= g[r];
+        }
+        if (e.row_scale) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= rs;
+        }
+        if (e.residual) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(e.residual + (size_t)m * e.ld_res + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += x[r];
+        }
+        if (OUT_F32) {
+          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          if (e.accumulate) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(c);
+            o += old;
+          }
+          *reinterpret_cast<f32x4*>(c) = o;
+        } else {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = o;
+        }
+      } else {  // ragged N tail: scalar path
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+          float x = v[r];
+          if (e.bias) x += e.bias[n + r];
+          if (e.act == VLM_ACT_GELU_BWD) {
+            x *= gelu_erf_grad((float)reinterpret_cast<const bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r]);
+          } else {
+            if (e.aux) reinterpret_cast<bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r] = (bf16_t)x;
+            if (e.act == VLM_ACT_GELU) x = gelu_erf(x);
+          }
+          if (e.col_scale) x *= e.col_scale[n + r];
+          if (e.row_scale) x *= rs;
+          if (e.residual) x += e.residual[(size_t)m * e.ld_res + n + r];
+          if (OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n + r;
+            *c = e.accumulate ? (*c + x) : x;
+          } else {
+            reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n + r] = (bf16_t)x;
+          }
+        }
+      }
+    }
+  }
+}
+
 // DMA_A / DMA_B: stage that operand by LDS-DMA (else through registers).  SPLITK: K is cut over gridDim.x / tiles
 // slices, the MFMA is issued un-swapped so that 16 consecutive lanes hold 16 consecutive output columns, and the
 // epilogue is a plain fp32 atomicAdd (C += alpha*acc): wgrad reduces over ~13.5k tokens into only 36-144 output
@@ -260,96 +355,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     return;
   }
 
-  // ---- epilogue: lane holds rows m = ..+(lane&15), columns n = ..+(lane>>4)*4 + r ------------------------------
-  const vlm_epilogue_t& e = p.epi;
-  // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
-  const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    const float rs = e.row_scale ? e.row_scale[m] : 1.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-      const bool full = vec_ok && (n + 3 < p.N);
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha;
-      if (full) {
-        if (e.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += b[r];
-        }
-        if (e.act == VLM_ACT_GELU_BWD) {
-          const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)h[r]);
-        } else {
-          if (e.aux) {
-            bf16x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n) = h;
-          }
-          if (e.act == VLM_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-          }
-        }
-        if (e.col_scale) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(e.col_scale + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= g[r];
-        }
-        if (e.row_scale) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= rs;
-        }
-        if (e.residual) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(e.residual + (size_t)m * e.ld_res + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += x[r];
-        }
-        if (OUT_F32) {
-          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          if (e.accumulate) {
-            const f32x4 old = *reinterpret_cast<const f32x4*>(c);
-            o += old;
-          }
-          *reinterpret_cast<f32x4*>(c) = o;
-        } else {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) = o;
-        }
-      } else {  // ragged N tail: scalar path
-        for (int r = 0; r < 4 && n + r < p.N; ++r) {
-          float x = v[r];
-          if (e.bias) x += e.bias[n + r];
-          if (e.act == VLM_ACT_GELU_BWD) {
-            x *= gelu_erf_grad((float)reinterpret_cast<const bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r]);
-          } else {
-            if (e.aux) reinterpret_cast<bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r] = (bf16_t)x;
-            if (e.act == VLM_ACT_GELU) x = gelu_erf(x);
-          }
-          if (e.col_scale) x *= e.col_scale[n + r];
-          if (e.row_scale) x *= rs;
-          if (e.residual) x += e.residual[(size_t)m * e.ld_res + n + r];
-          if (OUT_F32) {
-            float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n + r;
-            *c = e.accumulate ? (*c + x) : x;
-          } else {
-            reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n + r] = (bf16_t)x;
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <bool TA, bool TB, bool OUT_F32, bool DMA_A, bool DMA_B, bool SPLITK>
@@ -364,6 +370,120 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
   }
   dim3 grid(p.tiles_m * p.tiles_n * (SPLITK ? p.splits : 1)), block(GEMM_THREADS);
   hipLaunchKernelGGL((vlm_gemm_kernel<TA, TB, OUT_F32, DMA_A, DMA_B, SPLITK>), grid, block, smem, stream, p);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ======================================================================================================================
+// 256x128x64 tile, 8 waves (4x2, 64x64 each), THREE-stage LDS ring (3 x 48 KiB) filled by LDS-DMA with a counted
+// s_waitcnt: the 128x128 kernel above has one stage in flight and 2 workgroups per CU, so every K-step waits out a full
+// L2->LDS round trip (~2k cycles) for ~0.5-1k cycles of MFMA work (measured 23 % MFMA issue on K=768 shapes).  Here the
+// DMA for K-step t+2 is issued while step t computes; a wave waits only until ITS OWN loads for step t have landed
+// (vmcnt(6): the 6 DMA instructions of step t+1 may stay in flight), then one raw s_barrier publishes the stage.
+// A must be K-contiguous (forward and dgrad GEMMs); B K-contiguous or K-strided.
+#define BIG_BM 256
+#define BIG_THREADS 512
+#define BIG_STAGE_BYTES (48 * 1024)
+
+template <bool TB>
+__device__ __forceinline__ void big_stage_dma(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned char* stage,
+                                              uint32_t m0, uint32_t n0, uint32_t k0, uint32_t lda, uint32_t ldb,
+                                              int wave, int lane) {
+  // A: [256 rows][64 k], 32 instructions of 8 rows; B: 16 instructions (8 rows, or 4 k-rows when K-strided)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = wave + 8 * u;
+    const uint32_t row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(stage + j * 1024), 16, ((m0 + row) * lda + k0 + chunk * 8) * 2, 0, 0, 0);
+  }
+  unsigned char* sb = stage + 32 * 1024;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = wave + 8 * u;
+    uint32_t off;
+    if (!TB) {
+      const uint32_t row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
+      off = ((n0 + row) * ldb + k0 + chunk * 8) * 2;
+    } else {
+      const uint32_t krow = j * 4 + (lane >> 4), s16 = lane & 15;
+      const uint32_t c32 = (s16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
+      off = ((k0 + krow) * ldb + n0 + (c32 * 2 + (s16 & 1)) * 8) * 2;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb + j * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+template <bool TB, bool OUT_F32>
+__global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm_params_t p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // 4x2 waves, 64x64 each
+
+  const uint32_t nblk = gridDim.x, bid = blockIdx.x;
+  const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const uint32_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const uint32_t m0 = tm * BIG_BM, n0 = tn * GEMM_BN;
+
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.B), 0, (int)((uint64_t)(TB ? p.K : p.N) * p.ldb * 2), 0x00020000);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GEMM_BK;  // K % 64 == 0 guaranteed by the launcher
+  big_stage_dma<TB>(ra, rb, smem, m0, n0, 0, p.lda, p.ldb, wave, lane);
+  if (nk > 1) big_stage_dma<TB>(ra, rb, smem + BIG_STAGE_BYTES, m0, n0, GEMM_BK, p.lda, p.ldb, wave, lane);
+
+  int st = 0;  // stage of step kt
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      const int s2 = st >= 1 ? st - 1 : 2;  // (st + 2) % 3: the stage read during step kt-1, free after the barrier
+      big_stage_dma<TB>(ra, rb, smem + s2 * BIG_STAGE_BYTES, m0, n0, (kt + 2) * GEMM_BK, p.lda, p.ldb, wave, lane);
+    }
+    const unsigned char* la = smem + st * BIG_STAGE_BYTES;
+    const unsigned char* lb = la + 32 * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag_load<false>(la, wm * 4 + i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag_load<TB>(lb, wn * 4 + j, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    st = st == 2 ? 0 : st + 1;
+  }
+  gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+template <bool TB, bool OUT_F32>
+static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
+  const size_t smem = 3 * BIG_STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_big_kernel<TB, OUT_F32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return VLM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+  dim3 grid(p.tiles_m * p.tiles_n), block(BIG_THREADS);
+  hipLaunchKernelGGL((vlm_gemm_big_kernel<TB, OUT_F32>), grid, block, smem, stream, p);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
@@ -435,6 +555,16 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
       p.splits = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
+  }
+  // 256x128 three-stage kernel: A K-contiguous, whole 64-deep K tiles, and enough 256-row tiles to fill the chip
+  static int big_mode = -1;
+  if (big_mode < 0) {
+    const char* e = getenv("VLM_GEMM_BIG");
+    big_mode = e ? atoi(e) : 1;
+  }
+  if (big_mode && !ta && (K % GEMM_BK) == 0 && ((M + BIG_BM - 1) / BIG_BM) * p.tiles_n >= 512) {
+    if (tb) return c_is_f32 ? launch_gemm_big<true, true>(p, s) : launch_gemm_big<true, false>(p, s);
+    return c_is_f32 ? launch_gemm_big<false, true>(p, s) : launch_gemm_big<false, false>(p, s);
   }
   const int key = (ta ? 4 : 0) | (tb ? 2 : 0) | (c_is_f32 ? 1 : 0);
   switch (key) {
