@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvlm_hip.so")
+LIB_PATH = os.environ.get("VLM_LIB_PATH") or os.path.join(_HERE, "lib", "libvlm_hip.so")
 _lib = None
 
 c_void_p = ctypes.c_void_p
