@@ -141,6 +141,10 @@ int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_
                    void* stream);
 int vlm_cast_f32_bf16(const float* src, void* dst_bf16, uint64_t n, void* stream);
 int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W, int P, int lead_rows, void* stream);
+/* Gram cache (K15, src/cache_gram_matrices.py:246-254: G += X^T X in float64 for the input X of every hooked linear):
+ * the product runs on the MFMA GEMM (vlm_gemm_bf16 ta=1 tb=1 over the bf16 activations the linear consumed, fp32
+ * accumulation, split-K), and this entry point adds the fp32 [D,D] result into the float64 accumulator on device. */
+int vlm_accumulate_f32_f64(const float* src, double* dst_f64, uint64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (K4 + K7 + K7b): softmax(scale*Q K^T + bias[h] + key mask) V, head_dim = 64.

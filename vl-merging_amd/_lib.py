@@ -78,6 +78,7 @@ SIGNATURES = {
     "vlm_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_float, c_float, c_float,
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "vlm_accumulate_f32_f64": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_patch_im2col": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -92,6 +92,29 @@ __global__ __launch_bounds__(EW_THREADS) void im2col_kernel(const float* __restr
   }
 }
 
+// G64 += (double)T32 : folds the fp32 MFMA result of one X^T X product into the float64 Gram accumulator
+// (cache_gram_matrices.py:246-254 keeps the running sum in float64).
+__global__ __launch_bounds__(EW_THREADS) void acc_f64_kernel(const float* __restrict__ src, double* __restrict__ dst,
+                                                             size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * EW_THREADS) {
+    const f32x4 s = reinterpret_cast<const f32x4*>(src)[i];
+    double* d = dst + 4 * i;
+    d[0] += (double)s[0];
+    d[1] += (double)s[1];
+    d[2] += (double)s[2];
+    d[3] += (double)s[3];
+  }
+}
+
+extern "C" int vlm_accumulate_f32_f64(const float* src, double* dst, uint64_t n, void* stream) {
+  if (n == 0) return VLM_OK;
+  if (!src || !dst || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 31)) return VLM_ERR_ARG;
+  const size_t n4 = n >> 2;
+  hipLaunchKernelGGL(acc_f64_kernel, dim3(ew_grid(n4)), dim3(EW_THREADS), 0, (hipStream_t)stream, src, dst, n4);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
 extern "C" int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, float step_size,
                               float grad_scale, int zero_grad, void* stream) {

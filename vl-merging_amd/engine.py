@@ -182,6 +182,7 @@ class PassCtx:
         self.relpos = relpos
         self.keep0 = keep0
         self.keep1 = keep1
+        self.gram = None  # GramCapture when the Gram cache is being recorded
         self._row2sample = None
 
     def row2sample(self, device):
@@ -204,7 +205,34 @@ class PassCtx:
 class ExpertWeights:
     """Pointers one modality expert contributes to a block evaluation (all tensors are parameters)."""
 
-    __slots__ = ("n1w", "n1b", "qkvw", "qb", "vb", "projw", "projb", "n2w", "n2b", "fc1w", "fc1b", "fc2w", "fc2b")
+    __slots__ = ("n1w", "n1b", "qkvw", "qb", "vb", "projw", "projb", "n2w", "n2b", "fc1w", "fc1b", "fc2w", "fc2b",
+                 "gram_names")
+
+
+class GramCapture:
+    """Device-resident Gram accumulators of the inputs of the hooked linears (cache_gram_matrices.py:246-281):
+    name -> float64 [D,D].  `names(expert)` maps an expert to its four module names (qkv's key is the Attention
+    module, the others are the Linear modules), or fewer when a module is not hooked in that architecture."""
+
+    def __init__(self):
+        self.grams = {}
+        self._tmp = {}
+
+    def add(self, name, x):
+        if name is None or x.shape[0] == 0:
+            return
+        D = x.shape[1]
+        g = self.grams.get(name)
+        if g is None:
+            g = self.grams[name] = torch.zeros(D, D, device=x.device, dtype=torch.float64)
+        tmp = self._tmp.get(D)
+        if tmp is None:
+            tmp = self._tmp[D] = torch.empty(D, D, device=x.device, dtype=F32)
+        ops.gram_accumulate(x.contiguous(), g, tmp)
+
+    def state_dict(self):
+        """What the reference torch.save()s: name -> float64 CPU tensor (cache_gram_matrices.py:349)."""
+        return {k: v.cpu() for k, v in self.grams.items()}
 
 
 class BlockPlan:
@@ -268,6 +296,13 @@ class _BlockFn(torch.autograd.Function):
             ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b, act=L.ACT_GELU, aux=h[r0:r1])
             ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
                      row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
+        if pc.gram is not None:
+            for r0, r1, e in plan.ranges:
+                gn = e.gram_names
+                pc.gram.add(gn.get("qkv"), ln1[r0:r1])
+                pc.gram.add(gn.get("proj"), o[r0:r1])
+                pc.gram.add(gn.get("fc1"), ln2[r0:r1])
+                pc.gram.add(gn.get("fc2"), a[r0:r1])
         ctx.plan, ctx.pc, ctx.hook = plan, pc, hook
         ctx.has_bias = bias_t is not None
         ctx.save_for_backward(x, st1, ln1, qkv, o, lse, y1, x1, st2, ln2, h, a, y2,

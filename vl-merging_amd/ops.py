@@ -112,6 +112,20 @@ def cast_bf16(src, dst):
     return dst
 
 
+def gram_accumulate(x, gram64, tmp32=None):
+    """gram64 (float64 [D,D]) += x^T x for bf16 activations x [M,D] (the input of a hooked linear)."""
+    L.require_cuda(x, gram64, tmp32)
+    M, D = x.shape
+    if gram64.dtype != torch.float64 or tuple(gram64.shape) != (D, D) or not gram64.is_contiguous():
+        raise L.VlmError("gram accumulator must be a contiguous float64 [D,D] tensor")
+    if tmp32 is None:
+        tmp32 = torch.empty(D, D, device=x.device, dtype=F32)
+    gemm(x, x, tmp32, ta=True, tb=True)
+    L.check(L.get_lib().vlm_accumulate_f32_f64(L.ptr(tmp32), L.ptr(gram64), D * D, L.stream_ptr()),
+            "vlm_accumulate_f32_f64")
+    return gram64
+
+
 def patch_im2col(image, patches, patch, lead_rows):
     L.require_cuda(image, patches)
     B, C, H, W = image.shape

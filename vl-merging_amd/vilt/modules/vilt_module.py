@@ -177,6 +177,7 @@ class ViLTransformerSS(nn.Module):
         self._flat = None
         self._idx_cache = {}
         self._grad_hook = None
+        self._gram = None
         self.trainer = None
 
         # ---- checkpoint load / merge (vilt_module.py:270-295 and :345-364) -------------------------------------------
@@ -314,6 +315,21 @@ class ViLTransformerSS(nn.Module):
     def _hook(self):
         return self._grad_hook
 
+    # ---- Gram cache (src/cache_gram_matrices.py) ---------------------------------------------------------------
+    def start_gram_capture(self):
+        """Record G += X^T X (float64, on device) for the input X of every linear the reference hooks."""
+        self._gram = engine.GramCapture()
+        return self._gram
+
+    def stop_gram_capture(self):
+        g, self._gram = self._gram, None
+        return g
+
+    def _pass_ctx(self, *a, **k):
+        pc = engine.PassCtx(*a, **k)
+        pc.gram = getattr(self, "_gram", None)
+        return pc
+
     # ---- passes ----------------------------------------------------------------------------------------------------------
     def infer(self, batch, mask_text=False, mask_image=False, bool_masked_pos=None, image_token_type_idx=1,
               image_embeds=None, image_masks=None):
@@ -334,7 +350,7 @@ class ViLTransformerSS(nn.Module):
         x = torch.cat([trows, irows], 0)
         index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
             else self.text_imag_relative_position_index
-        pc = engine.PassCtx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
+        pc = self._pass_ctx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
                             keep0=text_masks.to(torch.uint8).contiguous())
         for blk in self.transformer.blocks:
             x = blk.run(x, pc, 2, self._hook())
@@ -377,7 +393,7 @@ class ViLTransformerSS(nn.Module):
         index = self.text_relative_position_index
         if self.max_vl_text_len is not None and T != index.shape[0]:
             index = index[:T, :T]
-        pc = engine.PassCtx(ops.Seq(B, T, 0), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
+        pc = self._pass_ctx(ops.Seq(B, T, 0), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
                             keep0=text_masks.to(torch.uint8).contiguous())
         l, v = self._unimodal(x, pc, 1, with_vlffn)
         D = l.shape[-1]
@@ -404,7 +420,7 @@ class ViLTransformerSS(nn.Module):
         B = img.shape[0]
         x, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
         image_masks = image_masks.type_as(text_masks)
-        pc = engine.PassCtx(ops.Seq(B, 0, I), self.hparams.config["num_heads"],
+        pc = self._pass_ctx(ops.Seq(B, 0, I), self.hparams.config["num_heads"],
                             self.get_rel_pos_bias(self.relative_position_index, 0))
         vf, v = self._unimodal(x, pc, 0, with_vlffn)
         D = vf.shape[-1]

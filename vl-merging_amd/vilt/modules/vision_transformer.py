@@ -116,6 +116,15 @@ class Block(nn.Module):
         e.qkvw, e.qb, e.vb = a.qkv.weight, a.q_bias, a.v_bias
         e.projw, e.projb = a.proj.weight, a.proj.bias
         e.fc1w, e.fc1b, e.fc2w, e.fc2b = m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias
+        # module names the reference's Gram hook keys on (cache_gram_matrices.py:264-281): with MoE modules the
+        # Attention module itself (input of qkv), attn.<m>.proj, mlp.<m>.fc1, mlp.<m>.fc2; shared (ufo) modules
+        # are hooked at mlp.fc1, mlp.fc2 and attn.proj only
+        pre = "transformer.blocks.%d." % self.layer_number
+        an = pre + "attn" + ("." + key if isinstance(self.attn, nn.ModuleDict) else "")
+        mn = pre + "mlp" + ("." + key if isinstance(self.mlp, nn.ModuleDict) else "")
+        e.gram_names = {"proj": an + ".proj", "fc1": mn + ".fc1", "fc2": mn + ".fc2"}
+        if self.use_moe:
+            e.gram_names["qkv"] = an
         return e
 
     def plan(self, type_id, seq):
