@@ -155,8 +155,11 @@ int vlm_accumulate_f32_f64(const float* src, double* dst_f64, uint64_t n, void* 
  *             applies `scale` (:346) to the scores.
  *   bias_t    f32 [n_cols, R]: TRANSPOSE of relative_position_bias_table [R, heads*layers]; row head_row0+h
  *             is head h of this layer.  NULL = no bias.
- *   rel_index int16 [index_rows, ld_index]: relative-position index in "index coordinates": text token t is
- *             position t, image token i is position pos1 + i (pos1 % 4 == 0, ld_index % 4 == 0).
+ *   rel_index / rel_index_t  int16 [index_rows, ld_index] and its transpose (BOTH are needed: each kernel reads the
+ *             orientation whose fast axis runs along its lanes, so every index load is a coalesced 64-B row piece;
+ *             the forward reads only rel_index_t): 4 x relative-position index (= byte offset into the fp32 table column,
+ *             R <= 8191) in "index coordinates": text token t is position t, image token i is position pos1 + i
+ *             (pos1 % 4 == 0, ld_index % 4 == 0).
  *   keep0/1   uint8 [B, n0] / [B, n1] key keep flags (text_masks; NULL = keep all), masked_fill(-inf) of :354.
  *   rows      segment-major: text (b,t) -> base0 + b*n0 + t ; image (b,i) -> base1 + b*n1 + i.
  *   mode      JOINT: every query sees text then image keys.  SEPARATE: queries see their own segment only.
@@ -174,9 +177,12 @@ typedef struct {
   int32_t total_rows;
   int32_t R;
   const float* bias_t;
-  const int16_t* rel_index;
+  const int16_t* rel_index;    /* [q position][key position] */
+  const int16_t* rel_index_t;  /* its transpose [key position][q position], same leading-dimension rules */
   int32_t ld_index;
   int32_t index_rows;
+  int32_t ld_index_t;
+  int32_t index_t_rows;
   int32_t head_row0;
   int32_t mode;
   const uint8_t* keep0;
@@ -187,12 +193,9 @@ typedef struct {
 } vlm_attn_desc_t;
 
 int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out_bf16, int ld_out, float* lse, void* stream);
-/* delta_ws: f32 [H, total_rows] scratch.  rel_index_t: the TRANSPOSE of rel_index (int16 [index cols, ld_index_t],
- * ld_index_t % 4 == 0) so the key-stationary kernel also reads 4 consecutive indices per 8-B load.
- * dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED. */
+/* delta_ws: f32 [H, total_rows] scratch.  dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED. */
 int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out_bf16, int ld_out, const void* dout_bf16, int ld_dout,
-                      const float* lse, float* delta_ws, const int16_t* rel_index_t, int ld_index_t, int index_t_rows,
-                      void* dqkv_bf16, int ld_dqkv, float* dbias_t, void* stream);
+                      const float* lse, float* delta_ws, void* dqkv_bf16, int ld_dqkv, float* dbias_t, void* stream);
 
 #ifdef __cplusplus
 }

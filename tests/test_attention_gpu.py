@@ -44,6 +44,13 @@ def build_case(B, n0, n1, H, seed, with_bias=True, with_mask=True):
                 keep0=keep0, R=R)
 
 
+def make_idx_t(c):
+    NP = c["pos1"] + c["n1"]
+    idx_t = torch.zeros(NP, (NP + 3) // 4 * 4, device="cuda", dtype=torch.int16)
+    idx_t[:, :NP] = c["idx"][:NP, :NP].t() * 4
+    return idx_t
+
+
 def to_seq(x, c):
     """segment-major [rows, F] -> [B, n0+n1, F]"""
     B, n0, n1 = c["B"], c["n0"], c["n1"]
@@ -106,8 +113,8 @@ def test_attention_fwd(ops, L, ci, sep, with_bias):
     layer = 1
     bias_t = c["table"].t().contiguous() if with_bias else None
     ops.attention_fwd(c["qkv"], out, lse, seq, c["H"], bias_t=bias_t, head_row0=layer * c["H"],
-                      rel_index=c["idx"] if with_bias else None, keep0=c["keep0"],
-                      mode=L.ATTN_SEPARATE if sep else L.ATTN_JOINT)
+                      rel_index=c["idx"] * 4 if with_bias else None, rel_index_t=make_idx_t(c) if with_bias else None,
+                      keep0=c["keep0"], mode=L.ATTN_SEPARATE if sep else L.ATTN_JOINT)
     torch.cuda.synchronize()
     ref, s, _ = reference(c, layer, sep)
     vmax = float(c["qkv"].float().abs().max())
@@ -136,16 +143,12 @@ def test_attention_bwd(ops, L, ci, sep, with_bias):
     lse = torch.empty(H, rows, device="cuda")
     bias_t = c["table"].t().contiguous() if with_bias else None
     mode = L.ATTN_SEPARATE if sep else L.ATTN_JOINT
-    kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=c["idx"] if with_bias else None, keep0=c["keep0"], mode=mode)
+    kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=c["idx"] * 4 if with_bias else None,
+              rel_index_t=make_idx_t(c) if with_bias else None, keep0=c["keep0"], mode=mode)
     ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
     dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
     dbias_t = torch.zeros_like(bias_t) if with_bias else None
-    idx_t = None
-    if with_bias:
-        NP = c["pos1"] + c["n1"]
-        idx_t = torch.zeros(NP, (NP + 3) // 4 * 4, device="cuda", dtype=torch.int16)
-        idx_t[:, :NP] = c["idx"][:NP, :NP].t()
-    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, rel_index_t=idx_t, dbias_t=dbias_t, **kw)
+    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
     torch.cuda.synchronize()
     # reference
     q32 = c["qkv"].float().requires_grad_(True)

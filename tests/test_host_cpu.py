@@ -76,8 +76,8 @@ def test_kernel_index_coordinates(vm):
     m, mt = vm._index16(idx["text_imag_relative_position_index"], 6)
     assert m.dtype == torch.int16 and m.shape[1] % 4 == 0 and m.shape == mt.shape
     pos = torch.cat([torch.arange(6), 8 + torch.arange(17)])
-    assert torch.equal(m[pos][:, pos].long(), idx["text_imag_relative_position_index"].long())
-    assert torch.equal(mt[pos][:, pos].long(), idx["text_imag_relative_position_index"].long().t())
+    assert torch.equal(m[pos][:, pos].long(), 4 * idx["text_imag_relative_position_index"].long())
+    assert torch.equal(mt[pos][:, pos].long(), 4 * idx["text_imag_relative_position_index"].long().t())
 
 
 def test_gpu_only_is_loud(cfgmod, vm):

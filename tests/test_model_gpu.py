@@ -128,7 +128,8 @@ def test_training_step_matches_reference_golden(mods, golden_dir, arch):
             got = named[n].grad.float().cpu()
             err = float((got - ref).abs().max())
             mx = float(ref.abs().max())
-            assert err <= (0.2 if mx <= 0.05 else 0.15) * mx + 1e-6, (n, err, mx)  # see grad_norm_ok
+            floor = 1e-4 if ref.numel() == 1 else 1e-6  # near-zero scalar (logit scale) gradients: see grad_norm_ok
+            assert err <= (0.2 if mx <= 0.05 else 0.15) * mx + floor, (n, err, mx)
 
 
 @pytest.mark.parametrize("arch", ["ufo", "all_moe"])

@@ -48,9 +48,10 @@ def main():
             if n0 == 0 and mode == L.ATTN_SEPARATE:
                 continue
             for wb in (True, False):
-                kw = dict(bias_t=bias_t if wb else None, head_row0=12, rel_index=m if wb else None, mode=mode)
+                kw = dict(bias_t=bias_t if wb else None, head_row0=12, rel_index=m if wb else None,
+                          rel_index_t=mt if wb else None, mode=mode)
                 f = timeit(lambda: ops.attention_fwd(qkv, out, lse, seq, H, **kw))
-                b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, dqkv, seq, H, rel_index_t=mt if wb else None,
+                b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, dqkv, seq, H,
                                                      dbias_t=dbias if wb else None, delta_ws=delta, **kw))
                 fl = flops if mode == L.ATTN_JOINT else 4.0 * B * H * 64 * (n0 * n0 + n1 * n1)
                 print("%s/%s bias=%d: fwd %.1f us (%.0f TF)  bwd %.1f us (%.0f TF of 2.5x fwd flops)" %

@@ -43,8 +43,9 @@ ATTN_JOINT, ATTN_SEPARATE = 0, 1
 class AttnDesc(ctypes.Structure):
     _fields_ = [
         ("qkv", c_void_p), ("ld_qkv", ctypes.c_int32), ("H", ctypes.c_int32), ("total_rows", ctypes.c_int32),
-        ("R", ctypes.c_int32), ("bias_t", c_void_p), ("rel_index", c_void_p), ("ld_index", ctypes.c_int32),
-        ("index_rows", ctypes.c_int32), ("head_row0", ctypes.c_int32), ("mode", ctypes.c_int32),
+        ("R", ctypes.c_int32), ("bias_t", c_void_p), ("rel_index", c_void_p), ("rel_index_t", c_void_p),
+        ("ld_index", ctypes.c_int32), ("index_rows", ctypes.c_int32), ("ld_index_t", ctypes.c_int32),
+        ("index_t_rows", ctypes.c_int32), ("head_row0", ctypes.c_int32), ("mode", ctypes.c_int32),
         ("keep0", c_void_p), ("keep1", c_void_p),
         ("B", ctypes.c_int32), ("n0", ctypes.c_int32), ("n1", ctypes.c_int32), ("base0", ctypes.c_int32),
         ("base1", ctypes.c_int32), ("pos1", ctypes.c_int32), ("scale", c_float), ("reserved", ctypes.c_int32),
@@ -68,7 +69,7 @@ SIGNATURES = {
                               c_int, ctypes.POINTER(Epilogue), c_void_p]),
     "vlm_attention_fwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_void_p]),
     "vlm_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                  c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+                                  c_void_p, c_int, c_void_p, c_void_p]),
     "vlm_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p]),
     "vlm_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,

@@ -40,8 +40,6 @@ struct attn_bwd_params_t {
   int ld_do;
   const float* lse;       // [H, rows] log2 domain
   const float* delta;     // [H, rows]
-  const int16_t* idx_t;   // transposed relative index [index_cols, ld_idx_t]
-  int ld_idx_t, idx_t_rows;
   bf16_t* dqkv;           // [rows, 3*H*64]
   int ld_dqkv;
   float* dbias_t;         // [n_cols, R] accumulate
@@ -94,6 +92,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
   }
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int16_t*>(p.idx), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
+  const uint32_t irow = (uint32_t)qpos * p.ld_idx;
+  u32x2 iw[8];
+  if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)kr.pos[kr.nt[0] > 0 ? 0 : 1], hh, iw);
 
   f32x16 o[2];
 #pragma unroll
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
     int rng, k0;
     att_tile_origin(kr, t, rng, k0);
     const int kpos0 = kr.pos[rng] + k0;
+    const bool need_mask = (k0 + ATT_BK > kr.n[rng]) || (kr.keep[rng] != nullptr);
 
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -136,17 +138,18 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         const int kl = kb * 32 + 8 * g4 + 4 * hh;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (HAS_BIAS) {
-          const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(qpos * p.ld_idx + kpos0 + kl) * 2, 0, 0);
-          bv[0] = tab[w[0] & 0xffff];
-          bv[1] = tab[w[0] >> 16];
-          bv[2] = tab[w[1] & 0xffff];
-          bv[3] = tab[w[1] >> 16];
+          const u32x2 w = iw[kb * 4 + g4];
+          bv[0] = att_tab(tab, w[0] & 0xffff);
+          bv[1] = att_tab(tab, w[0] >> 16);
+          bv[2] = att_tab(tab, w[1] & 0xffff);
+          bv[3] = att_tab(tab, w[1] >> 16);
         }
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(km + kl);
+        f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+        if (need_mask) mk = *reinterpret_cast<const f32x4*>(km + kl);  // wave-uniform branch
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + mk[e];
-          const float pr = exp2f(v - lse2);
+          const float pr = att_exp2(v - lse2);
           s[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl) * p.scale;  // dS^T, pre-scaled
         }
       }
@@ -161,6 +164,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, o[db], 0, 0, 0);
         }
       }
+    }
+    if (HAS_BIAS && t + 1 < ntiles) {  // next tile's indices (same registers), in flight across the barrier
+      int rng1, k1;
+      att_tile_origin(kr, t + 1, rng1, k1);
+      att_idx_tile(ridx, irow, (uint32_t)(kr.pos[rng1] + k1), hh, iw);
     }
     if (t + 1 < ntiles) {
       att_tile_store_rows(st.k, ldsK + (cur ^ 1) * ATT_TILE_BYTES, tid);
@@ -232,7 +240,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
     for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
   }
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int16_t*>(bp.idx_t), 0, HAS_BIAS ? bp.idx_t_rows * bp.ld_idx_t * 2 : 0, 0x00020000);
+      const_cast<int16_t*>(p.idx_t), 0, HAS_BIAS ? p.idx_t_rows * p.ld_idx_t * 2 : 0, 0x00020000);
+  const uint32_t irow = (uint32_t)kpos * p.ld_idx_t;
+  u32x2 iw[8];
+  if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)qr.pos[qr.nt[0] > 0 ? 0 : 1], hh, iw);
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -290,18 +301,18 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
         const int ql = qb * 32 + 8 * g4 + 4 * hh;  // local query row of element 0 of this group
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (HAS_BIAS) {
-          const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(kpos * bp.ld_idx_t + qpos0 + ql) * 2, 0, 0);
-          bv[0] = tab[w[0] & 0xffff];
-          bv[1] = tab[w[0] >> 16];
-          bv[2] = tab[w[1] & 0xffff];
-          bv[3] = tab[w[1] >> 16];
+          const u32x2 w = iw[qb * 4 + g4];
+          bv[0] = att_tab(tab, w[0] & 0xffff);
+          bv[1] = att_tab(tab, w[0] >> 16);
+          bv[2] = att_tab(tab, w[1] & 0xffff);
+          bv[3] = att_tab(tab, w[1] >> 16);
         }
         const f32x4 ls = *reinterpret_cast<const f32x4*>(qstat + ql);
         const f32x4 dl = *reinterpret_cast<const f32x4*>(qstat + 64 + ql);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + kmaskv;
-          const float pr = exp2f(v - ls[e]);
+          const float pr = att_exp2(v - ls[e]);
           s[4 * g4 + e] = pr;                               // P
           dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl[e]);   // dS (natural units, w.r.t. the biased score)
         }
@@ -323,6 +334,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb_, dk[db], 0, 0, 0);
         }
       }
+    }
+    if (HAS_BIAS && t + 1 < ntiles) {  // next query tile's indices (same registers), in flight across the barriers
+      int rng1, q1;
+      att_tile_origin(qr, t + 1, rng1, q1);
+      att_idx_tile(ridx, irow, (uint32_t)(qr.pos[rng1] + q1), hh, iw);
     }
     __syncthreads();
     if (t + 1 < ntiles) {
@@ -358,13 +374,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
 // the LDS histogram (B-fold fewer atomics), with the all-indices-equal tiles (text->image pairs share ONE table
 // row, vilt_module.py:180-181) reduced in registers instead.
 __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const attn_bwd_params_t bp) {
+  // Every operand tile is fetched COOPERATIVELY (one wave instruction = 8 rows x 128 B = 8 cache lines) and the MFMA
+  // fragments are read from LDS: per-lane row-fragment loads straight from global memory put 64 different cache
+  // lines behind every wave instruction and left the kernel bound by the CU's address coalescer (measured 216 us;
+  // the MFMA work is ~30 us).
   const attn_params_t& p = bp.f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsQ = smem;              // [2][32 q][64 d] row image (4 KiB each)
-  unsigned char* ldsO = smem + 2 * 4096;   // [2] dO row image
-  float* qstat = reinterpret_cast<float*>(smem + 4 * 4096);  // [2][64]: lse2[32], delta[32]
-  float* tab = qstat + 128;
-  float* hist = tab + ((p.R + 3) & ~3);
+  unsigned char* ldsK = smem;                        // [128 keys][64 d] row image
+  unsigned char* ldsV = smem + 2 * ATT_TILE_BYTES;   // [128 keys][64 d] row image
+  unsigned char* ldsQ = smem + 4 * ATT_TILE_BYTES;   // [32 q][64 d] row image
+  unsigned char* ldsO = ldsQ + 4096;                 // [32 q][64 d] dO row image
+  float* qstat = reinterpret_cast<float*>(ldsO + 4096);  // lse2[32], delta[32]
+  float* tab = qstat + 64;
+  float* hist = reinterpret_cast<float*>(smem);  // aliases the K/V tiles: only used after the sample loop
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -377,15 +399,15 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const at
   if (seg) kt -= nt0;
   const int nk = seg ? sq.n1 : sq.n0;
   att_ranges_t qr = att_key_ranges(sq, p.mode, seg, 0, nullptr, nullptr);
-  // 32-row query tiles of the interacting ranges
-  const int ntq0 = (qr.n[0] + 31) >> 5, ntq1 = (qr.n[1] + 31) >> 5;
+  const int ntq0 = (qr.n[0] + 31) >> 5, ntq1 = (qr.n[1] + 31) >> 5;  // 32-row query tiles of the interacting ranges
   if ((int)blockIdx.z >= ntq0 + ntq1) return;  // block-uniform, before any barrier
   const int rng = (int)blockIdx.z >= ntq0 ? 1 : 0;
   const int q0 = (rng ? (int)blockIdx.z - ntq0 : (int)blockIdx.z) << 5;
   const int qpos0 = qr.pos[rng] + q0;
   const int qn = qr.n[rng];
   const int qbase = qr.rowbase[rng];  // b = 0
-  const int key = kt * ATT_BQ + wave * 32 + r;
+  const int k0 = kt * ATT_BQ;
+  const int key = k0 + wave * 32 + r;
   const bool kvalid = key < nk;
   const int kc = kvalid ? key : nk - 1;
   const int kpos = (seg ? sq.pos1 : 0) + kc;
@@ -394,102 +416,114 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const at
 
   {
     const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
-    for (int i = tid; i < p.R; i += ATT_THREADS) {
-      tab[i] = col[i] * ATT_LOG2E;
-      hist[i] = 0.f;
-    }
+    for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
   }
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int16_t*>(bp.idx_t), 0, bp.idx_t_rows * bp.ld_idx_t * 2, 0x00020000);
-  // relative-position indices of this lane's 16 (q, key) pairs: independent of the sample
+      const_cast<int16_t*>(p.idx), 0, p.idx_rows * p.ld_idx * 2, 0x00020000);
+  const uint32_t ld2 = (uint32_t)p.ld_idx * 2, ivoff = (uint32_t)(kpos + 4 * hh * p.ld_idx) * 2;
+  // byte offsets (4 x relative-position index) of this lane's 16 (q, key) pairs: independent of the sample
   uint32_t ids[8];
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
-    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(kpos * bp.ld_idx_t + qpos0 + 8 * g4 + 4 * hh) * 2, 0, 0);
-    ids[2 * g4] = w[0];
-    ids[2 * g4 + 1] = w[1];
+    uint32_t io[4];
+    att_idx4(ridx, ivoff, (uint32_t)(qpos0 + 8 * g4), ld2, io);
+    ids[2 * g4] = io[0] | (io[1] << 16);
+    ids[2 * g4 + 1] = io[2] | (io[3] << 16);
   }
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  // staging: 32 rows x 128 B = 256 16-B pieces per tile -> one piece per thread per tile
-  u32x4 sq_, so_;
+  u32x4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3, rq, ro;
   float s_st = 0.f;
   const int srow = tid >> 3, schunk = tid & 7;
-  auto stage_load = [&](int b) {
-    const int rowbase = qbase + b * qn;
-    const int qq = q0 + srow;
-    if (qq < qn) {
-      sq_ = *reinterpret_cast<const u32x4*>(p.qkv + (size_t)(rowbase + qq) * p.ld_qkv + h * 64 + schunk * 8);
-      so_ = *reinterpret_cast<const u32x4*>(bp.d_o + (size_t)(rowbase + qq) * bp.ld_do + h * 64 + schunk * 8);
-    } else {
-      sq_ = so_ = (u32x4){0u, 0u, 0u, 0u};
-    }
-    if (tid < 64) {  // threads 0..31: lse2, 32..63: delta
-      const int q2 = q0 + (tid & 31);
-      const bool ok = q2 < qn;
-      const size_t row = (size_t)rowbase + (ok ? q2 : 0);
-      const float* src = (tid < 32) ? bp.lse : bp.delta;
-      s_st = ok ? src[(size_t)h * p.total_rows + row] : (tid < 32 ? INFINITY : 0.f);
-    }
-  };
-  auto stage_store = [&](int buf) {
-    const int byte = srow * 128 + ((schunk ^ (srow & 7)) << 4);
-    *reinterpret_cast<u32x4*>(ldsQ + buf * 4096 + byte) = sq_;
-    *reinterpret_cast<u32x4*>(ldsO + buf * 4096 + byte) = so_;
-    if (tid < 64) qstat[buf * 64 + tid] = s_st;
-  };
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
+  // (plain macros, not lambdas: by-reference captures of register arrays were placed in scratch memory)
+#define DB_LOAD_KV(U, RK, RV)                                                                              \
+  {                                                                                                        \
+    const int row_ = srow + 32 * (U);                                                                      \
+    if (k0 + row_ < nk) {                                                                                  \
+      const bf16_t* src_ = p.qkv + (size_t)(krow0_ + k0 + row_) * p.ld_qkv + D + h * 64 + schunk * 8;      \
+      RK = *reinterpret_cast<const u32x4*>(src_);                                                          \
+      RV = *reinterpret_cast<const u32x4*>(src_ + D);                                                      \
+    } else {                                                                                               \
+      RK = RV = (u32x4){0u, 0u, 0u, 0u};                                                                   \
+    }                                                                                                      \
+  }
+#define DB_STAGE_LOAD(B_)                                                                                  \
+  {                                                                                                        \
+    const int krow0_ = kbase + (B_) * nk;                                                                  \
+    DB_LOAD_KV(0, rk0, rv0) DB_LOAD_KV(1, rk1, rv1) DB_LOAD_KV(2, rk2, rv2) DB_LOAD_KV(3, rk3, rv3)        \
+    const int rowbase_ = qbase + (B_) * qn;                                                                \
+    const int qq_ = q0 + srow;                                                                             \
+    if (qq_ < qn) {                                                                                        \
+      rq = *reinterpret_cast<const u32x4*>(p.qkv + (size_t)(rowbase_ + qq_) * p.ld_qkv + h * 64 + schunk * 8); \
+      ro = *reinterpret_cast<const u32x4*>(bp.d_o + (size_t)(rowbase_ + qq_) * bp.ld_do + h * 64 + schunk * 8); \
+    } else {                                                                                               \
+      rq = ro = (u32x4){0u, 0u, 0u, 0u};                                                                   \
+    }                                                                                                      \
+    if (tid < 64) {                                                                                        \
+      const int q2_ = q0 + (tid & 31);                                                                     \
+      const bool ok_ = q2_ < qn;                                                                           \
+      const size_t rw_ = (size_t)rowbase_ + (ok_ ? q2_ : 0);                                               \
+      const float* sp_ = (tid < 32) ? bp.lse : bp.delta;                                                   \
+      s_st = ok_ ? sp_[(size_t)h * p.total_rows + rw_] : (tid < 32 ? INFINITY : 0.f);                      \
+    }                                                                                                      \
+  }
+#define DB_STORE_KV(U, RK, RV)                                                                             \
+  {                                                                                                        \
+    const int row_ = srow + 32 * (U);                                                                      \
+    const int byte_ = row_ * 128 + ((schunk ^ (row_ & 7)) << 4);                                           \
+    *reinterpret_cast<u32x4*>(ldsK + byte_) = RK;                                                          \
+    *reinterpret_cast<u32x4*>(ldsV + byte_) = RV;                                                          \
+  }
+#define DB_STAGE_STORE()                                                                                   \
+  {                                                                                                        \
+    DB_STORE_KV(0, rk0, rv0) DB_STORE_KV(1, rk1, rv1) DB_STORE_KV(2, rk2, rv2) DB_STORE_KV(3, rk3, rv3)    \
+    const int byte_ = srow * 128 + ((schunk ^ (srow & 7)) << 4);                                           \
+    *reinterpret_cast<u32x4*>(ldsQ + byte_) = rq;                                                          \
+    *reinterpret_cast<u32x4*>(ldsO + byte_) = ro;                                                          \
+    if (tid < 64) qstat[tid] = s_st;                                                                       \
+  }
+  DB_STAGE_LOAD(0)
   const float c1 = p.scale * ATT_LOG2E;
   for (int b = 0; b < sq.B; ++b) {
-    const int cur = b & 1;
-    bf16x8 kf[4], vf[4];
-    {
-      const size_t krow = (size_t)kbase + (size_t)b * nk + kc;
-      const bf16_t* kp = p.qkv + krow * p.ld_qkv + D + h * 64 + 8 * hh;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-        vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
-      }
-    }
+    __syncthreads();  // every wave is done with the previous sample's tiles
+    DB_STAGE_STORE()
+    __syncthreads();
+    if (b + 1 < sq.B) DB_STAGE_LOAD(b + 1)  // flies during this sample's MFMAs
     const bool kkeep = kvalid && (!keep || keep[(size_t)b * nk + kc] != 0);
     const float kmaskv = kkeep ? 0.f : -INFINITY;
-    if (b + 1 < sq.B) stage_load(b + 1);
-    const unsigned char* lq = ldsQ + cur * 4096;
-    const unsigned char* lo = ldsO + cur * 4096;
-    const float* qs = qstat + cur * 64;
     f32x16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
-      const bf16x8 a = att_k_rowfrag(lq, r, 2 * ss + hh);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ss], s, 0, 0, 0);
-      const bf16x8 oa = att_k_rowfrag(lo, r, 2 * ss + hh);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
+      const bf16x8 a = att_k_rowfrag(ldsQ, r, 2 * ss + hh);
+      const bf16x8 kf = att_k_rowfrag(ldsK, wave * 32 + r, 2 * ss + hh);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf, s, 0, 0, 0);
+      const bf16x8 oa = att_k_rowfrag(ldsO, r, 2 * ss + hh);
+      const bf16x8 vf = att_k_rowfrag(ldsV, wave * 32 + r, 2 * ss + hh);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf, dp, 0, 0, 0);
     }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int ql = 8 * g4 + 4 * hh;
       const uint32_t w0 = ids[2 * g4], w1 = ids[2 * g4 + 1];
-      const float bv[4] = {tab[w0 & 0xffff], tab[w0 >> 16], tab[w1 & 0xffff], tab[w1 >> 16]};
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(qs + ql);
-      const f32x4 dl = *reinterpret_cast<const f32x4*>(qs + 32 + ql);
+      const float bv[4] = {att_tab(tab, w0 & 0xffff), att_tab(tab, w0 >> 16), att_tab(tab, w1 & 0xffff), att_tab(tab, w1 >> 16)};
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(qstat + ql);
+      const f32x4 dl = *reinterpret_cast<const f32x4*>(qstat + 32 + ql);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + kmaskv;
-        const float pr = exp2f(v - ls[e]);
+        const float pr = att_exp2(v - ls[e]);
         acc[4 * g4 + e] += pr * (dp[4 * g4 + e] - dl[e]);
       }
     }
-    if (b + 1 < sq.B) stage_store(cur ^ 1);
-    __syncthreads();
   }
-  // ---- histogram of the batch-summed dS --------------------------------------------------------------------------
+  // ---- histogram of the batch-summed dS (in the LDS that held the K/V tiles) ---------------------------------------
+  __syncthreads();
+  for (int i = tid; i < p.R; i += ATT_THREADS) hist[i] = 0.f;
+  __syncthreads();
   {
     bool same = true;
 #pragma unroll
@@ -501,12 +535,12 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const at
 #pragma unroll
       for (int i = 0; i < 16; ++i) tsum += acc[i];
       tsum = wave_sum(tsum);
-      if (lane == 0) atomicAdd(hist + (first & 0xffff), tsum);
+      if (lane == 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + (first & 0xffff)), tsum);
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const uint32_t w = ids[i >> 1];
-        atomicAdd(hist + ((i & 1) ? (w >> 16) : (w & 0xffff)), acc[i]);
+        atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + ((i & 1) ? (w >> 16) : (w & 0xffff))), acc[i]);
       }
     }
   }
@@ -519,16 +553,15 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const at
 }
 
 extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int ld_out, const void* d_out,
-                                 int ld_dout, const float* lse, float* delta_ws, const int16_t* rel_index_t,
-                                 int ld_index_t, int index_t_rows, void* dqkv, int ld_dqkv, float* dbias_t,
-                                 void* stream) {
+                                 int ld_dout, const float* lse, float* delta_ws, void* dqkv, int ld_dqkv,
+                                 float* dbias_t, void* stream) {
   attn_bwd_params_t bp;
   int rc = att_fill_params(d, bp.f);
   if (rc != VLM_OK) return rc;
   if (!out || !d_out || !lse || !delta_ws || !dqkv) return VLM_ERR_ARG;
   if ((ld_out & 7) || (ld_dout & 7) || (ld_dqkv & 3) || ((uintptr_t)out & 15) || ((uintptr_t)d_out & 15))
     return VLM_ERR_ARG;
-  if (bp.f.bias_t && (!rel_index_t || (ld_index_t & 3) || ((uintptr_t)rel_index_t & 7))) return VLM_ERR_ARG;
+  if (bp.f.bias_t && (!bp.f.idx || (bp.f.ld_idx & 3))) return VLM_ERR_ARG;
   attn_params_t& p = bp.f;
   const int nt0 = (p.seq.n0 + ATT_BQ - 1) / ATT_BQ, nt1 = (p.seq.n1 + ATT_BQ - 1) / ATT_BQ;
   if (nt0 + nt1 == 0 || p.seq.B == 0) return VLM_OK;
@@ -537,9 +570,6 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   bp.ld_do = ld_dout;
   bp.lse = lse;
   bp.delta = delta_ws;
-  bp.idx_t = rel_index_t;
-  bp.ld_idx_t = ld_index_t;
-  bp.idx_t_rows = index_t_rows;
   bp.dqkv = reinterpret_cast<bf16_t*>(dqkv);
   bp.ld_dqkv = ld_dqkv;
   bp.dbias_t = dbias_t;
@@ -556,7 +586,7 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   const size_t Rp = (size_t)((p.R + 3) & ~3);
   const size_t smem_dq = 6 * ATT_TILE_BYTES + 512 + Rp * 4;
   const size_t smem_dkv = 4 * ATT_TILE_BYTES + 512 + Rp * 4;
-  const size_t smem_db = 4 * 4096 + 512 + 2 * Rp * 4;
+  const size_t smem_db = 4 * ATT_TILE_BYTES + 2 * 4096 + 256 + Rp * 4;  // histogram aliases the K/V tiles (R*4 <= 32 KiB)
   if (smem_dq > 160 * 1024 || smem_dkv > 160 * 1024) return VLM_ERR_UNSUPPORTED;
   if (p.bias_t) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>),

@@ -9,6 +9,14 @@
 #define ATT_LOG2E 1.4426950408889634f
 #define ATT_LN2 0.6931471805599453f
 
+// raw v_exp_f32 (2^x): libm's exp2f adds a denormal-range select/scale (5 instructions per call); scores that far
+// below the row maximum contribute 0 either way
+#define att_exp2(x) __builtin_amdgcn_exp2f(x)
+// bias-table gather: the relative-position index is stored PRE-MULTIPLIED by 4 (byte offset into the LDS column)
+__device__ __forceinline__ float att_tab(const float* tab, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(tab) + byte_off);
+}
+
 typedef __attribute__((address_space(3))) s16x4 att_lds_s16x4;
 
 struct attn_seq_t {
@@ -24,8 +32,10 @@ struct attn_params_t {
   int total_rows;
   const float* bias_t;
   int R, head_row0;
-  const int16_t* idx;
+  const int16_t* idx;    // [q][k]
   int ld_idx, idx_rows;
+  const int16_t* idx_t;  // [k][q]
+  int ld_idx_t, idx_t_rows;
   const uint8_t* keep0;
   const uint8_t* keep1;
   attn_seq_t seq;
@@ -39,7 +49,7 @@ static inline int att_fill_params(const vlm_attn_desc_t* d, attn_params_t& p) {
   if (d->bias_t && (!d->rel_index || d->R <= 0 || (d->ld_index & 3) || (d->pos1 & 3) || ((uintptr_t)d->rel_index & 7)))
     return VLM_ERR_ARG;
   if (d->mode != VLM_ATTN_JOINT && d->mode != VLM_ATTN_SEPARATE) return VLM_ERR_ARG;
-  if (d->R > 16384) return VLM_ERR_UNSUPPORTED;  // int16 index, LDS-resident bias column
+  if (d->R > 8191) return VLM_ERR_UNSUPPORTED;  // int16 byte offsets (4*index), LDS-resident bias column
   p.qkv = reinterpret_cast<const bf16_t*>(d->qkv);
   p.ld_qkv = d->ld_qkv;
   p.H = d->H;
@@ -53,12 +63,36 @@ static inline int att_fill_params(const vlm_attn_desc_t* d, attn_params_t& p) {
   p.idx = d->rel_index;
   p.ld_idx = d->ld_index;
   p.idx_rows = d->index_rows;
+  p.idx_t = d->rel_index_t;
+  p.ld_idx_t = d->ld_index_t;
+  p.idx_t_rows = d->index_t_rows;
   p.keep0 = d->keep0;
   p.keep1 = d->keep1;
   p.seq = (attn_seq_t){d->B, d->n0, d->n1, d->base0, d->base1, d->pos1};
   p.mode = d->mode;
   p.scale = d->scale;
   return VLM_OK;
+}
+
+// Bias byte-offsets (4 x relative-position index) of this lane's 32 (row, col) pairs of one 64-wide tile: 8 loads of
+// 8 B (4 consecutive columns each) from row `row` of `mat`, columns col0 + 32*kb + 8*g4 + 4*hh.  They are issued one
+// tile AHEAD (right after the previous tile's scores are formed, into the same 16 registers) so that their L2
+// round trip hides behind the softmax / P.V work instead of stalling the start of every tile.
+__device__ __forceinline__ void att_idx_tile(__amdgpu_buffer_rsrc_t mat, uint32_t row_off, uint32_t col0, int hh,
+                                             u32x2 (&iw)[8]) {
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      iw[kb * 4 + g4] = __builtin_amdgcn_raw_buffer_load_b64(mat, (row_off + col0 + kb * 32 + 8 * g4 + 4 * hh) * 2, 0, 0);
+}
+
+// Four byte-offsets for this lane's FAST position and the slow positions slow0..slow0+3 of a matrix stored
+// [slow][fast] (coalesced 16-bit loads; 4*hh*ld is folded into voff by the caller).
+__device__ __forceinline__ void att_idx4(__amdgpu_buffer_rsrc_t mat, uint32_t voff, uint32_t slow0, uint32_t ld2,
+                                         uint32_t (&o)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mat, voff, (slow0 + e) * ld2, 0);
 }
 
 // ---- key / query ranges of one sample ---------------------------------------------------------------------------

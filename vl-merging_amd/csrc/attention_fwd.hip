@@ -15,6 +15,7 @@
 // Softmax runs in the exp2 domain in fp32 (scale*log2e folded into one FMA with the gathered bias).
 #include "vlm_common.h"
 #include "attention_common.h"
+#include <type_traits>
 
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_params_t p) {
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_par
   }
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int16_t*>(p.idx), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
+  const uint32_t irow = (uint32_t)qpos * p.ld_idx;
+  u32x2 iw[8];
+  if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)kr.pos[kr.nt[0] > 0 ? 0 : 1], hh, iw);
 
   float m = -INFINITY, l = 0.f;
   f32x16 o[2];
@@ -92,50 +96,71 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_par
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ss], s[kb], 0, 0, 0);
       }
     }
-    // ---- scale + bias gather + mask ------------------------------------------------------------------------
+    // ---- scale + bias gather (+ mask only on tiles that can hold a masked / padded key) --------------------------
     float mx = -INFINITY;
+    const bool need_mask = (k0 + ATT_BK > kr.n[rng]) || (kr.keep[rng] != nullptr);  // wave-uniform
+    auto score = [&](auto masked) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int kl = kb * 32 + 8 * g4 + 4 * hh;  // local key of element 0 of this group of 4
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS) {
-          const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ridx, (uint32_t)(qpos * p.ld_idx + kpos0 + kl) * 2, 0, 0);
-          bv[0] = tab[w[0] & 0xffff];
-          bv[1] = tab[w[0] >> 16];
-          bv[2] = tab[w[1] & 0xffff];
-          bv[3] = tab[w[1] >> 16];
-        }
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(km + kl);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int kl = kb * 32 + 8 * g4 + 4 * hh;  // local key of element 0 of this group of 4
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (HAS_BIAS) {
+            const u32x2 w = iw[kb * 4 + g4];
+            bv[0] = att_tab(tab, w[0] & 0xffff);
+            bv[1] = att_tab(tab, w[0] >> 16);
+            bv[2] = att_tab(tab, w[1] & 0xffff);
+            bv[3] = att_tab(tab, w[1] >> 16);
+          }
+          f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+          if (decltype(masked)::value) mk = *reinterpret_cast<const f32x4*>(km + kl);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(s[kb][4 * g4 + e], c1, bv[e]) + mk[e];
-          s[kb][4 * g4 + e] = v;
-          mx = fmaxf(mx, v);
+          for (int e = 0; e < 4; ++e) {
+            float v = fmaf(s[kb][4 * g4 + e], c1, bv[e]);
+            if (decltype(masked)::value) v += mk[e];
+            s[kb][4 * g4 + e] = v;
+            mx = fmaxf(mx, v);
+          }
         }
       }
+    };
+    if (need_mask) score(std::true_type{});
+    else score(std::false_type{});
+    if (HAS_BIAS && t + 1 < ntiles) {  // next tile's indices: in flight during the softmax and P.V below
+      int rng1, k1;
+      att_tile_origin(kr, t + 1, rng1, k1);
+      att_idx_tile(ridx, irow, (uint32_t)(kr.pos[rng1] + k1), hh, iw);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m - m_use);  // m = -inf -> 0
-    m = m_new;
+    // deferred rescale (log2 domain): while no row of the wave grew by more than 2^6 keep the old maximum -- P then
+    // ranges up to 64 instead of 1 (same relative precision in bf16 / fp32) and the 32-register O rescale is skipped
+    float m_use;
+    const bool grow = !(mx - m <= 6.0f);  // also true for m = -inf (first tile) and NaN
+    if (__any(grow)) {
+      const float m_new = fmaxf(m, mx);
+      m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = att_exp2(m - m_use);  // m = -inf -> 0
+      m = m_new;
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
+    } else {
+      m_use = m;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = exp2f(s[kb][i] - m_use);
+        const float pv = att_exp2(s[kb][i] - m_use);
         s[kb][i] = pv;
         rs += pv;
       }
-    l = l * alpha + rs;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      o[0][i] *= alpha;
-      o[1][i] *= alpha;
-    }
+    l += rs;
     // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

@@ -278,7 +278,8 @@ class _BlockFn(torch.autograd.Function):
         lse = torch.empty(H, M, device=dev, dtype=F32)
         rp = pc.relpos
         ops.attention_fwd(qkv, o, lse, pc.seq, H, bias_t=bias_t, head_row0=plan.layer * H,
-                          rel_index=rp.index if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
+                          rel_index=rp.index if rp is not None else None,
+                          rel_index_t=rp.index_t if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
                           mode=plan.mode)
         x1 = torch.empty(M, D, device=dev, dtype=F32)
         y1 = torch.empty(M, D, device=dev, dtype=BF16)

@@ -152,8 +152,8 @@ class Seq:
         return self.B * (self.n0 + self.n1)
 
 
-def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, scale):
-    L.require_cuda(qkv, bias_t, rel_index, keep0, keep1)
+def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale):
+    L.require_cuda(qkv, bias_t, rel_index, rel_index_t, keep0, keep1)
     if qkv.dtype != BF16:
         raise L.VlmError("attention expects bf16 qkv")
     d = L.AttnDesc()
@@ -162,13 +162,21 @@ def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, sc
     d.H = H
     d.total_rows = qkv.shape[0]
     if bias_t is not None:
-        if bias_t.dtype != F32 or rel_index.dtype != torch.int16 or not bias_t.is_contiguous():
-            raise L.VlmError("attention bias_t must be contiguous f32 and rel_index int16")
+        if bias_t.dtype != F32 or not bias_t.is_contiguous():
+            raise L.VlmError("attention bias_t must be contiguous f32")
+        if rel_index_t is None or rel_index_t.dtype != torch.int16:
+            raise L.VlmError("attention needs the transposed int16 relative index (rel_index_t)")
         d.R = bias_t.shape[1]
         d.bias_t = bias_t.data_ptr()
-        d.rel_index = rel_index.data_ptr()
-        d.ld_index = _ld(rel_index)
-        d.index_rows = rel_index.shape[0]
+        d.rel_index_t = rel_index_t.data_ptr()
+        d.ld_index_t = _ld(rel_index_t)
+        d.index_t_rows = rel_index_t.shape[0]
+        if rel_index is not None:
+            if rel_index.dtype != torch.int16:
+                raise L.VlmError("rel_index must be int16")
+            d.rel_index = rel_index.data_ptr()
+            d.ld_index = _ld(rel_index)
+            d.index_rows = rel_index.shape[0]
     d.head_row0 = head_row0
     d.mode = mode
     for k in (keep0, keep1):
@@ -181,9 +189,9 @@ def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, sc
     return d
 
 
-def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=None, keep0=None, keep1=None,
-                  mode=L.ATTN_JOINT, scale=0.125):
-    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, scale)
+def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None, keep0=None,
+                  keep1=None, mode=L.ATTN_JOINT, scale=0.125):
+    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale)
     L.require_cuda(out, lse)
     rc = L.get_lib().vlm_attention_fwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(lse), L.stream_ptr())
     L.check(rc, "vlm_attention_fwd")
@@ -193,15 +201,13 @@ def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=
 def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None,
                   keep0=None, keep1=None, mode=L.ATTN_JOINT, scale=0.125, dbias_t=None, delta_ws=None):
     """dqkv <- d(loss)/d(qkv) (bf16, same layout as qkv); dbias_t += d(loss)/d(bias_t)."""
-    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, keep0, keep1, mode, scale)
-    L.require_cuda(out, dout, lse, dqkv, rel_index_t, dbias_t, delta_ws)
+    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale)
+    L.require_cuda(out, dout, lse, dqkv, dbias_t, delta_ws)
     if delta_ws is None:
         delta_ws = torch.empty(H, qkv.shape[0], device=qkv.device, dtype=F32)
-    if bias_t is not None and (rel_index_t is None or rel_index_t.dtype != torch.int16):
-        raise L.VlmError("attention_bwd needs the transposed int16 relative index")
-    rc = L.get_lib().vlm_attention_bwd(
-        ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(dout), _ld(dout), L.ptr(lse), L.ptr(delta_ws), L.ptr(rel_index_t),
-        _ld(rel_index_t) if rel_index_t is not None else 0, rel_index_t.shape[0] if rel_index_t is not None else 0,
-        L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t), L.stream_ptr())
+    if bias_t is not None and rel_index is None:
+        raise L.VlmError("attention_bwd needs both orientations of the int16 relative index")
+    rc = L.get_lib().vlm_attention_bwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(dout), _ld(dout), L.ptr(lse),
+                                       L.ptr(delta_ws), L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t), L.stream_ptr())
     L.check(rc, "vlm_attention_bwd")
     return dqkv

@@ -81,8 +81,11 @@ def build_relative_position_indices(window, max_text_len, max_text_len_of_initck
 
 def _index16(index, n0):
     """int16 index in kernel coordinates: text positions [0,n0), image positions start at pos1 = roundup(n0,4);
-    leading dimension padded to a multiple of 4.  Returns (index, transpose)."""
-    index = index.long()
+    leading dimension padded to a multiple of 4; values are 4 x index (byte offsets into the fp32 table column, see
+    include/vlm_hip.h).  Returns (index, transpose)."""
+    index = index.long() * 4
+    if int(index.max()) > 32767:
+        raise L.VlmError("relative-position table too large for int16 byte offsets (R <= 8191)")
     n = index.shape[0]
     n1 = n - n0
     pos1 = (n0 + 3) // 4 * 4
