@@ -116,14 +116,17 @@ int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, c
  */
 int vlm_layernorm_fwd(const float* x, int ldx, int M, int D, const float* gamma, const float* beta, float eps,
                       void* y, int ldy, int y_is_f32, float* stats, void* stream);
+/* workspace (optional, f32, >= VLM_ROW_WS_BYTES(D)): per-workgroup partial column sums folded by a second tiny
+ * launch; without it the column sums fall back to (heavily contended) float atomics. */
+#define VLM_ROW_WS_BYTES(D) ((size_t)1536 * 2 * (size_t)(D) * sizeof(float))
 int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx, const float* stats,
                       const float* gamma, int M, int D, const float* dres, int lddres, float* dx, int lddx,
-                      float* dgamma, float* dbeta, void* stream);
+                      float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes, void* stream);
 /* Backward of x_new = x + row_scale[m]*gamma[n]*y[m,n] (vision_transformer.py:586,:603) w.r.t. the branch:
  *   dy = bf16(row_scale*gamma*dx); dgamma[n] += sum_m row_scale*dx*y; dbias[n] += sum_m dy. */
 int vlm_layerscale_bwd(const float* dx, int lddx, const void* y_bf16, int ldy, const float* gamma,
                        const float* row_scale, int M, int D, void* dy_bf16, int lddy, float* dgamma, float* dbias,
-                       void* stream);
+                       float* workspace, size_t workspace_bytes, void* stream);
 /* out[n] += sum_m a[m,n] (bf16 a; N % 8 == 0): bias gradients of qkv / fc1 / heads. */
 int vlm_colsum_bf16(const void* a, int lda, int M, int N, float* out, void* stream);
 

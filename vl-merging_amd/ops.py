@@ -68,12 +68,27 @@ def layernorm_fwd(x, gamma, beta, eps, out, stats=None):
     return out
 
 
+_ROW_WS = {}
+
+
+def _row_workspace(device, D):
+    """Per-device scratch for the row kernels' per-workgroup column partials (VLM_ROW_WS_BYTES)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    n = 1536 * 2 * max(D, 1024)
+    ws = _ROW_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _ROW_WS[key] = torch.empty(n, device=device, dtype=F32)
+    return ws
+
+
 def layernorm_bwd(dy, x, stats, gamma, dx, dres=None, dgamma=None, dbeta=None):
     L.require_cuda(dy, x, stats, gamma, dx, dres, dgamma, dbeta)
     M, D = x.shape
+    ws = _row_workspace(x.device, D)
     rc = L.get_lib().vlm_layernorm_bwd(L.ptr(dy), _ld(dy), int(dy.dtype == F32), L.ptr(x), _ld(x), L.ptr(stats),
                                        L.ptr(gamma), M, D, L.ptr(dres), _ld(dres) if dres is not None else 0,
-                                       L.ptr(dx), _ld(dx), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr())
+                                       L.ptr(dx), _ld(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel() * 4,
+                                       L.stream_ptr())
     L.check(rc, "vlm_layernorm_bwd")
     return dx
 
@@ -81,8 +96,10 @@ def layernorm_bwd(dy, x, stats, gamma, dx, dres=None, dgamma=None, dbeta=None):
 def layerscale_bwd(dx, y, gamma, row_scale, dy, dgamma=None, dbias=None):
     L.require_cuda(dx, y, gamma, row_scale, dy, dgamma, dbias)
     M, D = dx.shape
+    ws = _row_workspace(dx.device, D)
     rc = L.get_lib().vlm_layerscale_bwd(L.ptr(dx), _ld(dx), L.ptr(y), _ld(y), L.ptr(gamma), L.ptr(row_scale), M, D,
-                                        L.ptr(dy), _ld(dy), L.ptr(dgamma), L.ptr(dbias), L.stream_ptr())
+                                        L.ptr(dy), _ld(dy), L.ptr(dgamma), L.ptr(dbias), L.ptr(ws), ws.numel() * 4,
+                                        L.stream_ptr())
     L.check(rc, "vlm_layerscale_bwd")
     return dy
 
