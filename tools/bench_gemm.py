@@ -25,7 +25,7 @@ def timeit(fn, n=20):
 
 
 def main():
-    M = 22 * 617
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 22 * 617
     shapes = [("qkv fwd", False, False, M, 2304, 768), ("proj fwd", False, False, M, 768, 768),
               ("fc1 fwd", False, False, M, 3072, 768), ("fc2 fwd", False, False, M, 768, 3072),
               ("fc1 dgrad", False, True, M, 768, 3072), ("fc2 dgrad", False, True, M, 3072, 768),

@@ -161,6 +161,74 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
   const vlm_epilogue_t& e = p.epi;
   // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
   const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
+  if (vec_ok && mw0 + 64 <= p.M && nw0 + 64 <= p.N) {
+    // Interior sub-tile.  The residual may alias C (in-place residual stream), so in the general loop below the
+    // compiler must keep every load behind the previous store: 16 dependent load->store round trips per wave.  Here
+    // all epilogue inputs of a 32-row half are fetched first (8-24 loads in flight), then combined and stored.
+    const bool has_res = e.residual != nullptr, bwd = e.act == VLM_ACT_GELU_BWD, accum = OUT_F32 && e.accumulate;
+    const int nl = nw0 + (lane >> 4) * 4;
+    f32x4 bia[4], gam[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bia[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nl + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      gam[j] = e.col_scale ? *reinterpret_cast<const f32x4*>(e.col_scale + nl + j * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x4 rsd[2][4], old[2][4];
+      bf16x4 hx[2][4];
+      float rs[2];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const size_t m = mw0 + (hf * 2 + ii) * 16 + (lane & 15);
+        rs[ii] = e.row_scale ? e.row_scale[m] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = nl + j * 16;
+          if (has_res) rsd[ii][j] = *reinterpret_cast<const f32x4*>(e.residual + m * e.ld_res + n);
+          if (bwd) hx[ii][j] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(e.aux) + m * e.ld_aux + n);
+          if (accum) old[ii][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n);
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const size_t m = mw0 + (hf * 2 + ii) * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = nl + j * 16;
+          f32x4 v = acc[hf * 2 + ii][j] * e.alpha + bia[j];
+          if (bwd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)hx[ii][j][r]);
+          } else {
+            if (e.aux) {
+              bf16x4 h;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = (bf16_t)v[r];
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(e.aux) + m * e.ld_aux + n) = h;
+            }
+            if (e.act == VLM_ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+          }
+          if (e.col_scale) v *= gam[j];
+          if (e.row_scale) v *= rs[ii];
+          if (has_res) v += rsd[ii][j];
+          if (OUT_F32) {
+            if (accum) v += old[ii][j];
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+          } else {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = mw0 + i * 16 + (lane & 15);
@@ -408,21 +476,22 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 }
 
 // ======================================================================================================================
-// 256x128x64 tile, 8 waves (4x2, 64x64 each), THREE-stage LDS ring (3 x 48 KiB) filled by LDS-DMA with a counted
-// s_waitcnt: the 128x128 kernel above has one stage in flight and 2 workgroups per CU, so every K-step waits out a full
-// L2->LDS round trip (~2k cycles) for ~0.5-1k cycles of MFMA work (measured 23 % MFMA issue on K=768 shapes).  Here the
-// DMA for K-step t+2 is issued while step t computes; a wave waits only until ITS OWN loads for step t have landed
-// (vmcnt(6): the 6 DMA instructions of step t+1 may stay in flight), then one raw s_barrier publishes the stage.
-// A must be K-contiguous (forward and dgrad GEMMs); B K-contiguous or K-strided.
+// 256x256x64 tile, 8 waves (2x4), 128x64 per wave, two LDS stages of 64 KiB filled by LDS-DMA.
+// Why: one LDS-DMA wave instruction (1 KiB) costs 60-180 issue cycles (MI355X_MICROARCH.md, cycle constants) against
+// 16 for an MFMA 16x16x32; a tile stages 16*(BM+BN)/(BM*BN) DMA instructions per MFMA = 0.25 for 128x128 (DMA issue
+// time > MFMA time: the measured ~40 % ceiling of the kernel above) but 0.125 for 256x256 with 64 MFMAs per wave and
+// K-step.  One workgroup per CU (128 KiB LDS), 2 waves per SIMD.  A must be K-contiguous; B either orientation.
 #define BIG_BM 256
+#define BIG_BN 256
 #define BIG_THREADS 512
-#define BIG_STAGE_BYTES (48 * 1024)
+#define BIG_STAGE_BYTES (64 * 1024)
 
 template <bool TB>
 __device__ __forceinline__ void big_stage_dma(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned char* stage,
                                               uint32_t m0, uint32_t n0, uint32_t k0, uint32_t lda, uint32_t ldb,
                                               int wave, int lane) {
-  // A: [256 rows][64 k], 32 instructions of 8 rows; B: 16 instructions (8 rows, or 4 k-rows when K-strided)
+  // A: [256 rows][64 k] = 32 instructions of 8 rows.  B: K-contiguous [256][64] (32 instructions of 8 rows) or
+  // K-strided as two [64][128] sub-tiles of 16 KiB (16 instructions of 4 k-rows each).
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int j = wave + 8 * u;
@@ -431,16 +500,17 @@ __device__ __forceinline__ void big_stage_dma(__amdgpu_buffer_rsrc_t ra, __amdgp
   }
   unsigned char* sb = stage + 32 * 1024;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int j = wave + 8 * u;
+  for (int u = 0; u < 4; ++u) {
+    const int j = wave + 8 * u;  // 0..31
     uint32_t off;
     if (!TB) {
       const uint32_t row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
       off = ((n0 + row) * ldb + k0 + chunk * 8) * 2;
     } else {
-      const uint32_t krow = j * 4 + (lane >> 4), s16 = lane & 15;
+      const uint32_t sub = j >> 4, jj = j & 15;  // sub-tile (128 columns each), instruction inside it
+      const uint32_t krow = jj * 4 + (lane >> 4), s16 = lane & 15;
       const uint32_t c32 = (s16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
-      off = ((k0 + krow) * ldb + n0 + (c32 * 2 + (s16 & 1)) * 8) * 2;
+      off = ((k0 + krow) * ldb + n0 + sub * 128 + (c32 * 2 + (s16 & 1)) * 8) * 2;
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb + j * 1024), 16, off, 0, 0, 0);
   }
@@ -452,61 +522,65 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // 4x2 waves, 64x64 each
+  const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 128x64 each
 
   const uint32_t nblk = gridDim.x, bid = blockIdx.x;
   const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const uint32_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const uint32_t m0 = tm * BIG_BM, n0 = tn * GEMM_BN;
+  const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG_BN;
 
   const __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.B), 0, (int)((uint64_t)(TB ? p.K : p.N) * p.ldb * 2), 0x00020000);
 
-  f32x4 acc[4][4];
+  f32x4 acc[2][4][4];  // [64-row half][16-row block][16-col block]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[hf][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / GEMM_BK;  // K % 64 == 0 guaranteed by the launcher
   big_stage_dma<TB>(ra, rb, smem, m0, n0, 0, p.lda, p.ldb, wave, lane);
-  if (nk > 1) big_stage_dma<TB>(ra, rb, smem + BIG_STAGE_BYTES, m0, n0, GEMM_BK, p.lda, p.ldb, wave, lane);
-
-  int st = 0;  // stage of step kt
+  __syncthreads();  // drains the DMA (vmcnt(0))
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) {
-      const int s2 = st >= 1 ? st - 1 : 2;  // (st + 2) % 3: the stage read during step kt-1, free after the barrier
-      big_stage_dma<TB>(ra, rb, smem + s2 * BIG_STAGE_BYTES, m0, n0, (kt + 2) * GEMM_BK, p.lda, p.ldb, wave, lane);
-    }
-    const unsigned char* la = smem + st * BIG_STAGE_BYTES;
+    const int cur = kt & 1;
+    if (kt + 1 < nk)
+      big_stage_dma<TB>(ra, rb, smem + (cur ^ 1) * BIG_STAGE_BYTES, m0, n0, (kt + 1) * GEMM_BK, p.lda, p.ldb, wave, lane);
+    const unsigned char* la = smem + cur * BIG_STAGE_BYTES;
     const unsigned char* lb = la + 32 * 1024;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag_load<false>(la, wm * 4 + i, ks, lane);
+      for (int j = 0; j < 4; ++j) {
+        const int xb = wn * 4 + j;  // 16-column block of the 256-wide B tile
+        fb[j] = TB ? frag_load<true>(lb + (xb >> 3) * (16 * 1024), xb & 7, ks, lane) : frag_load<false>(lb, xb, ks, lane);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = frag_load<TB>(lb, wn * 4 + j, ks, lane);
+      for (int hf = 0; hf < 2; ++hf) {
+        bf16x8 fa[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) fa[i] = frag_load<false>(la, wm * 8 + hf * 4 + i, ks, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[hf][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[hf][i][j], 0, 0, 0);
+      }
     }
-    st = st == 2 ? 0 : st + 1;
+    __syncthreads();
   }
-  gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  gemm_epilogue<OUT_F32>(p, acc[0], m0 + wm * 128, n0 + wn * 64, lane);
+  gemm_epilogue<OUT_F32>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, lane);
 }
 
 template <bool TB, bool OUT_F32>
 static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
-  const size_t smem = 3 * BIG_STAGE_BYTES;
+  const size_t smem = 2 * BIG_STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_big_kernel<TB, OUT_F32>),
@@ -515,6 +589,7 @@ static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
     attr_set = true;
   }
   p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+  p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
   dim3 grid(p.tiles_m * p.tiles_n), block(BIG_THREADS);
   hipLaunchKernelGGL((vlm_gemm_big_kernel<TB, OUT_F32>), grid, block, smem, stream, p);
   VLM_CHECK_LAUNCH();
@@ -589,13 +664,14 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
   }
-  // 256x128 three-stage kernel: A K-contiguous, whole 64-deep K tiles, and enough 256-row tiles to fill the chip
+  // 256x256 kernel: A K-contiguous, whole 64-deep K tiles, and at least ~2 rounds of 256 workgroups
   static int big_mode = -1;
   if (big_mode < 0) {
     const char* e = getenv("VLM_GEMM_BIG");
-    big_mode = e ? atoi(e) : 0;  // off by default: measured equal to the 128x128 kernel on the training shapes
+    big_mode = e ? atoi(e) : 0;  // off: one workgroup per CU leaves prologue+epilogue exposed at K=768 (measured 10-40 % slower)
   }
-  if (big_mode && !ta && (K % GEMM_BK) == 0 && ((M + BIG_BM - 1) / BIG_BM) * p.tiles_n >= 512) {
+  if (big_mode && !ta && (K % GEMM_BK) == 0 &&
+      ((M + BIG_BM - 1) / BIG_BM) * ((N + BIG_BN - 1) / BIG_BN) >= big_mode * 500) {
     if (tb) return c_is_f32 ? launch_gemm_big<true, true>(p, s) : launch_gemm_big<true, false>(p, s);
     return c_is_f32 ? launch_gemm_big<false, true>(p, s) : launch_gemm_big<false, false>(p, s);
   }
