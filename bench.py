@@ -93,6 +93,29 @@ class GemmTimer:
         return {"launches": n, "seconds": t, "flop": fl, "avg_us": t / n * 1e6, "tflops": fl / t / 1e12}
 
 
+def calibrate(dev):
+    """What this box attains with vendor code (report nominal AND attainable peaks): a large bf16 GEMM
+    through torch (hipBLASLt) and a device-to-device copy.  Context for roofline.frac; never used as its denominator."""
+    def ev_time(fn, n):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+    a = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+    t_mm = ev_time(lambda: torch.matmul(a, b), 10)
+    src = torch.empty(1 << 28, device=dev, dtype=torch.float32)  # 1 GiB
+    dst = torch.empty_like(src)
+    t_cp = ev_time(lambda: dst.copy_(src), 10)
+    return {"hipblaslt_bf16_8192_tflops": 2.0 * 8192 ** 3 / t_mm / 1e12,
+            "d2d_copy_GBps": 2.0 * src.numel() * 4 / t_cp / 1e9}
+
+
 def cpu_baseline(seconds_budget=30.0):
     """The oracle (parity-pinned CPU restatement of the reference) on this host: base_vl ufo, 224x224, B=2,
     mlm+itm+ifm fwd+bwd (BASELINE configs[0]); bounded sample."""
@@ -169,6 +192,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-merge", action="store_true")
+    ap.add_argument("--no-gemm-timer", action="store_true", help="skip the per-launch HIP events (overhead check)")
+    ap.add_argument("--no-calibrate", action="store_true", help="skip the attainable-peak probes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -216,7 +241,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     fence()
-    timer.on = rank == 0
+    timer.on = rank == 0 and not args.no_gemm_timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -250,6 +275,8 @@ def main():
                                "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "vlm_gemm_kernel",
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "gemm_share_of_step": gs["seconds"] / dt}
+        if not args.no_calibrate:
+            out["attainable"] = calibrate(dev)
         if not args.no_merge:
             bm = importlib.import_module("vl_merging_amd.bench_merge")
             del model, opt

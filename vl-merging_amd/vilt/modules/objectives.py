@@ -125,7 +125,7 @@ def compute_mlm_itm_fused(pl_module, batch, sim_i2t, sim_t2i):
     mlm_labels = batch["text_labels_mlm"]
     mlm_loss = F.cross_entropy(mlm_logits.float().view(-1, pl_module.hparams.config["vocab_size"]),
                                mlm_labels.view(-1), ignore_index=-100)
-    itm_labels = torch.cat([torch.ones(bsz), torch.zeros(bsz), torch.zeros(bsz)]).to(img.device)
+    itm_labels = torch.cat([torch.ones(bsz, device=img.device), torch.zeros(2 * bsz, device=img.device)])
     itm_logits = pl_module.itm_score(infer["cls_feats"][bsz:])
     itm_loss = F.cross_entropy(itm_logits.float(), itm_labels.long())
     return {"mlm_loss": mlm_loss * pl_module.hparams.config["vl_mlm_weight"], "mlm_logits": mlm_logits,
@@ -139,7 +139,7 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
     host round trip."""
     bsz = batch["text_ids_mlm"].size(0)
     dev = batch["text_ids"].device
-    itm_labels = torch.cat([torch.ones(bsz), torch.zeros(bsz), torch.zeros(bsz)]).to(dev)
+    itm_labels = torch.cat([torch.ones(bsz, device=dev), torch.zeros(2 * bsz, device=dev)])
     infer_pos = pl_module.infer(batch, mask_text=False, mask_image=False)
     with torch.no_grad():
         all_text_ids = _gather_cat(infer_pos["text_ids"])
