@@ -28,7 +28,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 1
+#define VLM_ABI_VERSION 2
 int vlm_abi_version(void);
 /* Number of compute units of the current device (grid sizing), or negative error. */
 int vlm_device_cus(void);
@@ -81,6 +81,8 @@ int vlm_merge_run(const void* workspace, void* stream);
  *         GELU_BWD  : v = v * gelu_erf'(aux[m,n])   (aux is an INPUT: the saved pre-activation)
  *   out = residual[m,n] + row_scale[m] * col_scale[n] * v     (each factor optional)
  *   C   = out  (bf16 or f32)  or  C += out (f32, accumulate != 0)
+ *   col_sum[n] += sum_m C[m,n] (optional, fp32 atomics, value before the bf16 rounding): the bias gradient of the
+ *         layer whose dY this GEMM produces (fc1 bias from the GELU-backward dgrad), saving a pass over dY
  * Requirements: lda, ldb multiples of 8; ldc, ld_aux, ld_res multiples of 4; 16-B aligned bases; K % 64 == 0
  * unless both operands are K-strided (ta=1 and tb=1).  Ragged M and N are handled in hardware.
  */
@@ -100,6 +102,7 @@ typedef struct {
   float alpha;
   int32_t accumulate;
   int32_t reserved;
+  float* col_sum;          /* f32 [N] or NULL: accumulated column sums of the values written to C */
 } vlm_epilogue_t;
 
 int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
@@ -196,9 +199,18 @@ typedef struct {
 } vlm_attn_desc_t;
 
 int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out_bf16, int ld_out, float* lse, void* stream);
-/* delta_ws: f32 [H, total_rows] scratch.  dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED. */
+/* Optional fused bias gradients: dq[s] / dv[s] (f32 [H*64], may be NULL) are ACCUMULATED with the column sums of dQ /
+ * dV over the rows of segment s (0 = text rows, 1 = image rows; modality experts own different q_bias / v_bias,
+ * vision_transformer.py:335), taken while the tiles are still in registers instead of re-reading dqkv. */
+typedef struct {
+  float* dq[2];
+  float* dv[2];
+} vlm_attn_colsum_t;
+
+/* delta_ws: f32 [H, total_rows] scratch.  dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED.  colsum may be NULL. */
 int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out_bf16, int ld_out, const void* dout_bf16, int ld_dout,
-                      const float* lse, float* delta_ws, void* dqkv_bf16, int ld_dqkv, float* dbias_t, void* stream);
+                      const float* lse, float* delta_ws, void* dqkv_bf16, int ld_dqkv, float* dbias_t,
+                      const vlm_attn_colsum_t* colsum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -148,8 +148,18 @@ def test_attention_bwd(ops, L, ci, sep, with_bias):
     ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
     dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
     dbias_t = torch.zeros_like(bias_t) if with_bias else None
-    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
+    # fused q_bias / v_bias gradients: per-segment column sums of dQ / dV, accumulated onto existing values
+    csq = [torch.full((D,), 0.5, device="cuda"), torch.full((D,), -1.0, device="cuda")]
+    csv = [torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")]
+    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, dq_colsum=csq, dv_colsum=csv, **kw)
     torch.cuda.synchronize()
+    n_text = seq.B * seq.n0
+    for sgm, rows_s in ((0, slice(0, n_text)), (1, slice(n_text, rows))):
+        for name, got, sl, init in (("dq", csq[sgm], slice(0, D), (0.5, -1.0)[sgm]), ("dv", csv[sgm], slice(2 * D, 3 * D), 0.0)):
+            want = dqkv[rows_s, sl].float().sum(0)  # the kernel sums the fp32 values it rounds to bf16 for dqkv
+            err = (got - init - want).abs()
+            lim = 2e-2 * float(want.abs().max()) + 0.05
+            assert float(err.max()) <= lim, "%s colsum seg %d: err %.4g lim %.4g" % (name, sgm, float(err.max()), lim)
     # reference
     q32 = c["qkv"].float().requires_grad_(True)
     tab = c["table"].clone().requires_grad_(True) if with_bias else None

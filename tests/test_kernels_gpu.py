@@ -163,6 +163,19 @@ def test_gemm_epilogues(ops, L):
     hh = h.float().requires_grad_(True)
     torch.nn.functional.gelu(hh).backward(acc)
     assert_close(d, hh.grad, 1e-2, 1e-2, "gelu bwd")
+    # fused bias gradient: col_sum += column sums of what the epilogue wrote (M = 1234 has interior AND edge tiles)
+    cs = torch.full((N,), 3.0, device="cuda")
+    ops.gemm(A, B, d, act=L.ACT_GELU_BWD, aux=h, alpha=0.05, col_sum=cs)
+    assert_close(cs - 3.0, hh.grad.sum(0), 2e-3, 2e-2, "col_sum (gelu bwd, bf16 out)")
+    cs32 = torch.zeros(N, device="cuda")
+    o32 = torch.empty(M, N, device="cuda")
+    ops.gemm(A, B, o32, bias=bias, alpha=0.05, col_sum=cs32)
+    assert_close(cs32, y.sum(0), 2e-3, 2e-2, "col_sum (f32 out)")
+    # ragged N (scalar tail path)
+    cs_r = torch.zeros(N, device="cuda")
+    o_r = torch.empty(M, 50, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B[:50], o_r, alpha=0.05, col_sum=cs_r)
+    assert_close(cs_r[:50], acc[:, :50].sum(0), 2e-3, 2e-2, "col_sum (ragged N)")
 
 
 def test_gemm_vocab_ragged_n(ops):

@@ -32,8 +32,12 @@ class Epilogue(ctypes.Structure):
     _fields_ = [
         ("bias", c_void_p), ("col_scale", c_void_p), ("row_scale", c_void_p), ("residual", c_void_p),
         ("ld_res", ctypes.c_int64), ("aux", c_void_p), ("ld_aux", ctypes.c_int64), ("act", ctypes.c_int32),
-        ("alpha", c_float), ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("alpha", c_float), ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32), ("col_sum", c_void_p),
     ]
+
+
+class AttnColsum(ctypes.Structure):
+    _fields_ = [("dq", c_void_p * 2), ("dv", c_void_p * 2)]
 
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
@@ -69,7 +73,7 @@ SIGNATURES = {
                               c_int, ctypes.POINTER(Epilogue), c_void_p]),
     "vlm_attention_fwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_void_p]),
     "vlm_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                  c_void_p, c_int, c_void_p, c_void_p]),
+                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vlm_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p]),
     "vlm_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,

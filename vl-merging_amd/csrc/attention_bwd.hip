@@ -43,6 +43,8 @@ struct attn_bwd_params_t {
   bf16_t* dqkv;           // [rows, 3*H*64]
   int ld_dqkv;
   float* dbias_t;         // [n_cols, R] accumulate
+  float* dq_colsum[2];    // per segment (0 text rows, 1 image rows): [H*64] += column sums of dQ (q_bias grad) or NULL
+  float* dv_colsum[2];    // same for dV (v_bias gradient)
 };
 
 // ----------------------------------------------------------------------------------------------------- dQ kernel
@@ -189,6 +191,26 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         for (int e = 0; e < 4; ++e) v[e] = (bf16_t)o[db][4 * g4 + e];
         *reinterpret_cast<bf16x4*>(op + db * 32 + 8 * g4) = v;
       }
+  }
+  if (bp.dq_colsum[seg]) {
+    // q_bias gradient = column sums of dQ: the 128x64 tile goes through LDS (row stride 68 floats: conflict-free
+    // 16-B writes), every thread sums 32 rows of one column, 256 atomics per workgroup -- no second pass over dqkv
+    float* red = reinterpret_cast<float*>(smem);
+    const int lr = wave * 32 + r;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qvalid) v = (f32x4){o[db][4 * g4], o[db][4 * g4 + 1], o[db][4 * g4 + 2], o[db][4 * g4 + 3]};
+        *reinterpret_cast<f32x4*>(red + lr * 68 + db * 32 + 8 * g4 + 4 * hh) = v;
+      }
+    __syncthreads();
+    const int col = tid & 63, part = tid >> 6;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) sum += red[(part * 32 + i) * 68 + col];
+    atomicAdd(bp.dq_colsum[seg] + h * 64 + col, sum);
   }
 }
 
@@ -362,6 +384,23 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
           dst[D + db * 32] = (bf16_t)dv[db][i];
         }
       }
+    }
+    if (bp.dv_colsum[seg]) {  // v_bias gradient = column sums of dV over this workgroup's 128 keys: 64 atomics
+      float* red = reinterpret_cast<float*>(smem);
+      __syncthreads();
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kl = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kbase + kl < nk) sum += dv[db][i];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        if (hh == 0) red[wave * 64 + db * 32 + r] = sum;
+      }
+      __syncthreads();
+      if (tid < 64) atomicAdd(bp.dv_colsum[seg] + h * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
     }
   }
 }
@@ -554,7 +593,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const at
 
 extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int ld_out, const void* d_out,
                                  int ld_dout, const float* lse, float* delta_ws, void* dqkv, int ld_dqkv,
-                                 float* dbias_t, void* stream) {
+                                 float* dbias_t, const vlm_attn_colsum_t* colsum, void* stream) {
   attn_bwd_params_t bp;
   int rc = att_fill_params(d, bp.f);
   if (rc != VLM_OK) return rc;
@@ -573,6 +612,10 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   bp.dqkv = reinterpret_cast<bf16_t*>(dqkv);
   bp.ld_dqkv = ld_dqkv;
   bp.dbias_t = dbias_t;
+  for (int sgm = 0; sgm < 2; ++sgm) {
+    bp.dq_colsum[sgm] = colsum ? colsum->dq[sgm] : nullptr;
+    bp.dv_colsum[sgm] = colsum ? colsum->dv[sgm] : nullptr;
+  }
 
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;

@@ -152,7 +152,18 @@ struct gemm_params_t {
   vlm_epilogue_t epi;
   int tiles_m, tiles_n;
   int splits, ksteps_per_split;  // split-K (wgrad): block -> (tile, K slice), fp32 atomic accumulation
+#ifdef VLM_GEMM_STAMPS
+  unsigned long long* stamps;  // diagnostic build only (tools/stamp_gemm.py): 8 u64 per workgroup
+#endif
 };
+
+// v_permlane16_swap_b32: x' = [x.row0, y.row0, x.row2, y.row2], y' = [x.row1, y.row1, x.row3, y.row3] (rows = 16 lanes;
+// probed on gfx950, tools/scratch/permlane.hip).  Inline asm: hipcc 7.2 folds four __builtin_amdgcn_permlane16_swap
+// calls on the elements of a vector into ONE swap + broadcast (wrong results); s_nop covers the VALU-write -> swap-read
+// distance the assembler cannot see.
+__device__ __forceinline__ void lane16_swap(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
 
 // ---- fused epilogue of one wave's 64x64 sub-tile (swapped layout: lane holds row m = mw0 + 16i + (lane&15) and the
 // 4 consecutive columns n = nw0 + 16j + 4*(lane>>4) + r) -----------------------------------------------------------
@@ -161,71 +172,136 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
   const vlm_epilogue_t& e = p.epi;
   // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
   const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
-  if (vec_ok && mw0 + 64 <= p.M && nw0 + 64 <= p.N) {
-    // Interior sub-tile.  The residual may alias C (in-place residual stream), so in the general loop below the
-    // compiler must keep every load behind the previous store: 16 dependent load->store round trips per wave.  Here
-    // all epilogue inputs of a 32-row half are fetched first (8-24 loads in flight), then combined and stored.
+  const bool vec8_ok = vec_ok && (OUT_F32 || (p.ldc & 7) == 0) && (!e.aux || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux & 15) == 0)) &&
+                       (!e.residual || ((uintptr_t)e.residual & 15) == 0) && (!e.bias || ((uintptr_t)e.bias & 15) == 0) &&
+                       (!e.col_scale || ((uintptr_t)e.col_scale & 15) == 0);
+  if (vec8_ok && mw0 + 64 <= p.M && nw0 + 64 <= p.N) {
+    // Interior sub-tile, two measures against the store-issue-bound tail (16 dwordx2 per lane ~ 9.4k cycles/tile):
+    // (1) v_permlane16_swap_b32 between the accumulators of column blocks 2jp and 2jp+1 leaves every lane with 8
+    //     consecutive columns (block 2jp+(g&1), columns 8(g>>1)..+7, g = lane>>4), so bf16 results leave as 8
+    //     dwordx4 stores and every aux / residual / bias read is 16 B wide;
+    // (2) the residual may alias C (in-place residual stream): all epilogue inputs of a 32-row half are fetched
+    //     before anything is stored, instead of 16 dependent load->store round trips.
     const bool has_res = e.residual != nullptr, bwd = e.act == VLM_ACT_GELU_BWD, accum = OUT_F32 && e.accumulate;
-    const int nl = nw0 + (lane >> 4) * 4;
-    f32x4 bia[4], gam[4];
+    const int g = lane >> 4;
+    const int nl = nw0 + (g & 1) * 16 + (g >> 1) * 8;  // + 32*jp
+    float bia[2][8], gam[2][8], csum[2][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bia[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nl + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      gam[j] = e.col_scale ? *reinterpret_cast<const f32x4*>(e.col_scale + nl + j * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
-    }
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) csum[jp][r] = 0.f;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 b4 = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nl + jp * 32 + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 g4 = e.col_scale ? *reinterpret_cast<const f32x4*>(e.col_scale + nl + jp * 32 + q * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bia[jp][q * 4 + r] = b4[r]; gam[jp][q * 4 + r] = g4[r]; }
+      }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      f32x4 rsd[2][4], old[2][4];
-      bf16x4 hx[2][4];
+      f32x4 rsd[2][2][2], old[2][2][2];
+      bf16x8 hx[2][2];
       float rs[2];
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const size_t m = mw0 + (hf * 2 + ii) * 16 + (lane & 15);
         rs[ii] = e.row_scale ? e.row_scale[m] : 1.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = nl + j * 16;
-          if (has_res) rsd[ii][j] = *reinterpret_cast<const f32x4*>(e.residual + m * e.ld_res + n);
-          if (bwd) hx[ii][j] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(e.aux) + m * e.ld_aux + n);
-          if (accum) old[ii][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n);
+        for (int jp = 0; jp < 2; ++jp) {
+          const int n = nl + jp * 32;
+          if (has_res) {
+            rsd[ii][jp][0] = *reinterpret_cast<const f32x4*>(e.residual + m * e.ld_res + n);
+            rsd[ii][jp][1] = *reinterpret_cast<const f32x4*>(e.residual + m * e.ld_res + n + 4);
+          }
+          if (bwd) hx[ii][jp] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(e.aux) + m * e.ld_aux + n);
+          if (accum) {
+            old[ii][jp][0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n);
+            old[ii][jp][1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.C) + m * p.ldc + n + 4);
+          }
         }
       }
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const size_t m = mw0 + (hf * 2 + ii) * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = nl + j * 16;
-          f32x4 v = acc[hf * 2 + ii][j] * e.alpha + bia[j];
+        for (int jp = 0; jp < 2; ++jp) {
+          const int n = nl + jp * 32;
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // alpha first: a compiler-scheduled VALU op consumes the MFMA result (hazard handled by hipcc), the swap
+            // then reads VALU results
+            float x = acc[hf * 2 + ii][2 * jp][r] * e.alpha, y = acc[hf * 2 + ii][2 * jp + 1][r] * e.alpha;
+            lane16_swap(x, y);
+            v[r] = x;
+            v[4 + r] = y;
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += bia[jp][r];
           if (bwd) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)hx[ii][j][r]);
+            for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)hx[ii][jp][r]);
           } else {
             if (e.aux) {
-              bf16x4 h;
+              bf16x8 h;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (bf16_t)v[r];
-              *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(e.aux) + m * e.ld_aux + n) = h;
+              for (int r = 0; r < 8; ++r) h[r] = (bf16_t)v[r];
+              *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(e.aux) + m * e.ld_aux + n) = h;
             }
             if (e.act == VLM_ACT_GELU) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+              for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
             }
           }
-          if (e.col_scale) v *= gam[j];
-          if (e.row_scale) v *= rs[ii];
-          if (has_res) v += rsd[ii][j];
-          if (OUT_F32) {
-            if (accum) v += old[ii][j];
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
-          } else {
-            bf16x4 o;
+          if (e.col_scale) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
+            for (int r = 0; r < 8; ++r) v[r] *= gam[jp][r];
+          }
+          if (e.row_scale) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= rs[ii];
+          }
+          if (has_res) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += rsd[ii][jp][r >> 2][r & 3];
+          }
+          if (OUT_F32 && accum) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += old[ii][jp][r >> 2][r & 3];
+          }
+          if (e.col_sum) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) csum[jp][r] += v[r];
+          }
+          if (OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+            *reinterpret_cast<f32x4*>(c) = (f32x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(c + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+          } else {
+            bf16x8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
           }
         }
       }
+    }
+    if (e.col_sum) {
+      // column sums of this wave's 64 rows: 4 row blocks summed in the lane above, the 16 rows of a block by DPP
+      // rotations inside the 16-lane row; lane 0 of each row then owns 16 columns -> 64 fp32 atomics per wave
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float t = csum[jp][r];
+          t += dpp_f32<0x128>(t);
+          t += dpp_f32<0x124>(t);
+          t += dpp_f32<0x122>(t);
+          t += dpp_f32<0x121>(t);
+          if ((lane & 15) == 0) atomicAdd(e.col_sum + nl + jp * 32 + r, t);
+        }
     }
     return;
   }
@@ -285,8 +361,16 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
             const f32x4 old = *reinterpret_cast<const f32x4*>(c);
             o += old;
           }
+          if (e.col_sum) {  // edge tiles only: plain atomics
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(e.col_sum + n + r, o[r]);
+          }
           *reinterpret_cast<f32x4*>(c) = o;
         } else {
+          if (e.col_sum) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(e.col_sum + n + r, v[r]);
+          }
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
@@ -305,9 +389,10 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
           if (e.col_scale) x *= e.col_scale[n + r];
           if (e.row_scale) x *= rs;
           if (e.residual) x += e.residual[(size_t)m * e.ld_res + n + r];
+          if (OUT_F32 && e.accumulate) x += reinterpret_cast<const float*>(p.C)[(size_t)m * p.ldc + n + r];
+          if (e.col_sum) atomicAdd(e.col_sum + n + r, x);
           if (OUT_F32) {
-            float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n + r;
-            *c = e.accumulate ? (*c + x) : x;
+            reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + r] = x;
           } else {
             reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n + r] = (bf16_t)x;
           }
@@ -328,6 +413,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64x64 each
+#ifdef VLM_GEMM_STAMPS
+#define STAMP(k)                                                                       \
+  if (p.stamps && tid == 0) {                                                          \
+    p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();             \
+    if ((k) == 0 || (k) == 3) p.stamps[(size_t)blockIdx.x * 8 + 4 + (k) / 3] = __builtin_amdgcn_s_memrealtime(); \
+  }
+#else
+#define STAMP(k)
+#endif
+  STAMP(0)
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
   // run of tiles with n fastest so a 128-row A panel is reused out of that XCD's L2 (bijective for any grid).
@@ -375,6 +470,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     else { stage_load<TB>(sb, rb, n0, kt0 * GEMM_BK, p.ldb, tid); stage_store<TB>(sb, LDS_B(0), tid); }
   }
   __syncthreads();  // hipcc drains a pending LDS-DMA (vmcnt(0)) in front of the barrier
+  STAMP(1)
 
   for (int kt = kt0; kt < kt1; ++kt) {
     const int cur = (kt - kt0) & 1;
@@ -439,6 +535,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     }
     __syncthreads();
   }
+  STAMP(2)
 
   if (SPLITK) {
     float* C = reinterpret_cast<float*>(p.C);
@@ -457,7 +554,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
   }
 
   gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+#ifdef VLM_GEMM_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);  // stores issued AND acknowledged for this wave
+  STAMP(3)
+#endif
 }
+
+#ifdef VLM_GEMM_STAMPS
+static unsigned long long* g_stamp_buffer = nullptr;
+extern "C" void vlm_debug_set_stamp_buffer(void* ptr) { g_stamp_buffer = (unsigned long long*)ptr; }
+#endif
 
 template <bool TA, bool TB, bool OUT_F32, bool DMA_A, bool DMA_B, bool SPLITK>
 static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
@@ -648,11 +754,14 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   p.splits = 1;
   p.ksteps_per_split = 0;
+#ifdef VLM_GEMM_STAMPS
+  p.stamps = g_stamp_buffer;
+#endif
   hipStream_t s = (hipStream_t)stream;
   // split-K: pure accumulation into fp32 (wgrad), few output tiles, long reduction
   const int ntile = p.tiles_m * p.tiles_n, nk = (K + GEMM_BK - 1) / GEMM_BK;
   const bool plain_acc = epi->accumulate && c_is_f32 && !epi->bias && !epi->col_scale && !epi->row_scale &&
-                         !epi->residual && !epi->aux && epi->act == VLM_ACT_NONE;
+                         !epi->residual && !epi->aux && !epi->col_sum && epi->act == VLM_ACT_NONE;
   if (gemm_splitk_enabled() && ta && tb && plain_acc && ntile < 512 && nk >= 32) {
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;

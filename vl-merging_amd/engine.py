@@ -235,6 +235,24 @@ class GramCapture:
         return {k: v.cpu() for k, v in self.grams.items()}
 
 
+_FUSE_BIAS_GRADS = os.environ.get("VLM_FUSE_BIAS_GRADS", "1") != "0"  # A/B switch for measurements
+
+
+def _segment_bias_grads(ranges, seq):
+    """Map the two token segments of a pass to the q_bias / v_bias gradient vectors of the expert that owns them."""
+    qb, vb = [None, None], [None, None]
+    for sgm, (base, n) in enumerate(((seq.base0, seq.n0), (seq.base1, seq.n1))):
+        if n == 0:
+            continue
+        lo, hi = base, base + seq.B * n
+        owner = [e for r0, r1, e in ranges if r0 <= lo and hi <= r1]
+        if len(owner) != 1:
+            return None, None, False
+        if owner[0].qb is not None:
+            qb[sgm], vb[sgm] = owner[0].qb.grad, owner[0].vb.grad
+    return qb, vb, True
+
+
 class BlockPlan:
     """Routing of one block evaluation: row ranges -> experts, attention mode.  Built by Block.plan()."""
 
@@ -333,8 +351,11 @@ class _BlockFn(torch.autograd.Function):
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
             ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad)
-            ops.gemm(dy2[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr])
-            ops.colsum(dh[rr], e.fc1b.grad)
+            # fc1 bias gradient = column sums of dh, taken in the epilogue that produces dh (no second pass over it)
+            ops.gemm(dy2[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr],
+                     col_sum=e.fc1b.grad if _FUSE_BIAS_GRADS else None)
+            if not _FUSE_BIAS_GRADS:
+                ops.colsum(dh[rr], e.fc1b.grad)
             with _Side(dy2, a, dh, ln2):
                 ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
                 ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
@@ -352,14 +373,18 @@ class _BlockFn(torch.autograd.Function):
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
         dln1 = torch.empty(M, D, device=dev, dtype=BF16)
         rp = pc.relpos
+        # q_bias / v_bias gradients: column sums of dQ / dV per segment, taken inside the attention backward when every
+        # segment lies inside ONE expert's row range (always true for the layouts Block.plan() builds)
+        qb_grads, vb_grads, fused_qv = _segment_bias_grads(plan.ranges, pc.seq) if _FUSE_BIAS_GRADS else (None, None, False)
         ops.attention_bwd(qkv, o, do, lse, dqkv, pc.seq, H, bias_t=bias_t, head_row0=plan.layer * H,
                           rel_index=rp.index if rp is not None else None,
                           rel_index_t=rp.index_t if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
-                          mode=plan.mode, dbias_t=rp.holder.get("dbias_t") if rp is not None else None)
+                          mode=plan.mode, dbias_t=rp.holder.get("dbias_t") if rp is not None else None,
+                          dq_colsum=qb_grads, dv_colsum=vb_grads)
         dx = torch.empty(M, D, device=dev, dtype=F32)
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
-            if e.qb is not None:
+            if e.qb is not None and not fused_qv:
                 ops.colsum(dqkv[rr, :D], e.qb.grad)
                 ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
             with _Side(dqkv, ln1):

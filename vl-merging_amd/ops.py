@@ -22,12 +22,12 @@ def _ld(t):
 
 
 def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, col_scale=None, row_scale=None,
-         residual=None, alpha=1.0, accumulate=False):
+         residual=None, alpha=1.0, accumulate=False, col_sum=None):
     """out[M,N] = epilogue(op(a)[M,K] @ op(b)[K,N]); see include/vlm_hip.h for the epilogue algebra.
 
     a: bf16 [M,K] (ta=False) or [K,M] (ta=True);  b: bf16 [N,K] (tb=False, nn.Linear layout) or [K,N] (tb=True).
     """
-    L.require_cuda(a, b, out, bias, aux, col_scale, row_scale, residual)
+    L.require_cuda(a, b, out, bias, aux, col_scale, row_scale, residual, col_sum)
     if a.dtype != BF16 or b.dtype != BF16:
         raise L.VlmError("gemm operands must be bfloat16")
     M, N = out.shape
@@ -48,7 +48,10 @@ def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, 
     e.act = act
     e.alpha = alpha
     e.accumulate = 1 if accumulate else 0
-    for t, dt in ((bias, F32), (col_scale, F32), (row_scale, F32), (residual, F32), (aux, BF16)):
+    e.col_sum = col_sum.data_ptr() if col_sum is not None else 0
+    if col_sum is not None and (col_sum.numel() < N or not col_sum.is_contiguous()):
+        raise L.VlmError("gemm: col_sum must be a contiguous f32 vector of at least N elements")
+    for t, dt in ((bias, F32), (col_scale, F32), (row_scale, F32), (residual, F32), (aux, BF16), (col_sum, F32)):
         if t is not None and t.dtype != dt:
             raise L.VlmError("gemm epilogue tensor has dtype %s, expected %s" % (t.dtype, dt))
     if out.dtype not in (BF16, F32):
@@ -216,15 +219,29 @@ def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=
 
 
 def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None,
-                  keep0=None, keep1=None, mode=L.ATTN_JOINT, scale=0.125, dbias_t=None, delta_ws=None):
-    """dqkv <- d(loss)/d(qkv) (bf16, same layout as qkv); dbias_t += d(loss)/d(bias_t)."""
+                  keep0=None, keep1=None, mode=L.ATTN_JOINT, scale=0.125, dbias_t=None, delta_ws=None,
+                  dq_colsum=None, dv_colsum=None):
+    """dqkv <- d(loss)/d(qkv) (bf16, same layout as qkv); dbias_t += d(loss)/d(bias_t).  dq_colsum / dv_colsum:
+    optional pairs (text-segment target, image-segment target) of f32 [H*64] vectors (None entries allowed) that
+    receive += column sums of dQ / dV over that segment's rows (the q_bias / v_bias gradients)."""
     d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale)
     L.require_cuda(out, dout, lse, dqkv, dbias_t, delta_ws)
+    cs = None
+    if dq_colsum is not None or dv_colsum is not None:
+        cs = L.AttnColsum()
+        for name, pair in (("dq", dq_colsum), ("dv", dv_colsum)):
+            for sgm, t in enumerate(pair or (None, None)):
+                if t is not None:
+                    L.require_cuda(t)
+                    if t.dtype != F32 or t.numel() < H * 64 or not t.is_contiguous():
+                        raise L.VlmError("attention_bwd: column-sum outputs must be contiguous f32 [H*64]")
+                    getattr(cs, name)[sgm] = t.data_ptr()
     if delta_ws is None:
         delta_ws = torch.empty(H, qkv.shape[0], device=qkv.device, dtype=F32)
     if bias_t is not None and rel_index is None:
         raise L.VlmError("attention_bwd needs both orientations of the int16 relative index")
     rc = L.get_lib().vlm_attention_bwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(dout), _ld(dout), L.ptr(lse),
-                                       L.ptr(delta_ws), L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t), L.stream_ptr())
+                                       L.ptr(delta_ws), L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t),
+                                       ctypes.byref(cs) if cs is not None else None, L.stream_ptr())
     L.check(rc, "vlm_attention_bwd")
     return dqkv
