@@ -12,19 +12,26 @@ PKG = os.path.join(ROOT, "vl-merging_amd")
 LIB = os.path.join(PKG, "lib", "libvlm_hip_stamps.so")
 
 
+VARIANTS = {"": [], "_noload": ["-DVLM_GEMM_EXP_NOLOAD"], "_nomfma": ["-DVLM_GEMM_EXP_NOMFMA"]}
+
+
 def build():
     sys.path.insert(0, PKG)
     import build_ext as B
     B.build(verbose=False)
-    obj = os.path.join(B.BUILD, "gemm_stamps.o")
-    subprocess.run([B.HIPCC] + B.COMMON + ["-DVLM_GEMM_STAMPS", "-c", os.path.join(B.CSRC, "gemm.hip"), "-o", obj], check=True)
-    objs = [os.path.join(B.BUILD, f) for f in os.listdir(B.BUILD) if f.endswith(".hip.o") and f != "gemm.hip.o"] + [obj]
-    subprocess.run([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs, check=True)
-    print("built", LIB)
+    for suffix, flags in VARIANTS.items():
+        obj = os.path.join(B.BUILD, "gemm_stamps%s.o" % suffix)
+        subprocess.run([B.HIPCC] + B.COMMON + ["-DVLM_GEMM_STAMPS"] + flags + ["-c", os.path.join(B.CSRC, "gemm.hip"), "-o", obj],
+                       check=True, capture_output=True)
+        objs = [os.path.join(B.BUILD, f) for f in os.listdir(B.BUILD) if f.endswith(".hip.o") and f != "gemm.hip.o"] + [obj]
+        lib = LIB.replace(".so", suffix + ".so")
+        subprocess.run([B.HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs, check=True)
+        print("built", lib)
 
 
 def main():
-    os.environ["VLM_LIB_PATH"] = LIB
+    os.environ["VLM_LIB_PATH"] = LIB.replace(".so", os.environ.get("STAMP_VARIANT", "") + ".so")
+    print("variant:", os.environ.get("STAMP_VARIANT", "") or "full")
     import torch
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
@@ -54,7 +61,8 @@ def main():
         ("fc1 dgrad", lambda: ops.gemm(x3072, w_fc1, torch.empty(M, 768, device=dev, dtype=bf), False, True), 768),
     ]
     for name, fn, n in cases:
-        nwg = ((M + 127) // 128) * ((n + 127) // 128)
+        tile = 256 if os.environ.get("VLM_GEMM_BIG", "0") != "0" else 128
+        nwg = ((M + tile - 1) // tile) * ((n + tile - 1) // tile)
         st = torch.zeros(nwg * 8, device=dev, dtype=torch.int64)
         for _ in range(3):
             fn()

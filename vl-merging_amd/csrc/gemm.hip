@@ -151,6 +151,7 @@ struct gemm_params_t {
   int lda, ldb, ldc;
   vlm_epilogue_t epi;
   int tiles_m, tiles_n;
+  int group_m;  // raster group height in tiles (1 = row-major)
   int splits, ksteps_per_split;  // split-K (wgrad): block -> (tile, K slice), fp32 atomic accumulation
 #ifdef VLM_GEMM_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/stamp_gemm.py): 8 u64 per workgroup
@@ -168,7 +169,8 @@ __device__ __forceinline__ void lane16_swap(float& x, float& y) {
 // ---- fused epilogue of one wave's 64x64 sub-tile (swapped layout: lane holds row m = mw0 + 16i + (lane&15) and the
 // 4 consecutive columns n = nw0 + 16j + 4*(lane>>4) + r) -----------------------------------------------------------
 template <bool OUT_F32>
-__device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x4 (&acc)[4][4], int mw0, int nw0, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
+                                              float* red = nullptr, int red_off = 0) {
   const vlm_epilogue_t& e = p.epi;
   // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
   const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
@@ -300,7 +302,12 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
           t += dpp_f32<0x124>(t);
           t += dpp_f32<0x122>(t);
           t += dpp_f32<0x121>(t);
-          if ((lane & 15) == 0) atomicAdd(e.col_sum + nl + jp * 32 + r, t);
+          if ((lane & 15) == 0) {
+            // red (workgroup-uniform, interior tiles): partials meet in LDS and leave as full-width 256-B atomics;
+            // 4-lane atomics straight from here cost +180 us on the fc2 dgrad (memory-side atomics, contended rows)
+            if (red) red[red_off + (g & 1) * 16 + (g >> 1) * 8 + jp * 32 + r] = t;
+            else atomicAdd(e.col_sum + nl + jp * 32 + r, t);
+          }
         }
     }
     return;
@@ -437,7 +444,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
     tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   }
-  const uint32_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  // grouped raster: the ~64 tiles an XCD runs at once form an 8 (m) x 8 (n) block, so its L2 holds 16 operand panels
+  // instead of the 3.5 + tiles_n panels of a row-major sweep (qkv/fc1: 4.2-5.2 MB > the 4 MiB L2)
+  uint32_t tm, tn;
+  {
+    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;
+    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;
+    tm = first + in % rows;
+    tn = in / rows;
+  }
   const uint32_t m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
   // buffer descriptors: byte extent = rows * ld * 2 so that ragged row tails read as zero
@@ -474,7 +489,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 
   for (int kt = kt0; kt < kt1; ++kt) {
     const int cur = (kt - kt0) & 1;
+#ifdef VLM_GEMM_EXP_NOLOAD  // diagnostic timing build only: the K loop re-reads the first stage (results are wrong)
+    if (false) {
+#else
     if (kt + 1 < kt1) {  // next tile's loads fly during this tile's MFMAs
+#endif
       if (DMA_A) stage_dma<TA>(ra, LDS_A(cur ^ 1), m0, (kt + 1) * GEMM_BK, p.lda, wave_u, lane);
       else stage_load<TA>(sa, ra, m0, (kt + 1) * GEMM_BK, p.lda, tid);
       if (DMA_B) stage_dma<TB>(rb, LDS_B(cur ^ 1), n0, (kt + 1) * GEMM_BK, p.ldb, wave_u, lane);
@@ -520,19 +539,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifdef VLM_GEMM_EXP_NOMFMA  // diagnostic timing build only: keep the fragment reads alive without the matrix pipe
+          if (i == j) acc[i][j][0] += (float)fa[ks][i][0] + (float)fb[ks][j][0];
+#else
           if (SPLITK)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+#endif
         }
 #if GEMM_FRAG_MODE == 1
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
+#ifndef VLM_GEMM_EXP_NOLOAD
     if (kt + 1 < kt1) {
       if (!DMA_A) stage_store<TA>(sa, LDS_A(cur ^ 1), tid);
       if (!DMA_B) stage_store<TB>(sb, LDS_B(cur ^ 1), tid);
     }
+#endif
     __syncthreads();
   }
   STAMP(2)
@@ -553,7 +578,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     return;
   }
 
-  gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  {
+    // column sums (bias gradient): whole-tile-interior workgroups reduce their 2x2 waves through LDS (free after the
+    // loop's last barrier) and issue two 64-lane contiguous atomics; edge tiles fall back to per-wave atomics
+    const bool lds_sum = p.epi.col_sum && m0 + GEMM_BM <= (uint32_t)p.M && n0 + GEMM_BN <= (uint32_t)p.N && p.epi.reserved == 1;
+    float* red = reinterpret_cast<float*>(smem);
+    gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, lds_sum ? red : nullptr, wm * 128 + wn * 64);
+    if (lds_sum) {
+      __syncthreads();
+      if (tid < 128) atomicAdd(p.epi.col_sum + n0 + tid, red[tid] + red[128 + tid]);
+    }
+  }
 #ifdef VLM_GEMM_STAMPS
   __builtin_amdgcn_s_waitcnt(0);  // stores issued AND acknowledged for this wave
   STAMP(3)
@@ -629,6 +664,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 128x64 each
+  STAMP(0)
 
   const uint32_t nblk = gridDim.x, bid = blockIdx.x;
   const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
@@ -652,6 +688,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm
   const int nk = p.K / GEMM_BK;  // K % 64 == 0 guaranteed by the launcher
   big_stage_dma<TB>(ra, rb, smem, m0, n0, 0, p.lda, p.ldb, wave, lane);
   __syncthreads();  // drains the DMA (vmcnt(0))
+  STAMP(1)
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk)
@@ -680,8 +717,13 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm
     }
     __syncthreads();
   }
+  STAMP(2)
   gemm_epilogue<OUT_F32>(p, acc[0], m0 + wm * 128, n0 + wn * 64, lane);
   gemm_epilogue<OUT_F32>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, lane);
+#ifdef VLM_GEMM_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP(3)
+#endif
 }
 
 template <bool TB, bool OUT_F32>
@@ -750,10 +792,24 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.epi = *epi;
+  {  // workgroup-uniform copy of the epilogue's 8-column fast-path test (gemm_epilogue: vec8_ok), for the LDS column sums
+    const bool v4 = ((ldc & 3) == 0) && (!epi->aux || (epi->ld_aux & 3) == 0) && (!epi->residual || (epi->ld_res & 3) == 0);
+    const bool v8 = v4 && (c_is_f32 || (ldc & 7) == 0) && (!epi->aux || ((epi->ld_aux & 7) == 0 && ((uintptr_t)epi->aux & 15) == 0)) &&
+                    (!epi->residual || ((uintptr_t)epi->residual & 15) == 0) && (!epi->bias || ((uintptr_t)epi->bias & 15) == 0) &&
+                    (!epi->col_scale || ((uintptr_t)epi->col_scale & 15) == 0);
+    p.epi.reserved = v8 ? 1 : 0;
+  }
   p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   p.splits = 1;
   p.ksteps_per_split = 0;
+  static int group_m = -1;  // 0 = by shape (measured at M = 54 296, tools/bench_gemm.py): wide outputs want tall groups
+  if (group_m < 0) {
+    const char* e = getenv("VLM_GEMM_GROUP_M");
+    group_m = e ? atoi(e) : 0;
+    if (group_m < 0) group_m = 0;
+  }
+  p.group_m = group_m ? group_m : (p.tiles_n >= 12 ? 16 : 4);
 #ifdef VLM_GEMM_STAMPS
   p.stamps = g_stamp_buffer;
 #endif
@@ -770,6 +826,7 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     if (splits > 1) {
       p.ksteps_per_split = (nk + splits - 1) / splits;
       p.splits = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
+      if (!group_m && p.tiles_n >= 12) p.group_m = 1;  // split-K: co-resident blocks already share tiles across K slices
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
   }

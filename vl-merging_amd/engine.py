@@ -235,7 +235,10 @@ class GramCapture:
         return {k: v.cpu() for k, v in self.grams.items()}
 
 
-_FUSE_BIAS_GRADS = os.environ.get("VLM_FUSE_BIAS_GRADS", "1") != "0"  # A/B switch for measurements
+# A/B switch for measurements: 0 = separate colsum launches, 1 = all fused, 2 = attention (q/v bias) fused only
+_FUSE_MODE = int(os.environ.get("VLM_FUSE_BIAS_GRADS", "2"))
+_FUSE_BIAS_GRADS = _FUSE_MODE != 0
+_FUSE_FC1_BIAS = _FUSE_MODE == 1
 
 
 def _segment_bias_grads(ranges, seq):
@@ -353,8 +356,8 @@ class _BlockFn(torch.autograd.Function):
             ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad)
             # fc1 bias gradient = column sums of dh, taken in the epilogue that produces dh (no second pass over it)
             ops.gemm(dy2[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr],
-                     col_sum=e.fc1b.grad if _FUSE_BIAS_GRADS else None)
-            if not _FUSE_BIAS_GRADS:
+                     col_sum=e.fc1b.grad if _FUSE_FC1_BIAS else None)
+            if not _FUSE_FC1_BIAS:
                 ops.colsum(dh[rr], e.fc1b.grad)
             with _Side(dy2, a, dh, ln2):
                 ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
