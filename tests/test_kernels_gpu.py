@@ -178,6 +178,35 @@ def test_gemm_epilogues(ops, L):
     assert_close(cs_r[:50], acc[:, :50].sum(0), 2e-3, 2e-2, "col_sum (ragged N)")
 
 
+def test_gemm_wide_tile_kernel(ops, L):
+    """Shapes large enough for the 256x128x32 three-stage kernel (>= 1000 tiles, both operands K-contiguous): ragged M,
+    every epilogue of the transformer block, against fp32 matmul of the bf16 operands."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(21)
+    M, N, K = 256 * 130 + 77, 2304, 768
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    B = bf(torch.randn(N, K, device="cuda", generator=gen))
+    ref = (A.float() @ B.float().t()) * 0.05
+    bias = torch.randn(N, device="cuda", generator=gen)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, out, bias=bias, alpha=0.05)
+    assert_close(out, ref + bias, 1e-2, 2e-2, "wide bf16+bias")
+    gamma = torch.randn(N, device="cuda", generator=gen) * 0.1
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    want = res + gamma[None] * (ref + bias)
+    ops.gemm(A, B, res, bias=bias, col_scale=gamma, residual=res, alpha=0.05)  # in-place residual stream
+    assert_close(res, want, 1e-3, 5e-3, "wide f32 residual")
+    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    a = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, a, bias=bias, act=L.ACT_GELU, aux=h, alpha=0.05)
+    assert_close(h, ref + bias, 1e-2, 2e-2, "wide preact")
+    assert_close(a, torch.nn.functional.gelu(ref + bias), 1e-2, 2e-2, "wide gelu")
+    # K = 64 (two 32-deep K steps) and 128 (four): pipeline prologue / tail
+    for k in (64, 128):
+        o2 = torch.empty(M, N, device="cuda")
+        ops.gemm(A[:, :k], B[:, :k], o2)
+        assert_close(o2, A[:, :k].float() @ B[:, :k].float().t(), 1e-3, 2e-3 * math.sqrt(k), "wide K=%d" % k)
+
+
 def test_gemm_vocab_ragged_n(ops):
     gen = torch.Generator(device="cuda"); gen.manual_seed(3)
     M, N, K, NP = 80, 30522, 768, 30528

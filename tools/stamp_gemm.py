@@ -61,8 +61,10 @@ def main():
         ("fc1 dgrad", lambda: ops.gemm(x3072, w_fc1, torch.empty(M, 768, device=dev, dtype=bf), False, True), 768),
     ]
     for name, fn, n in cases:
-        tile = 256 if os.environ.get("VLM_GEMM_BIG", "0") != "0" else 128
-        nwg = ((M + tile - 1) // tile) * ((n + tile - 1) // tile)
+        tm_, tn_ = int(os.environ.get("STAMP_TILE_M", 128)), int(os.environ.get("STAMP_TILE_N", 128))
+        nwg = ((M + tm_ - 1) // tm_) * ((n + tn_ - 1) // tn_)
+        if os.environ.get("STAMP_PERSISTENT"):
+            nwg = min(nwg, 256)
         st = torch.zeros(nwg * 8, device=dev, dtype=torch.int64)
         for _ in range(3):
             fn()
@@ -74,6 +76,11 @@ def main():
         pro, loop, epi = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
         tot = s[:, 3] - s[:, 0]
         real = (s[:, 5] - s[:, 4]) * 10.0  # ns (100 MHz)
+        if os.environ.get("STAMP_PERSISTENT"):
+            print("%-24s persistent: loop %6.0f cyc/tile, epilogue(issue) %6.0f cyc/tile, tiles/WG %.1f, WG total %.0f cyc, clock %.2f GHz, span %.1f us"
+                  % (name, loop.median(), epi.median(), s[:, 7].median(), s[:, 6].median(),
+                     (s[:, 6] / real).median(), (s[:, 5].max() - s[:, 4].min()) * 10.0 / 1e3))
+            continue
         clk = (tot / real).median()
         span_ns = (s[:, 5].max() - s[:, 4].min()) * 10.0
         print("%-24s wgs %5d  prologue %6.0f  loop %6.0f  epilogue %6.0f  total %6.0f cyc (medians)  clock %.2f GHz  "

@@ -168,9 +168,11 @@ __device__ __forceinline__ void lane16_swap(float& x, float& y) {
 
 // ---- fused epilogue of one wave's 64x64 sub-tile (swapped layout: lane holds row m = mw0 + 16i + (lane&15) and the
 // 4 consecutive columns n = nw0 + 16j + 4*(lane>>4) + r) -----------------------------------------------------------
-template <bool OUT_F32>
-__device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
-                                              float* red = nullptr, int red_off = 0) {
+// Returns the number of vector-memory instructions issued AFTER the last one whose result was waited for (the stores
+// of the interior fast path), or -1 when unknown (edge tiles, column sums): the persistent kernel's counted waits.
+template <bool OUT_F32, bool LEAN = false>  // LEAN: no column sums, bias/gamma re-read per row block (fewer live registers)
+__device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4 (&acc)[4][4], int mw0, int nw0, int lane,
+                                             float* red = nullptr, int red_off = 0) {
   const vlm_epilogue_t& e = p.epi;
   // 16-B / 8-B epilogue vectors need every leading dimension to keep 4-element alignment
   const bool vec_ok = ((p.ldc & 3) == 0) && (!e.aux || (e.ld_aux & 3) == 0) && (!e.residual || (e.ld_res & 3) == 0);
@@ -182,7 +184,7 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
     // (1) v_permlane16_swap_b32 between the accumulators of column blocks 2jp and 2jp+1 leaves every lane with 8
     //     consecutive columns (block 2jp+(g&1), columns 8(g>>1)..+7, g = lane>>4), so bf16 results leave as 8
     //     dwordx4 stores and every aux / residual / bias read is 16 B wide;
-    // (2) the residual may alias C (in-place residual stream): all epilogue inputs of a 32-row half are fetched
+    // (2) the residual may alias C (in-place residual stream): all epilogue inputs of a 16-row block are fetched
     //     before anything is stored, instead of 16 dependent load->store round trips.
     const bool has_res = e.residual != nullptr, bwd = e.act == VLM_ACT_GELU_BWD, accum = OUT_F32 && e.accumulate;
     const int g = lane >> 4;
@@ -192,23 +194,26 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
     for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
       for (int r = 0; r < 8; ++r) csum[jp][r] = 0.f;
+#define EPI_LOAD_COL_VECTORS()                                                                                          \
+  _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                    \
+    const f32x4 b4 = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nl + jp * 32 + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f}; \
+    const f32x4 g4 =                                                                                                    \
+        e.col_scale ? *reinterpret_cast<const f32x4*>(e.col_scale + nl + jp * 32 + q * 4) : (f32x4){1.f, 1.f, 1.f, 1.f}; \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                     \
+      bia[jp][q * 4 + r] = b4[r];                                                                                       \
+      gam[jp][q * 4 + r] = g4[r];                                                                                       \
+    }                                                                                                                   \
+  }
+    if (!LEAN) { EPI_LOAD_COL_VECTORS() }
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
+    for (int hf = 0; hf < 4; ++hf) {  // one 16-row block at a time: 4-8 loads in flight, few live registers
+      f32x4 rsd[1][2][2], old[1][2][2];
+      bf16x8 hx[1][2];
+      float rs[1];
+      if (LEAN) { EPI_LOAD_COL_VECTORS() }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const f32x4 b4 = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nl + jp * 32 + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 g4 = e.col_scale ? *reinterpret_cast<const f32x4*>(e.col_scale + nl + jp * 32 + q * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { bia[jp][q * 4 + r] = b4[r]; gam[jp][q * 4 + r] = g4[r]; }
-      }
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      f32x4 rsd[2][2][2], old[2][2][2];
-      bf16x8 hx[2][2];
-      float rs[2];
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const size_t m = mw0 + (hf * 2 + ii) * 16 + (lane & 15);
+      for (int ii = 0; ii < 1; ++ii) {
+        const size_t m = mw0 + (hf + ii) * 16 + (lane & 15);
         rs[ii] = e.row_scale ? e.row_scale[m] : 1.0f;
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
@@ -225,8 +230,8 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
         }
       }
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const size_t m = mw0 + (hf * 2 + ii) * 16 + (lane & 15);
+      for (int ii = 0; ii < 1; ++ii) {
+        const size_t m = mw0 + (hf + ii) * 16 + (lane & 15);
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           const int n = nl + jp * 32;
@@ -235,7 +240,7 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
           for (int r = 0; r < 4; ++r) {
             // alpha first: a compiler-scheduled VALU op consumes the MFMA result (hazard handled by hipcc), the swap
             // then reads VALU results
-            float x = acc[hf * 2 + ii][2 * jp][r] * e.alpha, y = acc[hf * 2 + ii][2 * jp + 1][r] * e.alpha;
+            float x = acc[hf + ii][2 * jp][r] * e.alpha, y = acc[hf + ii][2 * jp + 1][r] * e.alpha;
             lane16_swap(x, y);
             v[r] = x;
             v[4 + r] = y;
@@ -273,7 +278,7 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += old[ii][jp][r >> 2][r & 3];
           }
-          if (e.col_sum) {
+          if (!LEAN && e.col_sum) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) csum[jp][r] += v[r];
           }
@@ -290,7 +295,7 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
         }
       }
     }
-    if (e.col_sum) {
+    if (!LEAN && e.col_sum) {
       // column sums of this wave's 64 rows: 4 row blocks summed in the lane above, the 16 rows of a block by DPP
       // rotations inside the 16-lane row; lane 0 of each row then owns 16 columns -> 64 fp32 atomics per wave
 #pragma unroll
@@ -309,8 +314,10 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
             else atomicAdd(e.col_sum + nl + jp * 32 + r, t);
           }
         }
+      return -1;
     }
-    return;
+    // stores of the fast path: 4 row blocks x 2 column pairs x (two 16-B halves for f32) + the aux (pre-activation) copy
+    return 8 * (OUT_F32 ? 2 : 1) + ((e.aux && !bwd) ? 8 : 0);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -407,6 +414,7 @@ __device__ __forceinline__ void gemm_epilogue(const gemm_params_t& p, const f32x
       }
     }
   }
+  return -1;
 }
 
 // DMA_A / DMA_B: stage that operand by LDS-DMA (else through registers).  SPLITK: K is cut over gridDim.x / tiles
@@ -617,65 +625,76 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 }
 
 // ======================================================================================================================
-// 256x256x64 tile, 8 waves (2x4), 128x64 per wave, two LDS stages of 64 KiB filled by LDS-DMA.
-// Why: one LDS-DMA wave instruction (1 KiB) costs 60-180 issue cycles (MI355X_MICROARCH.md, cycle constants) against
-// 16 for an MFMA 16x16x32; a tile stages 16*(BM+BN)/(BM*BN) DMA instructions per MFMA = 0.25 for 128x128 (DMA issue
-// time > MFMA time: the measured ~40 % ceiling of the kernel above) but 0.125 for 256x256 with 64 MFMAs per wave and
-// K-step.  One workgroup per CU (128 KiB LDS), 2 waves per SIMD.  A must be K-contiguous; B either orientation.
-#define BIG_BM 256
-#define BIG_BN 256
-#define BIG_THREADS 512
-#define BIG_STAGE_BYTES (64 * 1024)
+// 256x128x32 tile, 4 waves (2x2) of 128x64, THREE LDS stages of 24 KiB filled by LDS-DMA, two workgroups per CU.
+// Why (tools/stamp_gemm.py, profiles/): the 128x128 loop runs at the rate its operands arrive from L2 -- 2 x 32 KiB
+// per CU and 64-deep K step at ~30 B/clk/CU, twice the MFMA time; with the staging switched off the same loop sits on
+// the MFMA bound.  This tile moves 0.75x the bytes per flop, keeps two K steps (48 KiB per workgroup) in flight
+// instead of one, and still leaves a partner workgroup on the CU to cover prologue and epilogue.
+// Both operands K-contiguous (nn.Linear layout); K % 32 == 0.
+#define W_BM 256
+#define W_BN 128
+#define W_BK 32
+#define W_STAGES 3
+#define W_A_BYTES (W_BM * W_BK * 2)               // 16 KiB
+#define W_STAGE_BYTES ((W_BM + W_BN) * W_BK * 2)  // 24 KiB
 
-template <bool TB>
-__device__ __forceinline__ void big_stage_dma(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned char* stage,
-                                              uint32_t m0, uint32_t n0, uint32_t k0, uint32_t lda, uint32_t ldb,
-                                              int wave, int lane) {
-  // A: [256 rows][64 k] = 32 instructions of 8 rows.  B: K-contiguous [256][64] (32 instructions of 8 rows) or
-  // K-strided as two [64][128] sub-tiles of 16 KiB (16 instructions of 4 k-rows each).
+// Stage image: a tile row is 64 B (32 bf16); rows 2R and 2R+1 share the 128-B line R, whose eight 16-B chunks
+// C = 4*(row&1) + kchunk are stored at position C ^ (R & 7): the 16 lanes of one ds_read_b128 cycle hit 16 different
+// 16-B slots of both 128-B bank halves (conflict-free, same argument as the 128-B-row image above).
+__device__ __forceinline__ bf16x8 w_frag(const unsigned char* tile, int row16, int lane) {
+  const int r = row16 * 16 + (lane & 15), R = r >> 1;
+  const int phys = ((((r & 1) << 2) | (lane >> 4)) ^ (R & 7));
+  return *reinterpret_cast<const bf16x8*>(tile + R * 128 + phys * 16);
+}
+
+// one wave's share (6 of 24 instructions) of a stage: instruction jj covers 16 tile rows = 8 lines = 1 KiB of LDS
+__device__ __forceinline__ void w_stage_dma(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned char* stage,
+                                            uint32_t m0, uint32_t n0, uint32_t k0, uint32_t lda, uint32_t ldb, int wave,
+                                            int lane) {
+  const uint32_t Rl = lane >> 3, C = (lane & 7) ^ Rl;     // line inside the instruction, logical chunk
+  const uint32_t rl = 2 * Rl + (C >> 2), kc = (C & 3) * 8;  // tile row inside the 16-row block, k offset (elements)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int j = wave + 8 * u;
-    const uint32_t row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(stage + j * 1024), 16, ((m0 + row) * lda + k0 + chunk * 8) * 2, 0, 0, 0);
+    const uint32_t jj = wave + 4 * u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(stage + jj * 1024), 16,
+                                             ((m0 + jj * 16 + rl) * lda + k0 + kc) * 2, 0, 0, 0);
   }
-  unsigned char* sb = stage + 32 * 1024;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int j = wave + 8 * u;  // 0..31
-    uint32_t off;
-    if (!TB) {
-      const uint32_t row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
-      off = ((n0 + row) * ldb + k0 + chunk * 8) * 2;
-    } else {
-      const uint32_t sub = j >> 4, jj = j & 15;  // sub-tile (128 columns each), instruction inside it
-      const uint32_t krow = jj * 4 + (lane >> 4), s16 = lane & 15;
-      const uint32_t c32 = (s16 >> 1) ^ (krow & 3) ^ (((krow >> 3) & 1) << 2);
-      off = ((k0 + krow) * ldb + n0 + sub * 128 + (c32 * 2 + (s16 & 1)) * 8) * 2;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(sb + j * 1024), 16, off, 0, 0, 0);
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t jj = wave + 4 * u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(stage + W_A_BYTES + jj * 1024), 16,
+                                             ((n0 + jj * 16 + rl) * ldb + k0 + kc) * 2, 0, 0, 0);
   }
 }
 
-template <bool TB, bool OUT_F32>
-__global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm_params_t p) {
+// s_waitcnt with only the vmcnt field active (gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14)
+#define W_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_wide_kernel(const gemm_params_t p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 128x64 each
+  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 128x64 each
   STAMP(0)
 
   const uint32_t nblk = gridDim.x, bid = blockIdx.x;
   const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const uint32_t tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG_BN;
+  uint32_t tm, tn;
+  {
+    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;
+    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;
+    tm = first + in % rows;
+    tn = in / rows;
+  }
+  const uint32_t m0 = tm * W_BM, n0 = tn * W_BN;
 
   const __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.B), 0, (int)((uint64_t)(TB ? p.K : p.N) * p.ldb * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
 
   f32x4 acc[2][4][4];  // [64-row half][16-row block][16-col block]
 #pragma unroll
@@ -685,37 +704,39 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[hf][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / GEMM_BK;  // K % 64 == 0 guaranteed by the launcher
-  big_stage_dma<TB>(ra, rb, smem, m0, n0, 0, p.lda, p.ldb, wave, lane);
-  __syncthreads();  // drains the DMA (vmcnt(0))
+  const int nk = p.K / W_BK;
+  w_stage_dma(ra, rb, smem, m0, n0, 0, p.lda, p.ldb, wave, lane);
+  if (nk > 1) {
+    w_stage_dma(ra, rb, smem + W_STAGE_BYTES, m0, n0, W_BK, p.lda, p.ldb, wave, lane);
+    W_WAIT_VM(6);  // stage 0 landed, stage 1 may still fly
+  } else {
+    W_WAIT_VM(0);
+  }
+  __builtin_amdgcn_s_barrier();
   STAMP(1)
+
+  int slot = 0, slot2 = 2;  // slot of K step kt, slot of K step kt+2
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk)
-      big_stage_dma<TB>(ra, rb, smem + (cur ^ 1) * BIG_STAGE_BYTES, m0, n0, (kt + 1) * GEMM_BK, p.lda, p.ldb, wave, lane);
-    const unsigned char* la = smem + cur * BIG_STAGE_BYTES;
-    const unsigned char* lb = la + 32 * 1024;
+    if (kt + 2 < nk)
+      w_stage_dma(ra, rb, smem + slot2 * W_STAGE_BYTES, m0, n0, (kt + 2) * W_BK, p.lda, p.ldb, wave, lane);
+    const unsigned char* la = smem + slot * W_STAGE_BYTES;
+    const unsigned char* lb = la + W_A_BYTES;
+    bf16x8 fa[8], fb[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fb[4];
+    for (int j = 0; j < 4; ++j) fb[j] = w_frag(lb, wn * 4 + j, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int xb = wn * 4 + j;  // 16-column block of the 256-wide B tile
-        fb[j] = TB ? frag_load<true>(lb + (xb >> 3) * (16 * 1024), xb & 7, ks, lane) : frag_load<false>(lb, xb, ks, lane);
-      }
+    for (int i = 0; i < 8; ++i) fa[i] = w_frag(la, wm * 8 + i, lane);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        bf16x8 fa[4];
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = frag_load<false>(la, wm * 8 + hf * 4 + i, ks, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[hf][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[hf][i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
+      for (int j = 0; j < 4; ++j)
+        acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i >> 2][i & 3][j], 0, 0, 0);
+    // K step kt+1 must have landed before anyone reads it; the step issued above (6 instructions per wave) may fly on
+    if (kt + 2 < nk) W_WAIT_VM(6);
+    else W_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    slot = slot == 2 ? 0 : slot + 1;
+    slot2 = slot2 == 2 ? 0 : slot2 + 1;
   }
   STAMP(2)
   gemm_epilogue<OUT_F32>(p, acc[0], m0 + wm * 128, n0 + wn * 64, lane);
@@ -726,20 +747,210 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void vlm_gemm_big_kernel(const gemm
 #endif
 }
 
-template <bool TB, bool OUT_F32>
-static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
-  const size_t smem = 2 * BIG_STAGE_BYTES;
+template <bool OUT_F32>
+static int launch_gemm_wide(gemm_params_t p, hipStream_t stream) {
+  const size_t smem = W_STAGES * W_STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_big_kernel<TB, OUT_F32>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_wide_kernel<OUT_F32>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return VLM_ERR_LAUNCH;
     attr_set = true;
   }
-  p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
-  p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
-  dim3 grid(p.tiles_m * p.tiles_n), block(BIG_THREADS);
-  hipLaunchKernelGGL((vlm_gemm_big_kernel<TB, OUT_F32>), grid, block, smem, stream, p);
+  p.tiles_m = (p.M + W_BM - 1) / W_BM;
+  p.tiles_n = (p.N + W_BN - 1) / W_BN;
+  dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
+  hipLaunchKernelGGL((vlm_gemm_wide_kernel<OUT_F32>), grid, block, smem, stream, p);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ======================================================================================================================
+// Persistent 256x256x32 kernel: ONE workgroup of 8 waves (2x4, 128x64 each) per CU, four LDS stages of 32 KiB.
+// Why (tools/stamp_gemm.py): per 64-deep K step both kernels above spend ~1500 cycles where the MFMAs need 1024 and
+// the same loop without staging runs at 993 -- the vector-memory path (one LDS-DMA instruction per KiB, 64 B/clk/CU)
+// is the co-bottleneck, and 128x128 tiles ask it for 64 B per MFMA cycle.  A 256x256 tile asks for 16.  With one
+// workgroup per CU nothing else hides prologue and epilogue, so the kernel is persistent: after a tile's last K step
+// it issues the next tile's first three stages, THEN runs the epilogue, and the next tile's first waits are counted
+// (s_waitcnt vmcnt(N) with N = everything younger than the stage, the epilogue's stores included), so the stores
+// drain under the next tile's MFMAs instead of being waited for at s_endpgm.
+// Both operands K-contiguous; K % 32 == 0, K >= 96.
+#define P_BM 256
+#define P_BN 256
+#define P_THREADS 512
+#define P_STAGES 4
+#define P_HALF_BYTES (256 * W_BK * 2)  // 16 KiB: A or B part of a stage
+#define P_STAGE_BYTES (2 * P_HALF_BYTES)
+
+__device__ __forceinline__ void p_wait_vm(int n) {  // runtime-counted vmcnt wait (the immediate must be constant)
+  switch (n) {
+    case 4: W_WAIT_VM(4); break;
+    case 8: W_WAIT_VM(8); break;
+    case 16: W_WAIT_VM(16); break;
+    case 20: W_WAIT_VM(20); break;
+    case 24: W_WAIT_VM(24); break;
+    case 32: W_WAIT_VM(32); break;
+    case 36: W_WAIT_VM(36); break;
+    case 40: W_WAIT_VM(40); break;
+    case 48: W_WAIT_VM(48); break;
+    case 52: W_WAIT_VM(52); break;
+    case 56: W_WAIT_VM(56); break;
+    default: W_WAIT_VM(0); break;
+  }
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(P_THREADS, 2) void vlm_gemm_p256_kernel(const gemm_params_t p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 128x64 each
+
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
+  const uint32_t ntile = p.tiles_m * p.tiles_n;
+  const int nk = p.K / W_BK;
+
+  // per-lane part of the DMA source offsets (stage image of w_frag): instruction jj covers tile rows 16*jj..+15
+  const uint32_t Rl = lane >> 3, Cc = (lane & 7) ^ Rl;
+  const uint32_t rl = 2 * Rl + (Cc >> 2), kcb = (Cc & 3) * 16;  // row inside the block, k offset in bytes
+  uint32_t offa[2], offb[2];
+
+  // (macros, not lambdas: a lambda capturing the offset arrays by reference sends them to scratch memory, and scratch
+  // traffic would also break the vmcnt bookkeeping below)
+#define P_TILE_ORIGIN(vv, mm0, nn0)                                                                                    \
+  {                                                                                                                    \
+    const uint32_t q8 = ntile >> 3, r8 = ntile & 7, xcd = (vv) & 7;                                                    \
+    const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((vv) >> 3);                 \
+    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;                 \
+    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;                                 \
+    mm0 = (first + in % rows) * P_BM;                                                                                  \
+    nn0 = (in / rows) * P_BN;                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                    \
+      const uint32_t jj = wave + 8 * u;                                                                                \
+      offa[u] = (mm0 + jj * 16 + rl) * p.lda * 2 + kcb;                                                                \
+      offb[u] = (nn0 + jj * 16 + rl) * p.ldb * 2 + kcb;                                                                \
+    }                                                                                                                  \
+  }
+#define P_ISSUE_STAGE(slot_, kt_) /* 4 LDS-DMA instructions per wave */                                                \
+  {                                                                                                                    \
+    unsigned char* st = smem + (slot_) * P_STAGE_BYTES;                                                                \
+    const int kbytes = (kt_) * (W_BK * 2);                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
+        ra, (lds_void*)(st + (wave + 8 * u) * 1024), 16, offa[u], kbytes, 0, 0);                                       \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
+        rb, (lds_void*)(st + P_HALF_BYTES + (wave + 8 * u) * 1024), 16, offb[u], kbytes, 0, 0);                        \
+  }
+
+  uint32_t v = blockIdx.x, m0, n0;
+  P_TILE_ORIGIN(v, m0, n0)
+  P_ISSUE_STAGE(0, 0)
+  P_ISSUE_STAGE(1, 1)
+  P_ISSUE_STAGE(2, 2)
+  int after = 0;  // vector-memory instructions this wave issued AFTER the three prologue stages (epilogue stores)
+#ifdef VLM_GEMM_STAMPS
+  unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  for (;;) {
+#ifdef VLM_GEMM_STAMPS
+    const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+#endif
+    f32x4 acc[2][4][4];  // [64-row half][16-row block][16-col block]
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[hf][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt must have landed: everything younger may still fly (up to two later stages, plus -- during the first
+      // three steps of a tile -- the previous tile's epilogue stores, which were issued after this tile's prologue)
+      const int younger = 4 * min(2, nk - 1 - kt);
+      if (kt < 3) {
+        if (after < 0) W_WAIT_VM(0);
+        else p_wait_vm(younger + after);
+      } else if (younger == 8) {
+        W_WAIT_VM(8);
+      } else if (younger == 4) {
+        W_WAIT_VM(4);
+      } else {
+        W_WAIT_VM(0);
+      }
+      __builtin_amdgcn_s_barrier();  // stage kt visible to all waves; everyone is done reading the slot of step kt-1
+      if (kt + 3 < nk) P_ISSUE_STAGE((slot + 3) & 3, kt + 3)
+      const unsigned char* la = smem + slot * P_STAGE_BYTES;
+      const unsigned char* lb = la + P_HALF_BYTES;
+      bf16x8 fa[8], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = w_frag(lb, wn * 4 + j, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = w_frag(la, wm * 8 + i, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i >> 2][i & 3][j], 0, 0, 0);
+      slot = (slot + 1) & 3;
+    }
+
+#ifdef VLM_GEMM_STAMPS
+    const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
+    const uint32_t vn = v + gridDim.x;
+    const bool more = vn < ntile;
+    const uint32_t em0 = m0, en0 = n0;
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading the ring before the next tile's stages overwrite it
+    if (more) {
+      P_TILE_ORIGIN(vn, m0, n0)
+      P_ISSUE_STAGE(0, 0)
+      P_ISSUE_STAGE(1, 1)
+      P_ISSUE_STAGE(2, 2)
+    }
+    const int s0 = gemm_epilogue<OUT_F32, true>(p, acc[0], em0 + wm * 128, en0 + wn * 64, lane);
+    const int s1 = gemm_epilogue<OUT_F32, true>(p, acc[1], em0 + wm * 128 + 64, en0 + wn * 64, lane);
+#ifdef VLM_GEMM_STAMPS
+    st_loop += st_b - st_a;
+    st_epi += __builtin_amdgcn_s_memtime() - st_b;
+    st_n += 1;
+#endif
+    if (!more) break;
+    after = (s0 < 0 || s1 < 0) ? -1 : s0 + s1;
+    v = vn;
+  }
+#ifdef VLM_GEMM_STAMPS
+  if (p.stamps && tid == 0) {  // per workgroup: [0]=0, [1]=loop cycles per tile, [2]=+epilogue issue, [3]=total/tiles
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tot = __builtin_amdgcn_s_memtime() - st_t0;
+    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+    o[0] = 0; o[1] = 0; o[2] = st_loop / st_n; o[3] = (st_loop + st_epi) / st_n;
+    o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = tot; o[7] = st_n;
+  }
+#endif
+}
+
+template <bool OUT_F32>
+static int launch_gemm_p256(gemm_params_t p, hipStream_t stream) {
+  const size_t smem = P_STAGES * P_STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_p256_kernel<OUT_F32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return VLM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + P_BM - 1) / P_BM;
+  p.tiles_n = (p.N + P_BN - 1) / P_BN;
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  const int ntile = p.tiles_m * p.tiles_n;
+  dim3 grid(ntile < cus ? ntile : cus), block(P_THREADS);
+  hipLaunchKernelGGL((vlm_gemm_p256_kernel<OUT_F32>), grid, block, smem, stream, p);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
@@ -830,16 +1041,30 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
   }
-  // 256x256 kernel: A K-contiguous, whole 64-deep K tiles, and at least ~2 rounds of 256 workgroups
-  static int big_mode = -1;
-  if (big_mode < 0) {
-    const char* e = getenv("VLM_GEMM_BIG");
-    big_mode = e ? atoi(e) : 0;  // off: one workgroup per CU leaves prologue+epilogue exposed at K=768 (measured 10-40 % slower)
+  // 256x128 three-stage kernel: both operands K-contiguous and at least ~2 rounds of 512 resident workgroups
+  static int wide_mode = -1, wide_group = 0;
+  if (wide_mode < 0) {
+    const char* e = getenv("VLM_GEMM_WIDE");
+    wide_mode = e ? atoi(e) : 0;  // measured equal to the 128x128 kernel per flop (same ~1500 cycles per 32 MFMAs)
+    const char* g = getenv("VLM_GEMM_WIDE_GROUP_M");
+    wide_group = g ? atoi(g) : 0;
   }
-  if (big_mode && !ta && (K % GEMM_BK) == 0 &&
-      ((M + BIG_BM - 1) / BIG_BM) * ((N + BIG_BN - 1) / BIG_BN) >= big_mode * 500) {
-    if (tb) return c_is_f32 ? launch_gemm_big<true, true>(p, s) : launch_gemm_big<true, false>(p, s);
-    return c_is_f32 ? launch_gemm_big<false, true>(p, s) : launch_gemm_big<false, false>(p, s);
+  static int p256_mode = -1;
+  if (p256_mode < 0) {
+    const char* e = getenv("VLM_GEMM_P256");
+    p256_mode = e ? atoi(e) : 1;
+  }
+  if (p256_mode && !ta && !tb && (K % W_BK) == 0 && K >= 3 * W_BK && !epi->col_sum &&
+      ((M + P_BM - 1) / P_BM) * ((N + P_BN - 1) / P_BN) >= p256_mode * 1000) {
+    const char* g = getenv("VLM_GEMM_P256_GROUP_M");
+    static int p256_group = g ? atoi(g) : 8;
+    p.group_m = p256_group;
+    return c_is_f32 ? launch_gemm_p256<true>(p, s) : launch_gemm_p256<false>(p, s);
+  }
+  if (wide_mode && !ta && !tb && (K % W_BK) == 0 && ((M + W_BM - 1) / W_BM) * ((N + W_BN - 1) / W_BN) >= wide_mode * 1000) {
+    if (wide_group > 0) p.group_m = wide_group;
+    else if (!group_m) p.group_m = 4;
+    return c_is_f32 ? launch_gemm_wide<true>(p, s) : launch_gemm_wide<false>(p, s);
   }
   const int key = (ta ? 4 : 0) | (tb ? 2 : 0) | (c_is_f32 ? 1 : 0);
   switch (key) {
