@@ -178,9 +178,9 @@ def test_gemm_epilogues(ops, L):
     assert_close(cs_r[:50], acc[:, :50].sum(0), 2e-3, 2e-2, "col_sum (ragged N)")
 
 
-def test_gemm_wide_tile_kernel(ops, L):
-    """Shapes large enough for the 256x128x32 three-stage kernel (>= 1000 tiles, both operands K-contiguous): ragged M,
-    every epilogue of the transformer block, against fp32 matmul of the bf16 operands."""
+def test_gemm_large_m_epilogues(ops, L):
+    """Training-sized M (thousands of tiles, grouped raster, ragged last tile) with every epilogue of the transformer
+    block, against fp32 matmul of the bf16 operands."""
     gen = torch.Generator(device="cuda"); gen.manual_seed(21)
     M, N, K = 256 * 130 + 77, 2304, 768
     A = bf(torch.randn(M, K, device="cuda", generator=gen))

@@ -624,337 +624,19 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
   return VLM_OK;
 }
 
-// ======================================================================================================================
-// 256x128x32 tile, 4 waves (2x2) of 128x64, THREE LDS stages of 24 KiB filled by LDS-DMA, two workgroups per CU.
-// Why (tools/stamp_gemm.py, profiles/): the 128x128 loop runs at the rate its operands arrive from L2 -- 2 x 32 KiB
-// per CU and 64-deep K step at ~30 B/clk/CU, twice the MFMA time; with the staging switched off the same loop sits on
-// the MFMA bound.  This tile moves 0.75x the bytes per flop, keeps two K steps (48 KiB per workgroup) in flight
-// instead of one, and still leaves a partner workgroup on the CU to cover prologue and epilogue.
-// Both operands K-contiguous (nn.Linear layout); K % 32 == 0.
-#define W_BM 256
-#define W_BN 128
-#define W_BK 32
-#define W_STAGES 3
-#define W_A_BYTES (W_BM * W_BK * 2)               // 16 KiB
-#define W_STAGE_BYTES ((W_BM + W_BN) * W_BK * 2)  // 24 KiB
-
-// Stage image: a tile row is 64 B (32 bf16); rows 2R and 2R+1 share the 128-B line R, whose eight 16-B chunks
-// C = 4*(row&1) + kchunk are stored at position C ^ (R & 7): the 16 lanes of one ds_read_b128 cycle hit 16 different
-// 16-B slots of both 128-B bank halves (conflict-free, same argument as the 128-B-row image above).
-__device__ __forceinline__ bf16x8 w_frag(const unsigned char* tile, int row16, int lane) {
-  const int r = row16 * 16 + (lane & 15), R = r >> 1;
-  const int phys = ((((r & 1) << 2) | (lane >> 4)) ^ (R & 7));
-  return *reinterpret_cast<const bf16x8*>(tile + R * 128 + phys * 16);
-}
-
-// one wave's share (6 of 24 instructions) of a stage: instruction jj covers 16 tile rows = 8 lines = 1 KiB of LDS
-__device__ __forceinline__ void w_stage_dma(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned char* stage,
-                                            uint32_t m0, uint32_t n0, uint32_t k0, uint32_t lda, uint32_t ldb, int wave,
-                                            int lane) {
-  const uint32_t Rl = lane >> 3, C = (lane & 7) ^ Rl;     // line inside the instruction, logical chunk
-  const uint32_t rl = 2 * Rl + (C >> 2), kc = (C & 3) * 8;  // tile row inside the 16-row block, k offset (elements)
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const uint32_t jj = wave + 4 * u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(stage + jj * 1024), 16,
-                                             ((m0 + jj * 16 + rl) * lda + k0 + kc) * 2, 0, 0, 0);
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const uint32_t jj = wave + 4 * u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(stage + W_A_BYTES + jj * 1024), 16,
-                                             ((n0 + jj * 16 + rl) * ldb + k0 + kc) * 2, 0, 0, 0);
-  }
-}
-
-// s_waitcnt with only the vmcnt field active (gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14)
-#define W_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14))
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_wide_kernel(const gemm_params_t p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 128x64 each
-  STAMP(0)
-
-  const uint32_t nblk = gridDim.x, bid = blockIdx.x;
-  const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  uint32_t tm, tn;
-  {
-    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;
-    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;
-    tm = first + in % rows;
-    tn = in / rows;
-  }
-  const uint32_t m0 = tm * W_BM, n0 = tn * W_BN;
-
-  const __amdgpu_buffer_rsrc_t ra =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
-
-  f32x4 acc[2][4][4];  // [64-row half][16-row block][16-col block]
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[hf][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / W_BK;
-  w_stage_dma(ra, rb, smem, m0, n0, 0, p.lda, p.ldb, wave, lane);
-  if (nk > 1) {
-    w_stage_dma(ra, rb, smem + W_STAGE_BYTES, m0, n0, W_BK, p.lda, p.ldb, wave, lane);
-    W_WAIT_VM(6);  // stage 0 landed, stage 1 may still fly
-  } else {
-    W_WAIT_VM(0);
-  }
-  __builtin_amdgcn_s_barrier();
-  STAMP(1)
-
-  int slot = 0, slot2 = 2;  // slot of K step kt, slot of K step kt+2
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 2 < nk)
-      w_stage_dma(ra, rb, smem + slot2 * W_STAGE_BYTES, m0, n0, (kt + 2) * W_BK, p.lda, p.ldb, wave, lane);
-    const unsigned char* la = smem + slot * W_STAGE_BYTES;
-    const unsigned char* lb = la + W_A_BYTES;
-    bf16x8 fa[8], fb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = w_frag(lb, wn * 4 + j, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = w_frag(la, wm * 8 + i, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i >> 2][i & 3][j], 0, 0, 0);
-    // K step kt+1 must have landed before anyone reads it; the step issued above (6 instructions per wave) may fly on
-    if (kt + 2 < nk) W_WAIT_VM(6);
-    else W_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
-    slot = slot == 2 ? 0 : slot + 1;
-    slot2 = slot2 == 2 ? 0 : slot2 + 1;
-  }
-  STAMP(2)
-  gemm_epilogue<OUT_F32>(p, acc[0], m0 + wm * 128, n0 + wn * 64, lane);
-  gemm_epilogue<OUT_F32>(p, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, lane);
-#ifdef VLM_GEMM_STAMPS
-  __builtin_amdgcn_s_waitcnt(0);
-  STAMP(3)
-#endif
-}
-
-template <bool OUT_F32>
-static int launch_gemm_wide(gemm_params_t p, hipStream_t stream) {
-  const size_t smem = W_STAGES * W_STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_wide_kernel<OUT_F32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return VLM_ERR_LAUNCH;
-    attr_set = true;
-  }
-  p.tiles_m = (p.M + W_BM - 1) / W_BM;
-  p.tiles_n = (p.N + W_BN - 1) / W_BN;
-  dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
-  hipLaunchKernelGGL((vlm_gemm_wide_kernel<OUT_F32>), grid, block, smem, stream, p);
-  VLM_CHECK_LAUNCH();
-  return VLM_OK;
-}
-
-// ======================================================================================================================
-// Persistent 256x256x32 kernel: ONE workgroup of 8 waves (2x4, 128x64 each) per CU, four LDS stages of 32 KiB.
-// Why (tools/stamp_gemm.py): per 64-deep K step both kernels above spend ~1500 cycles where the MFMAs need 1024 and
-// the same loop without staging runs at 993 -- the vector-memory path (one LDS-DMA instruction per KiB, 64 B/clk/CU)
-// is the co-bottleneck, and 128x128 tiles ask it for 64 B per MFMA cycle.  A 256x256 tile asks for 16.  With one
-// workgroup per CU nothing else hides prologue and epilogue, so the kernel is persistent: after a tile's last K step
-// it issues the next tile's first three stages, THEN runs the epilogue, and the next tile's first waits are counted
-// (s_waitcnt vmcnt(N) with N = everything younger than the stage, the epilogue's stores included), so the stores
-// drain under the next tile's MFMAs instead of being waited for at s_endpgm.
-// Both operands K-contiguous; K % 32 == 0, K >= 96.
-#define P_BM 256
-#define P_BN 256
-#define P_THREADS 512
-#define P_STAGES 4
-#define P_HALF_BYTES (256 * W_BK * 2)  // 16 KiB: A or B part of a stage
-#define P_STAGE_BYTES (2 * P_HALF_BYTES)
-
-__device__ __forceinline__ void p_wait_vm(int n) {  // runtime-counted vmcnt wait (the immediate must be constant)
-  switch (n) {
-    case 4: W_WAIT_VM(4); break;
-    case 8: W_WAIT_VM(8); break;
-    case 16: W_WAIT_VM(16); break;
-    case 20: W_WAIT_VM(20); break;
-    case 24: W_WAIT_VM(24); break;
-    case 32: W_WAIT_VM(32); break;
-    case 36: W_WAIT_VM(36); break;
-    case 40: W_WAIT_VM(40); break;
-    case 48: W_WAIT_VM(48); break;
-    case 52: W_WAIT_VM(52); break;
-    case 56: W_WAIT_VM(56); break;
-    default: W_WAIT_VM(0); break;
-  }
-}
-
-template <bool OUT_F32>
-__global__ __launch_bounds__(P_THREADS, 2) void vlm_gemm_p256_kernel(const gemm_params_t p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // 2x4 waves, 128x64 each
-
-  const __amdgpu_buffer_rsrc_t ra =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
-  const uint32_t ntile = p.tiles_m * p.tiles_n;
-  const int nk = p.K / W_BK;
-
-  // per-lane part of the DMA source offsets (stage image of w_frag): instruction jj covers tile rows 16*jj..+15
-  const uint32_t Rl = lane >> 3, Cc = (lane & 7) ^ Rl;
-  const uint32_t rl = 2 * Rl + (Cc >> 2), kcb = (Cc & 3) * 16;  // row inside the block, k offset in bytes
-  uint32_t offa[2], offb[2];
-
-  // (macros, not lambdas: a lambda capturing the offset arrays by reference sends them to scratch memory, and scratch
-  // traffic would also break the vmcnt bookkeeping below)
-#define P_TILE_ORIGIN(vv, mm0, nn0)                                                                                    \
-  {                                                                                                                    \
-    const uint32_t q8 = ntile >> 3, r8 = ntile & 7, xcd = (vv) & 7;                                                    \
-    const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((vv) >> 3);                 \
-    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;                 \
-    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;                                 \
-    mm0 = (first + in % rows) * P_BM;                                                                                  \
-    nn0 = (in / rows) * P_BN;                                                                                          \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                    \
-      const uint32_t jj = wave + 8 * u;                                                                                \
-      offa[u] = (mm0 + jj * 16 + rl) * p.lda * 2 + kcb;                                                                \
-      offb[u] = (nn0 + jj * 16 + rl) * p.ldb * 2 + kcb;                                                                \
-    }                                                                                                                  \
-  }
-#define P_ISSUE_STAGE(slot_, kt_) /* 4 LDS-DMA instructions per wave */                                                \
-  {                                                                                                                    \
-    unsigned char* st = smem + (slot_) * P_STAGE_BYTES;                                                                \
-    const int kbytes = (kt_) * (W_BK * 2);                                                                             \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
-        ra, (lds_void*)(st + (wave + 8 * u) * 1024), 16, offa[u], kbytes, 0, 0);                                       \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(                            \
-        rb, (lds_void*)(st + P_HALF_BYTES + (wave + 8 * u) * 1024), 16, offb[u], kbytes, 0, 0);                        \
-  }
-
-  uint32_t v = blockIdx.x, m0, n0;
-  P_TILE_ORIGIN(v, m0, n0)
-  P_ISSUE_STAGE(0, 0)
-  P_ISSUE_STAGE(1, 1)
-  P_ISSUE_STAGE(2, 2)
-  int after = 0;  // vector-memory instructions this wave issued AFTER the three prologue stages (epilogue stores)
-#ifdef VLM_GEMM_STAMPS
-  unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  for (;;) {
-#ifdef VLM_GEMM_STAMPS
-    const unsigned long long st_a = __builtin_amdgcn_s_memtime();
-#endif
-    f32x4 acc[2][4][4];  // [64-row half][16-row block][16-col block]
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[hf][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      // stage kt must have landed: everything younger may still fly (up to two later stages, plus -- during the first
-      // three steps of a tile -- the previous tile's epilogue stores, which were issued after this tile's prologue)
-      const int younger = 4 * min(2, nk - 1 - kt);
-      if (kt < 3) {
-        if (after < 0) W_WAIT_VM(0);
-        else p_wait_vm(younger + after);
-      } else if (younger == 8) {
-        W_WAIT_VM(8);
-      } else if (younger == 4) {
-        W_WAIT_VM(4);
-      } else {
-        W_WAIT_VM(0);
-      }
-      __builtin_amdgcn_s_barrier();  // stage kt visible to all waves; everyone is done reading the slot of step kt-1
-      if (kt + 3 < nk) P_ISSUE_STAGE((slot + 3) & 3, kt + 3)
-      const unsigned char* la = smem + slot * P_STAGE_BYTES;
-      const unsigned char* lb = la + P_HALF_BYTES;
-      bf16x8 fa[8], fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = w_frag(lb, wn * 4 + j, lane);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = w_frag(la, wm * 8 + i, lane);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i >> 2][i & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i >> 2][i & 3][j], 0, 0, 0);
-      slot = (slot + 1) & 3;
-    }
-
-#ifdef VLM_GEMM_STAMPS
-    const unsigned long long st_b = __builtin_amdgcn_s_memtime();
-#endif
-    const uint32_t vn = v + gridDim.x;
-    const bool more = vn < ntile;
-    const uint32_t em0 = m0, en0 = n0;
-    __builtin_amdgcn_s_barrier();  // every wave has finished reading the ring before the next tile's stages overwrite it
-    if (more) {
-      P_TILE_ORIGIN(vn, m0, n0)
-      P_ISSUE_STAGE(0, 0)
-      P_ISSUE_STAGE(1, 1)
-      P_ISSUE_STAGE(2, 2)
-    }
-    const int s0 = gemm_epilogue<OUT_F32, true>(p, acc[0], em0 + wm * 128, en0 + wn * 64, lane);
-    const int s1 = gemm_epilogue<OUT_F32, true>(p, acc[1], em0 + wm * 128 + 64, en0 + wn * 64, lane);
-#ifdef VLM_GEMM_STAMPS
-    st_loop += st_b - st_a;
-    st_epi += __builtin_amdgcn_s_memtime() - st_b;
-    st_n += 1;
-#endif
-    if (!more) break;
-    after = (s0 < 0 || s1 < 0) ? -1 : s0 + s1;
-    v = vn;
-  }
-#ifdef VLM_GEMM_STAMPS
-  if (p.stamps && tid == 0) {  // per workgroup: [0]=0, [1]=loop cycles per tile, [2]=+epilogue issue, [3]=total/tiles
-    __builtin_amdgcn_s_waitcnt(0);
-    const unsigned long long tot = __builtin_amdgcn_s_memtime() - st_t0;
-    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
-    o[0] = 0; o[1] = 0; o[2] = st_loop / st_n; o[3] = (st_loop + st_epi) / st_n;
-    o[4] = st_r0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = tot; o[7] = st_n;
-  }
-#endif
-}
-
-template <bool OUT_F32>
-static int launch_gemm_p256(gemm_params_t p, hipStream_t stream) {
-  const size_t smem = P_STAGES * P_STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vlm_gemm_p256_kernel<OUT_F32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return VLM_ERR_LAUNCH;
-    attr_set = true;
-  }
-  p.tiles_m = (p.M + P_BM - 1) / P_BM;
-  p.tiles_n = (p.N + P_BN - 1) / P_BN;
-  int cus = vlm_device_cus();
-  if (cus <= 0) cus = 256;
-  const int ntile = p.tiles_m * p.tiles_n;
-  dim3 grid(ntile < cus ? ntile : cus), block(P_THREADS);
-  hipLaunchKernelGGL((vlm_gemm_p256_kernel<OUT_F32>), grid, block, smem, stream, p);
-  VLM_CHECK_LAUNCH();
-  return VLM_OK;
-}
-
+// ----------------------------------------------------------------------------------------------------------------------
+// Tile-shape experiments (round 1, removed from the build; see DESIGN.md section 4 and git history for the code):
+//  * 256x128x32, 4 waves of 128x64, three 24-KiB stages, two workgroups per CU: same ~1500 cycles per 32 MFMAs per wave
+//    pair as this kernel (0.75x the operand bytes did not matter);
+//  * 256x256, 8 waves, one workgroup per CU, two 64-KiB stages: 3400 cycles per 64-deep K step (MFMA bound 2048) and an
+//    exposed 21k-cycle epilogue;
+//  * persistent 256x256x32, four 32-KiB stages, counted vmcnt waits so the stores of tile t drain under tile t+1:
+//    2088 cycles per 32-deep step (two waves of ONE workgroup on a SIMD run in lock step behind the same barrier and
+//    do not overlap each other's LDS phase) and a 17.7k-cycle store-issue-bound epilogue (~7 B/clk/CU, as
+//    MI355X_MICROARCH.md reports for store tails) that no partner workgroup hides.
+// With staging switched off (tools/stamp_gemm.py, variant _noload) this kernel's loop runs at the MFMA bound (993 of
+// 1024 cycles per K step); with staging and no MFMAs it takes as long as the full loop: what remains is the vector-memory
+// issue path (8 LDS-DMA instructions per wave and K step) overlapped only by the partner workgroup's MFMAs.
 // staging policy: K-contiguous operands by LDS-DMA, K-strided operands through registers (VLM_GEMM_STAGE: 0 = all
 // registers, 1 = all DMA, 2 = hybrid [default]); VLM_GEMM_SPLITK=0 disables split-K
 static int gemm_stage_mode() {
@@ -1040,31 +722,6 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
       if (!group_m && p.tiles_n >= 12) p.group_m = 1;  // split-K: co-resident blocks already share tiles across K slices
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
-  }
-  // 256x128 three-stage kernel: both operands K-contiguous and at least ~2 rounds of 512 resident workgroups
-  static int wide_mode = -1, wide_group = 0;
-  if (wide_mode < 0) {
-    const char* e = getenv("VLM_GEMM_WIDE");
-    wide_mode = e ? atoi(e) : 0;  // measured equal to the 128x128 kernel per flop (same ~1500 cycles per 32 MFMAs)
-    const char* g = getenv("VLM_GEMM_WIDE_GROUP_M");
-    wide_group = g ? atoi(g) : 0;
-  }
-  static int p256_mode = -1;
-  if (p256_mode < 0) {
-    const char* e = getenv("VLM_GEMM_P256");
-    p256_mode = e ? atoi(e) : 1;
-  }
-  if (p256_mode && !ta && !tb && (K % W_BK) == 0 && K >= 3 * W_BK && !epi->col_sum &&
-      ((M + P_BM - 1) / P_BM) * ((N + P_BN - 1) / P_BN) >= p256_mode * 1000) {
-    const char* g = getenv("VLM_GEMM_P256_GROUP_M");
-    static int p256_group = g ? atoi(g) : 8;
-    p.group_m = p256_group;
-    return c_is_f32 ? launch_gemm_p256<true>(p, s) : launch_gemm_p256<false>(p, s);
-  }
-  if (wide_mode && !ta && !tb && (K % W_BK) == 0 && ((M + W_BM - 1) / W_BM) * ((N + W_BN - 1) / W_BN) >= wide_mode * 1000) {
-    if (wide_group > 0) p.group_m = wide_group;
-    else if (!group_m) p.group_m = 4;
-    return c_is_f32 ? launch_gemm_wide<true>(p, s) : launch_gemm_wide<false>(p, s);
   }
   const int key = (ta ? 4 : 0) | (tb ? 2 : 0) | (c_is_f32 ? 1 : 0);
   switch (key) {
