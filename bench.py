@@ -93,6 +93,18 @@ class GemmTimer:
         return {"launches": n, "seconds": t, "flop": fl, "avg_us": t / n * 1e6, "tflops": fl / t / 1e12}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same bench command
+    (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units,
+    FETCH_SIZE doubled on gfx950).  Counters cannot be read from inside the timed process; None if the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def calibrate(dev):
     """What this box attains with vendor code (report nominal AND attainable peaks): a large bf16 GEMM
     through torch (hipBLASLt) and a device-to-device copy.  Context for roofline.frac; never used as its denominator."""
@@ -276,7 +288,9 @@ def main():
         out["model_tflops"] = value * flop_per_sample / 1e12 / world
         if gs:
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "vlm_gemm_kernel",
+                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("vlm_gemm_kernel"),
+                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                               "kernel": "vlm_gemm_kernel",
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "timed_steps": len(range(0, args.steps, max(1, args.gemm_timer_every))),
                                "gemm_share_of_step": gs["seconds"] / (dt / args.steps *
@@ -291,8 +305,8 @@ def main():
             out["merge"] = {"metric": "all_moe->ufo interpolation merge, base size, fp32", "GBps": m["GBps"],
                             "seconds_median": m["seconds_median"], "algorithmic_bytes": m["algorithmic_bytes"],
                             "roofline": {"bound": "hbm", "achieved": m["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                         "frac": m["GBps"] / HBM_PEAK_GBPS, "traffic": None,
-                                         "kernel": "vlm_merge_kernel"}}
+                                         "frac": m["GBps"] / HBM_PEAK_GBPS,
+                                         "traffic": pmc_traffic("vlm_merge_kernel"), "kernel": "vlm_merge_kernel"}}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline()
