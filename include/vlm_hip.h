@@ -146,6 +146,10 @@ int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_
                    float beta2, float eps, float weight_decay, float step_size, float grad_scale, int zero_grad,
                    void* stream);
 int vlm_cast_f32_bf16(const float* src, void* dst_bf16, uint64_t n, void* stream);
+/* DropPath (timm drop_path, modules/vision_transformer.py:446 used at :586/:603): out[row] = u[b] < keep ? 1/keep : 0
+ * for every token row of sample b in the segment-major layout (text rows base0 + b*n0 + t, image rows
+ * base1 + b*n1 + i); u = one uniform [0,1) draw per sample.  The result is the GEMM epilogue's row_scale. */
+int vlm_droppath_rows(const float* u, float keep, int B, int n0, int n1, int base0, int base1, float* out, void* stream);
 int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W, int P, int lead_rows, void* stream);
 /* Gram cache (K15, src/cache_gram_matrices.py:246-254: G += X^T X in float64 for the input X of every hooked linear):
  * the product runs on the MFMA GEMM (vlm_gemm_bf16 ta=1 tb=1 over the bf16 activations the linear consumed, fp32

@@ -108,3 +108,34 @@ def test_param_groups_follow_reference_rule(pkg):
     assert g("mlm_score.bias") == 1
     lam = [vu.polynomial_decay_lambda(s, 10, 110, 1e-4) for s in (0, 5, 10, 60, 110, 200)]
     assert lam[0] == 0 and lam[1] == 0.5 and lam[2] == 1.0 and abs(lam[3] - 0.5) < 1e-12 and lam[4] == 0 and lam[5] == 0
+
+
+def test_flat_params_qkv_bias_view():
+    """FlatParams lays q_bias | zero gap | v_bias out back to back so cat(q_bias, 0, v_bias) (vision_transformer.py:335)
+    is a view; the gap is part of q_bias' extent (optimizer ranges and DDP buckets stay contiguous)."""
+    import torch
+    import importlib
+    import __graft_entry__ as ge
+    ge.import_package()
+    engine = importlib.import_module("vl_merging_amd.engine")
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj_bias = torch.nn.Parameter(torch.randn(128))
+            self.q_bias = torch.nn.Parameter(torch.randn(128))
+            self.v_bias = torch.nn.Parameter(torch.randn(128))
+            self.w = torch.nn.Parameter(torch.randn(8, 8))
+
+    top = torch.nn.Module()
+    top.attn = Attn()
+    m = top.attn
+    q0, v0 = m.q_bias.detach().clone(), m.v_bias.detach().clone()
+    flat = engine.FlatParams(top, order_key=lambda n: n)
+    oq, kq = flat.offsets["attn.q_bias"]
+    ov, _ = flat.offsets["attn.v_bias"]
+    assert ov == oq + 2 * kq and flat.extent["attn.q_bias"] == 2 * kq
+    view = m.q_bias._vlm_qkv_bias
+    assert view.data_ptr() == m.q_bias.data_ptr() and view.numel() == 3 * kq
+    assert torch.equal(view, torch.cat([q0, torch.zeros(128), v0]))
+    assert flat.slice_of(["attn.q_bias"]) == (oq, oq + 2 * kq)

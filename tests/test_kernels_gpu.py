@@ -306,3 +306,20 @@ def test_im2col_matches_conv(ops):
     got = out.view(B, np_ + 1, D)
     assert_close(got[:, 1:], ref, 1e-3, 2e-3, "patch embed")
     assert_close(got[:, 0], bias.expand(B, D), 0, 0, "lead row = bias")
+
+
+def test_droppath_rows(ops):
+    """vlm_droppath_rows == timm drop_path's per-sample mask/keep expanded to the segment-major rows."""
+    B, n0, n1 = 5, 7, 13
+    seq = ops.Seq(B, n0, n1)
+    u = torch.tensor([0.05, 0.95, 0.5, 0.899, 0.9], device="cuda")
+    out = torch.full((seq.rows,), -1.0, device="cuda")
+    ops.droppath_rows(u, 0.9, seq, out)
+    per = torch.where(u < 0.9, torch.tensor(1.0 / 0.9, device="cuda"), torch.tensor(0.0, device="cuda"))
+    want = torch.cat([per.repeat_interleave(n0), per.repeat_interleave(n1)])
+    assert torch.equal(out, want)
+    # image-only layout (n0 = 0)
+    seq2 = ops.Seq(B, 0, n1)
+    out2 = torch.empty(seq2.rows, device="cuda")
+    ops.droppath_rows(u, 0.9, seq2, out2)
+    assert torch.equal(out2, per.repeat_interleave(n1))

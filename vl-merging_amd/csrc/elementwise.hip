@@ -138,6 +138,37 @@ extern "C" int vlm_cast_f32_bf16(const float* src, void* dst, uint64_t n, void* 
   return VLM_OK;
 }
 
+// DropPath row scales (timm drop_path as used at vision_transformer.py:586,:603): per-sample bernoulli(keep)/keep
+// expanded to the segment-major token rows of a pass; u holds one uniform [0,1) draw per sample.
+__global__ __launch_bounds__(EW_THREADS) void droppath_rows_kernel(const float* __restrict__ u, float keep, float inv_keep,
+                                                                   int B, int n0, int n1, int base0, int base1,
+                                                                   float* __restrict__ out) {
+  const int nt = B * n0, total = nt + B * n1;
+  for (int i = blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += gridDim.x * EW_THREADS) {
+    int b, row;
+    if (i < nt) {
+      b = i / n0;
+      row = base0 + i;
+    } else {
+      const int j = i - nt;
+      b = j / n1;
+      row = base1 + j;
+    }
+    out[row] = u[b] < keep ? inv_keep : 0.0f;
+  }
+}
+
+extern "C" int vlm_droppath_rows(const float* u, float keep, int B, int n0, int n1, int base0, int base1, float* out,
+                                 void* stream) {
+  if (B <= 0 || n0 + n1 <= 0) return VLM_OK;
+  if (!u || !out || n0 < 0 || n1 < 0 || base0 < 0 || base1 < 0 || !(keep > 0.0f) || keep > 1.0f) return VLM_ERR_ARG;
+  const size_t total = (size_t)B * (n0 + n1);
+  hipLaunchKernelGGL(droppath_rows_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, u, keep,
+                     1.0f / keep, B, n0, n1, base0, base1, out);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
 extern "C" int vlm_patch_im2col(const float* image, void* patches, int B, int H, int W, int P, int lead_rows,
                                 void* stream) {
   if (B == 0) return VLM_OK;

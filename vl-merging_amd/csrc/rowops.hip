@@ -113,9 +113,12 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const void* __restr
   for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float invD = 1.0f / (float)D;
   for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
-    f32x4 v[MAXU], d[MAXU];
+    f32x4 v[MAXU], d[MAXU], rs[MAXU];
     load_row<MAXU, false>(x, row, ldx, D, lane, v);
     load_row<MAXU, DY_BF16>(dy, row, lddy, D, lane, d);
+    // the residual-path gradient is fetched with the row, not after the two wave reductions (its latency used to sit
+    // between the reduction and the store of every row)
+    if (dres) load_row<MAXU, false>(dres, row, lddres, D, lane, rs);
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const void* __restr
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = rstd * (d[u][r] - m1 - v[u][r] * m2);
-        if (dres) o += *reinterpret_cast<const f32x4*>(dres + row * lddres + c);
+        if (dres) o += rs[u];
         *reinterpret_cast<f32x4*>(dx + row * lddx + c) = o;
       }
     }

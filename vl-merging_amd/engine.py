@@ -34,10 +34,21 @@ class FlatParams:
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         self.offsets = {}
+        self.extent = {}  # padded footprint of a parameter in the flat buffers (what optimizer ranges / buckets cover)
         off = 0
-        for n, p in named:
+        for i, (n, p) in enumerate(named):
             self.offsets[n] = (off, p.numel())
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            ext = (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            # q_bias | zeros | v_bias laid out back to back: cat(q_bias, zeros_like(v_bias), v_bias)
+            # (vision_transformer.py:335) becomes a VIEW of the flat buffer instead of two launches per block and pass.
+            # The gap belongs to q_bias' footprint: zero parameters with zero gradients stay zero under AdamW.
+            nxt = named[i + 1] if i + 1 < len(named) else None
+            if (n.endswith(".q_bias") and nxt is not None and nxt[0] == n[:-len("q_bias")] + "v_bias"
+                    and p.numel() % ALIGN == 0 and nxt[1].numel() == p.numel()):
+                ext = 2 * p.numel()
+                p._vlm_qkv_bias_span = 3 * p.numel()
+            self.extent[n] = ext
+            off += ext
         self.numel = off
         dev = self.params[0].device
         pad = 64 * 4096  # tail slack: K-strided GEMM operands may be addressed a few rows past a ragged weight
@@ -51,6 +62,8 @@ class FlatParams:
             p.grad = self.flat_g[o:o + k].view_as(p)
             p._vlm_name = n
             p._vlm_bf16 = self.flat_b[o:o + k].view_as(p) if self.flat_b is not None else None
+            span = getattr(p, "_vlm_qkv_bias_span", 0)
+            p._vlm_qkv_bias = self.flat_p[o:o + span] if span else None
         self.dirty = True
 
     def refresh_shadow(self):
@@ -66,7 +79,7 @@ class FlatParams:
     def slice_of(self, names):
         """(start, end) of the contiguous flat range covering `names` (a DDP bucket)."""
         lo = min(self.offsets[n][0] for n in names)
-        hi = max(self.offsets[n][0] + (self.offsets[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names)
+        hi = max(self.offsets[n][0] + self.extent[n] for n in names)
         return lo, hi
 
 
@@ -184,6 +197,7 @@ class PassCtx:
         self.keep1 = keep1
         self.gram = None  # GramCapture when the Gram cache is being recorded
         self._row2sample = None
+        self._dp_pool, self._dp_next = None, 0
 
     def row2sample(self, device):
         if self._row2sample is None:
@@ -194,12 +208,19 @@ class PassCtx:
         return self._row2sample
 
     def drop_path_rows(self, prob, training, device):
-        """Per-row scale of timm's DropPath (per-sample bernoulli(keep)/keep), or None when inactive."""
+        """Per-row scale of timm's DropPath (per-sample bernoulli(keep)/keep), or None when inactive.  One uniform
+        draw per pass feeds up to 64 DropPath sites; each site is ONE launch (vlm_droppath_rows) instead of
+        bernoulli_ + div_ + index + contiguous."""
         if not training or prob <= 0.0:
             return None
-        keep = 1.0 - prob
-        per_sample = torch.empty(self.seq.B, device=device, dtype=F32).bernoulli_(keep).div_(keep)
-        return per_sample[self.row2sample(device)].contiguous()
+        if self._dp_pool is None or self._dp_next >= self._dp_pool.shape[0]:
+            self._dp_pool = torch.rand(64, self.seq.B, device=device, dtype=F32)
+            self._dp_next = 0
+        u = self._dp_pool[self._dp_next]
+        self._dp_next += 1
+        s = self.seq
+        rows = max(s.base0 + s.B * s.n0, s.base1 + s.B * s.n1)
+        return ops.droppath_rows(u, 1.0 - prob, s, torch.empty(rows, device=device, dtype=F32))
 
 
 class ExpertWeights:
@@ -272,6 +293,9 @@ def _qkv_bias(e):
     # vision_transformer.py:335: cat(q_bias, zeros_like(v_bias), v_bias)
     if e.qb is None:
         return None
+    view = getattr(e.qb, "_vlm_qkv_bias", None)
+    if view is not None:
+        return view  # [q_bias | 0 | v_bias] as laid out by FlatParams
     return torch.cat((e.qb.detach(), torch.zeros_like(e.vb), e.vb.detach()))
 
 

@@ -132,6 +132,16 @@ def cast_bf16(src, dst):
     return dst
 
 
+def droppath_rows(u, keep, seq, out):
+    """out[row] = bernoulli(keep)/keep of the row's sample (u: one uniform draw per sample), include/vlm_hip.h."""
+    L.require_cuda(u, out)
+    if u.dtype != F32 or out.dtype != F32 or u.numel() < seq.B or not out.is_contiguous():
+        raise L.VlmError("droppath_rows: u f32 [B], out contiguous f32 [rows]")
+    L.check(L.get_lib().vlm_droppath_rows(L.ptr(u), float(keep), seq.B, seq.n0, seq.n1, seq.base0, seq.base1, L.ptr(out),
+                                          L.stream_ptr()), "vlm_droppath_rows")
+    return out
+
+
 def gram_accumulate(x, gram64, tmp32=None):
     """gram64 (float64 [D,D]) += x^T x for bf16 activations x [M,D] (the input of a hooked linear)."""
     L.require_cuda(x, gram64, tmp32)

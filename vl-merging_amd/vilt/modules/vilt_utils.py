@@ -128,7 +128,7 @@ def set_schedule(pl_module, max_steps=None):
     buckets = [[] for _ in range(4)]
     for n in flat.names:
         o, k = flat.offsets[n]
-        buckets[param_group_of(n, heads)].append((o, o + (k + 63) // 64 * 64))
+        buckets[param_group_of(n, heads)].append((o, o + flat.extent[n]))
     groups = [dict(lr=l_, initial_lr=l_, weight_decay=w_, ranges=_merge_ranges(b)) for (w_, l_), b in zip(spec, buckets)]
     if cfg["optim_type"] != "adamw":
         raise NotImplementedError("only optim_type='adamw' is on the hot path")
