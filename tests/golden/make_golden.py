@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
 
-Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr gram)
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt)
 Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
 expected outputs are what the reference computed); no reference source is stored.
 """
@@ -279,9 +279,78 @@ def gold_irtr():
         np.savez_compressed(os.path.join(HERE, f"irtr_tiny_{arch}.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- checkpoint re-keying
+def beit_state(D, F, heads, layers, src_window, shared_table, salt=3):
+    """A BEiT-format state_dict as the reference expects it at vilt_module.py:808 (keys already under "transformer."):
+    per-layer (pt22k) or shared (pt22k_ft22k) relative-position tables at `src_window`, fc_norm instead of norm."""
+    R = (2 * src_window - 1) ** 2 + 3
+    n = src_window * src_window + 1
+    sd = {}
+
+    def put(k, shape):
+        sd[k] = torch.from_numpy(det_array(k, shape, salt))
+
+    put("transformer.cls_token", (1, 1, D))
+    put("transformer.patch_embed.proj.weight", (D, 3, 16, 16))
+    put("transformer.patch_embed.proj.bias", (D,))
+    for i in range(layers):
+        b = "transformer.blocks.%d." % i
+        for k, shp in (("gamma_1", (D,)), ("gamma_2", (D,)), ("norm1.weight", (D,)), ("norm1.bias", (D,)),
+                       ("attn.q_bias", (D,)), ("attn.v_bias", (D,)), ("attn.qkv.weight", (3 * D, D)),
+                       ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("norm2.weight", (D,)),
+                       ("norm2.bias", (D,)), ("mlp.fc1.weight", (F, D)), ("mlp.fc1.bias", (F,)),
+                       ("mlp.fc2.weight", (D, F)), ("mlp.fc2.bias", (D,))):
+            put(b + k, shp)
+        if not shared_table:
+            put(b + "attn.relative_position_bias_table", (R, heads))
+            sd[b + "attn.relative_position_index"] = torch.arange(n * n, dtype=torch.int64).view(n, n) % R
+    if shared_table:
+        put("transformer.rel_pos_bias.relative_position_bias_table", (R, heads))
+        sd["transformer.rel_pos_bias.relative_position_index"] = torch.arange(n * n, dtype=torch.int64).view(n, n) % R
+    put("transformer.fc_norm.weight", (D,))
+    put("transformer.fc_norm.bias", (D,))
+    return sd
+
+
+CKPT_CASES = [
+    dict(name="beit_moe_perlayer_clone", arch="all_moe", shared=False, fn="modify_checkpoint_beit",
+         cfg=dict(use_vision_weights_for_other_modalities=True)),
+    dict(name="beit_moe_shared", arch="all_moe", shared=True, fn="modify_checkpoint_beit", cfg=dict()),
+    dict(name="beit_ufo_perlayer", arch="ufo", shared=False, fn="modify_checkpoint_beit", cfg=dict()),
+    dict(name="self_ufo_shared", arch="ufo", shared=True, fn="modify_checkpoint_self", cfg=dict()),
+]
+
+
+def gold_ckpt():
+    out = {}
+    meta = {}
+    for case in CKPT_CASES:
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_text_len=40, vocab_size=64,
+                          loss_names={"irtr": 1}, **case["cfg"])
+        model, cfg = build_reference_model(cfg, case["arch"])
+        load_det_weights(model)
+        sd = beit_state(192, 768, 3, 12, 7, case["shared"])
+        if case["fn"] == "modify_checkpoint_self":
+            # the reference reads these two keys unconditionally (vilt_module.py:979): a 60-position text table to truncate
+            sd["text_embeddings.position_embeddings.weight"] = torch.from_numpy(
+                det_array("text_embeddings.position_embeddings.weight", (60, 192), 3))
+            sd["text_embeddings.position_ids"] = torch.arange(60).view(1, 60)
+            res = model.modify_checkpoint_self(dict(sd))
+        else:
+            res = model.modify_checkpoint_beit({"state_dict": dict(sd)})
+        digest = {k: [list(v.shape), str(v.dtype).replace("torch.", ""), sha(v.detach().contiguous().numpy())]
+                  for k, v in res.items()}
+        meta[case["name"]] = digest
+        out[case["name"] + "/relative_position_bias_table"] = res["relative_position_bias_table"].detach().numpy()
+        print(case["name"], len(sd), "->", len(res), "keys; table", tuple(res["relative_position_bias_table"].shape))
+    np.savez_compressed(os.path.join(HERE, "ckpt_rekey.npz"), **out)
+    with open(os.path.join(HERE, "ckpt_rekey_digests.json"), "w") as f:
+        json.dump(meta, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["index", "merge", "merge_base", "model", "irtr"]
     torch.manual_seed(0)
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
-         "irtr": gold_irtr}[w]()
+         "irtr": gold_irtr, "ckpt": gold_ckpt}[w]()

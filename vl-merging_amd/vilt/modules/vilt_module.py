@@ -279,6 +279,16 @@ class ViLTransformerSS(nn.Module):
             state_dict["relative_position_bias_table"] = torch.cat((embed, extra), dim=0)
         return state_dict
 
+    def modify_checkpoint_beit(self, ckpt):
+        """vilt_module.py:808-972 (BEiT checkpoints -> this model's keys), see vl_merging_amd/checkpoint.py."""
+        from ... import checkpoint
+        return checkpoint.modify_checkpoint_beit(self, ckpt)
+
+    def modify_checkpoint_self(self, ckpt):
+        """vilt_module.py:974-1058."""
+        from ... import checkpoint
+        return checkpoint.modify_checkpoint_self(self, ckpt)
+
     # ---- relative position bias --------------------------------------------------------------------------------------------
     def get_rel_pos_bias(self, relative_position_index, n_text=None):
         """Reference :1061-1064 returns a dense [H*L, N, N] tensor; here: an engine.RelPos handle for the attention
