@@ -246,3 +246,20 @@ def gram_inputs(sd, a: Arch, idx, batch):
             add(f"transformer.blocks.{i}.mlp.{m}.fc2", a1)
             x = x + g2 * F.linear(a1, sd[_k(i, "mlp", "fc2.weight", m)], sd[_k(i, "mlp", "fc2.bias", m)])
     return grams
+
+
+def recall_ref(img_feats, txt_feats, iids, tiids, ks=(1, 5, 10)):
+    """TEST INFRASTRUCTURE.  numpy restatement of the recall arithmetic of compute_irtr_recall, reference
+    src/vilt/modules/objectives.py:679-710: scores = img @ txt^T; a query is a hit at k when any of its k best
+    candidates (largest score first, ties by lower index as torch.topk on CPU resolves them) carries its id.
+    Returns (ir_r1, ir_r5, ir_r10, tr_r1, tr_r5, tr_r10) as float32 means, like the reference's .float().mean()."""
+    import numpy as np
+    scores = np.asarray(img_feats, dtype=np.float32) @ np.asarray(txt_feats, dtype=np.float32).T
+    iids, tiids = np.asarray(iids), np.asarray(tiids)
+    tr, ir = [], []
+    for k in ks:
+        top_txt = np.argsort(-scores, axis=1, kind="stable")[:, :k]
+        tr.append(np.float32((iids[:, None] == tiids[top_txt]).any(axis=1).astype(np.float32).mean()))
+        top_img = np.argsort(-scores, axis=0, kind="stable")[:k, :]
+        ir.append(np.float32((tiids[None, :] == iids[top_img]).any(axis=0).astype(np.float32).mean()))
+    return tuple(ir) + tuple(tr)

@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
 
-Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt)
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt recall)
 Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
 expected outputs are what the reference computed); no reference source is stored.
 """
@@ -348,9 +348,85 @@ def gold_ckpt():
         json.dump(meta, f, indent=0, sort_keys=True)
 
 
+# ----------------------------------------------------------------------------- retrieval recall
+class _RecallDset(torch.utils.data.Dataset):
+    """Stand-in for the datamodule's no-false test dataset: items are what BaseDataset.collate would have produced."""
+
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    @staticmethod
+    def collate(batch, mlm_collator=None):
+        out = {"img_index": [b["img_index"] for b in batch]}
+        for k in batch[0]:
+            if k == "img_index":
+                continue
+            if k == "image":
+                out[k] = [torch.stack([b[k] for b in batch])]
+            else:
+                out[k] = torch.stack([b[k] for b in batch])
+        return out
+
+
+def recall_inputs(n_img=10, caps=3, size=224, T=40, vocab=1024):
+    ib = det_batch(n_img, size, T, vocab, seed=91)
+    tb = det_batch(n_img * caps, size, T, vocab, seed=92)
+    texts = [{"text_ids": torch.from_numpy(tb["text_ids"][j]), "text_masks": torch.from_numpy(tb["text_masks"][j]),
+              "text_labels": torch.from_numpy(tb["text_labels"][j]), "img_index": j // caps}
+             for j in range(n_img * caps)]
+    images = [{"image": torch.from_numpy(ib["image"][i]), "img_index": i} for i in range(n_img)]
+    return texts, images
+
+
+def gold_recall():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    vm, vit, obj = import_reference()
+    out = {}
+    for arch in ("ufo", "all_moe"):
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_text_len=40,
+                          vocab_size=1024, loss_names={"irtr": 1}, drop_rate=0.1)
+        model, cfg = build_reference_model(cfg, arch)
+        load_det_weights(model)  # same weights as irtr_tiny_<arch>.npz / keys_tiny_irtr_<arch>.json
+        model.eval()
+        texts, images = recall_inputs()
+
+        class DM:
+            tokenizer = None
+            mlm_collator = None
+
+            def make_no_false_test_dset(self, image_only=False):
+                return _RecallDset(images if image_only else texts)
+
+        model.trainer = types.SimpleNamespace(datamodule=types.SimpleNamespace(dms=[DM()]))
+        r = obj.compute_irtr_recall(model, split="test")
+        out[arch + "/recalls"] = np.array([float(x) for x in r])  # ir_r1, ir_r5, ir_r10, tr_r1, tr_r5, tr_r10
+        with torch.no_grad():
+            tf = model.infer_text_ft({"text_ids": torch.stack([t["text_ids"] for t in texts]),
+                                      "text_masks": torch.stack([t["text_masks"] for t in texts]),
+                                      "text_labels": torch.stack([t["text_labels"] for t in texts])})["cls_feats"]
+            imf = model.infer_image_ft({"image": [torch.stack([i["image"] for i in images])],
+                                        "text_masks": texts[0]["text_masks"][None]})["cls_feats"]
+        out[arch + "/txt_cls_feats"] = tf.numpy()
+        out[arch + "/img_cls_feats"] = imf.numpy()
+        out[arch + "/tiids"] = np.array([t["img_index"] for t in texts])
+        out[arch + "/iids"] = np.array([i["img_index"] for i in images])
+        print(arch, "recalls", out[arch + "/recalls"])
+    np.savez_compressed(os.path.join(HERE, "irtr_recall_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["index", "merge", "merge_base", "model", "irtr"]
     torch.manual_seed(0)
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
-         "irtr": gold_irtr, "ckpt": gold_ckpt}[w]()
+         "irtr": gold_irtr, "ckpt": gold_ckpt, "recall": gold_recall}[w]()

@@ -168,3 +168,35 @@ def test_train_mode_step_and_optimizer(mods, golden_dir):
     assert float((w1 - w0).abs().max()) > 0
     assert torch.equal(model._flat.flat_b[:model._flat.numel], model._flat.flat_p[:model._flat.numel].to(torch.bfloat16))
     assert float(model._flat.flat_g.abs().max()) == 0.0  # fused zero_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_irtr_recall_matches_reference_golden(mods, golden_dir, arch):
+    """compute_irtr_recall end to end on the engine: the two feature sweeps against the reference's features (bf16 GEMM
+    tolerance 3e-2 on L2-normalised features) and the six recalls against the reference's own compute_irtr_recall on
+    the same 10 images x 3 captions (a recall may move by one query, 0.1 / 0.034, when a bf16-sized score gap flips)."""
+    from oracle.detweights import det_batch
+    gold = np.load(os.path.join(golden_dir, "irtr_recall_tiny.npz"))
+    obj = importlib.import_module("vl_merging_amd.vilt.modules.objectives")
+    model = build(mods, arch, f"tiny_irtr_{arch}", golden_dir, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0}, max_vl=None)
+    ib = det_batch(10, 224, 40, 1024, seed=91)
+    tb = det_batch(30, 224, 40, 1024, seed=92)
+    texts, images = [], []
+    for lo in range(0, 30, 8):  # ragged batches (8, 8, 8, 6): batching must not change the result
+        sl = slice(lo, min(30, lo + 8))
+        texts.append({"text_ids": torch.from_numpy(tb["text_ids"][sl]), "text_masks": torch.from_numpy(tb["text_masks"][sl]),
+                      "text_labels": torch.from_numpy(tb["text_labels"][sl]), "img_index": [j // 3 for j in range(sl.start, sl.stop)]})
+    for lo in range(0, 10, 4):
+        sl = slice(lo, min(10, lo + 4))
+        images.append({"image": [torch.from_numpy(ib["image"][sl])], "img_index": list(range(sl.start, sl.stop)),
+                       "text_masks": torch.from_numpy(tb["text_masks"][:1])})
+    out = obj.compute_irtr_recall(model, texts, images)
+    feats = out[6]
+    for name in ("txt_cls_feats", "img_cls_feats"):
+        err = float((feats[name].cpu() - torch.from_numpy(gold[f"{arch}/{name}"])).abs().max())
+        assert err <= 3e-2, (name, err)
+    got = np.array([float(x) for x in out[:6]])
+    want = gold[f"{arch}/recalls"]
+    step = np.array([1 / 30] * 3 + [1 / 10] * 3)
+    assert np.all(np.abs(got - want) <= step + 1e-6), (got, want)

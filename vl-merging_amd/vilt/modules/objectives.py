@@ -164,3 +164,79 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
     itm_logits = pl_module.itm_score(all_cls_feats)
     itm_loss = F.cross_entropy(itm_logits.float(), itm_labels.long())
     return {"itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
+
+
+# ---------------------------------------------------------------------------------------------------- retrieval recall
+def recall_at_k(scores, iids, tiids, ks=(1, 5, 10)):
+    """(ir_r1, ir_r5, ir_r10, tr_r1, tr_r5, tr_r10) from the image x text score matrix, objectives.py:683-710:
+    text retrieval (tr): an image is a hit at k when one of its top-k captions carries the image's id; image retrieval
+    (ir): a caption is a hit when one of its top-k images is its own.  `iids` [n_img], `tiids` [n_txt] integer ids."""
+    iids = torch.as_tensor(iids, device=scores.device)
+    tiids = torch.as_tensor(tiids, device=scores.device)
+    tr, ir = [], []
+    for k in ks:
+        top_txt = tiids[scores.topk(k, dim=1).indices]               # [n_img, k]
+        tr.append((iids.unsqueeze(1) == top_txt).float().max(dim=1)[0].mean())
+        top_img = iids[scores.topk(k, dim=0).indices]                # [k, n_txt]
+        ir.append((tiids.unsqueeze(0) == top_img).float().max(dim=0)[0].mean())
+    return tuple(ir) + tuple(tr)
+
+
+def _gather_ragged_rows(t):
+    """all_gather of per-rank feature blocks with different row counts, returned in rank order."""
+    world, rank = _world()
+    if world == 1:
+        return [t]
+    n = torch.tensor([t.shape[0]], device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s) for s in sizes]
+    pad = torch.zeros(max(sizes), t.shape[1], device=t.device, dtype=t.dtype)
+    pad[: t.shape[0]] = t
+    out = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
+@torch.no_grad()
+def compute_irtr_recall(pl_module, text_preload, image_preload):
+    """Retrieval evaluation, objectives.py:572-710, over the batch lists the reference prefetches from its datamodule
+    (`text_preload`: dicts with text_ids / text_masks / text_labels / img_index; `image_preload`: dicts with
+    image=[tensor] / img_index / text_masks).  The reference repeats both feature sweeps on every rank; here rank r
+    encodes batches r, r+W, ... and the [n, D] features are all-gathered (the sweeps are the cost, the score GEMM and
+    top-k are O(n_img * n_txt))."""
+    world, rank = _world()
+    dev = pl_module.device
+
+    def sweep(batches, encode):
+        mine = [encode(b) for b in batches[rank::world]]
+        D = pl_module.hparams.config["hidden_size"]
+        local = torch.cat(mine) if mine else torch.zeros(0, D, device=dev)
+        per_rank = _gather_ragged_rows(local.float())
+        # undo the round-robin: batch j sits in rank j % W's block, in order
+        counts = [b_count(b) for b in batches]
+        cursor = [0] * world
+        parts = []
+        for j, n in enumerate(counts):
+            r = j % world
+            parts.append(per_rank[r][cursor[r]: cursor[r] + n])
+            cursor[r] += n
+        return torch.cat(parts) if parts else local
+
+    def b_count(b):
+        return len(b["img_index"])
+
+    def enc_text(b):
+        return pl_module.infer_text_ft({"text_ids": b["text_ids"].to(dev), "text_masks": b["text_masks"].to(dev),
+                                        "text_labels": b["text_labels"].to(dev)})["cls_feats"]
+
+    def enc_image(b):
+        return pl_module.infer_image_ft({"image": [b["image"][0].to(dev)],
+                                         "text_masks": b["text_masks"].to(dev)})["cls_feats"]
+
+    txt = sweep(text_preload, enc_text)
+    img = sweep(image_preload, enc_image)
+    tiids = torch.tensor([i for b in text_preload for i in b["img_index"]], device=dev)
+    iids = torch.tensor([i for b in image_preload for i in b["img_index"]], device=dev)
+    scores = img @ txt.t()
+    return recall_at_k(scores, iids, tiids) + ({"txt_cls_feats": txt, "img_cls_feats": img, "scores": scores},)
