@@ -214,9 +214,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:  # RCCL prints a version banner on stdout in every process: only rank 0 may write there
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("VLM_BENCH_FORCE_DIST", "0") != "0"  # 1-GPU smoke test of the RCCL code path
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ge.import_package()
     cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
@@ -233,7 +238,7 @@ def main():
     model.train()
     model.setup_engine()
     (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"])
-    reducer = ddp.FlatGradReducer(model)
+    reducer = ddp.FlatGradReducer(model, force_collectives=force_dist)
     opt.grad_scale = reducer.grad_scale
     batch = synthetic_batch(args.batch, args.image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
     timer = GemmTimer(ops)
@@ -249,7 +254,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -264,7 +269,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.on = False
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,10 +317,16 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes last: whatever native libraries (RCCL's banner) left in C stdio buffers is flushed first
+        sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

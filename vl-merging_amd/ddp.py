@@ -19,7 +19,9 @@ _BLOCK = re.compile(r"transformer\.blocks\.(\d+)\.")
 
 
 class FlatGradReducer:
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, force_collectives=False):
+        """force_collectives: issue the all-reduces even at world size 1 (a single-GPU smoke test of the RCCL path)."""
+        self.force = force_collectives
         self.model = model
         self.flat = model._flat
         self.group = process_group
@@ -60,7 +62,7 @@ class FlatGradReducer:
         self.expected[layer] += 1
 
     def _launch(self, lo, hi):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         buf = self.flat.flat_g[lo:hi]
         if self.comm_stream is not None:
