@@ -146,6 +146,18 @@ int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_
                    float beta2, float eps, float weight_decay, float step_size, float grad_scale, int zero_grad,
                    void* stream);
 int vlm_cast_f32_bf16(const float* src, void* dst_bf16, uint64_t n, void* stream);
+/* Transposed bf16 weight shadows.  The backward of F.linear (dX = dY . W, modules/vision_transformer.py:291/:295/:335/
+ * :360 through autograd) reads W [N_out, K_in] along its strided axis; with W^T [K_in, N_out] kept next to W the dgrad
+ * is an ordinary K-contiguous GEMM (both operands by LDS-DMA).  One launch refreshes every listed matrix: the device
+ * table holds one entry per 64x64 tile (src [rows, cols] row-major -> dst [cols, rows] row-major). */
+typedef struct {
+  uint64_t src;      /* bf16 device pointer */
+  uint64_t dst;      /* bf16 device pointer */
+  int32_t rows, cols;
+  int32_t tile_row, tile_col;
+} vlm_transpose_tile_t;
+int vlm_transpose_bf16_tiles(const vlm_transpose_tile_t* tiles_dev, int n_tiles, void* stream);
+
 /* DropPath (timm drop_path, modules/vision_transformer.py:446 used at :586/:603): out[row] = u[b] < keep ? 1/keep : 0
  * for every token row of sample b in the segment-major layout (text rows base0 + b*n0 + t, image rows
  * base1 + b*n1 + i); u = one uniform [0,1) draw per sample.  The result is the GEMM epilogue's row_scale. */

@@ -323,3 +323,16 @@ def test_droppath_rows(ops):
     out2 = torch.empty(seq2.rows, device="cuda")
     ops.droppath_rows(u, 0.9, seq2, out2)
     assert torch.equal(out2, per.repeat_interleave(n1))
+
+
+def test_transpose_tiles(ops):
+    """Batched bf16 transpose: several matrices (one ragged) in one launch, bit-exact."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    shapes = [(768, 2304), (192, 64), (100, 70), (64, 64)]
+    srcs = [bf(torch.randn(r, c, device="cuda", generator=gen)) for r, c in shapes]
+    dsts = [torch.full((c, r), 7.0, device="cuda", dtype=torch.bfloat16) for r, c in shapes]
+    table, n = ops.transpose_table(list(zip(srcs, dsts)))
+    assert n == 12 * 36 + 3 * 1 + 2 * 2 + 1
+    ops.transpose_tiles(table, n)
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_, s_.t().contiguous())

@@ -85,6 +85,7 @@ SIGNATURES = {
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "vlm_accumulate_f32_f64": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
+    "vlm_transpose_bf16_tiles": (c_int, [c_void_p, c_int, c_void_p]),
     "vlm_droppath_rows": (c_int, [c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlm_patch_im2col": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -169,6 +169,50 @@ extern "C" int vlm_droppath_rows(const float* u, float keep, int B, int n0, int 
   return VLM_OK;
 }
 
+// Batched bf16 transpose (weights -> K-contiguous operands of the dgrad GEMMs): one workgroup per 64x64 tile of any of
+// the listed matrices, through LDS (row stride 66 elements: the column gather walks 33 banks).  Ragged edges guarded.
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(const vlm_transpose_tile_t* __restrict__ tiles, int n_tiles) {
+  __shared__ bf16_t tile[64][66];
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const vlm_transpose_tile_t j = tiles[t];
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(j.src);
+    bf16_t* dst = reinterpret_cast<bf16_t*>(j.dst);
+    const int r0 = j.tile_row * 64, c0 = j.tile_col * 64;
+    const int lr = threadIdx.x >> 2, lc = (threadIdx.x & 3) * 16;
+    {
+      const int r = r0 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = c0 + lc + e;
+        tile[lr][lc + e] = (r < j.rows && c < j.cols) ? src[(size_t)r * j.cols + c] : (bf16_t)0.0f;
+      }
+    }
+    __syncthreads();
+    {
+      const int c = c0 + lr;  // output row = source column
+      if (c < j.cols) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = r0 + lc + e;
+          if (r < j.rows) dst[(size_t)c * j.rows + r] = tile[lc + e][lr];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int vlm_transpose_bf16_tiles(const vlm_transpose_tile_t* tiles_dev, int n_tiles, void* stream) {
+  if (n_tiles == 0) return VLM_OK;
+  if (!tiles_dev || n_tiles < 0) return VLM_ERR_ARG;
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  const int grid = n_tiles < cus * 16 ? n_tiles : cus * 16;
+  hipLaunchKernelGGL(transpose_tiles_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tiles_dev, n_tiles);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
 extern "C" int vlm_patch_im2col(const float* image, void* patches, int B, int H, int W, int P, int lead_rows,
                                 void* stream) {
   if (B == 0) return VLM_OK;

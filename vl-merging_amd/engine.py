@@ -71,7 +71,27 @@ class FlatParams:
         if self.flat_b is None:
             raise L.VlmError("the bf16 shadow lives on the GPU; move the model to cuda before flattening")
         ops.cast_bf16(self.flat_p[:self.numel], self.flat_b[:self.numel])
+        self.refresh_transposed()
         self.dirty = False
+
+    def enable_transposed(self, predicate):
+        """Keep W^T (bf16, [in, out] row-major) next to the bf16 shadow of every 2-D parameter `predicate(name)` selects:
+        the backward dX = dY . W then reads both GEMM operands K-contiguously (LDS-DMA) instead of staging the strided
+        W through registers.  +2 B per selected weight; refreshed by ONE batched launch after each optimizer step."""
+        if self.flat_b is None:
+            return
+        self.flat_bt = torch.zeros_like(self.flat_b)
+        pairs = []
+        for n, p in zip(self.names, self.params):
+            if p.dim() == 2 and predicate(n):
+                o, k = self.offsets[n]
+                p._vlm_bf16_t = self.flat_bt[o:o + k].view(p.shape[1], p.shape[0])
+                pairs.append((p._vlm_bf16, p._vlm_bf16_t))
+        self._tr_table, self._tr_tiles = ops.transpose_table(pairs) if pairs else (None, 0)
+
+    def refresh_transposed(self):
+        if getattr(self, "_tr_tiles", 0):
+            ops.transpose_tiles(self._tr_table, self._tr_tiles)
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -134,6 +154,19 @@ class _Side:
         if self.ctx is not None:
             self.ctx.__exit__(*a)
         return False
+
+
+def wT16(p):
+    """Transposed bf16 shadow [in, out] of a weight, or None when the model keeps none for it."""
+    return getattr(p, "_vlm_bf16_t", None)
+
+
+def _dgrad(dy, w, dx, **epi):
+    """dx = dy . W (+ epilogue): through W^T as a K-contiguous GEMM when the transposed shadow exists."""
+    wt = wT16(w)
+    if wt is not None:
+        return ops.gemm(dy, wt, dx, **epi)
+    return ops.gemm(dy, w16(w), dx, tb=True, **epi)
 
 
 def w16(p):
@@ -379,14 +412,13 @@ class _BlockFn(torch.autograd.Function):
             rr = slice(r0, r1)
             ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad)
             # fc1 bias gradient = column sums of dh, taken in the epilogue that produces dh (no second pass over it)
-            ops.gemm(dy2[rr], w16(e.fc2w), dh[rr], tb=True, act=L.ACT_GELU_BWD, aux=h[rr],
-                     col_sum=e.fc1b.grad if _FUSE_FC1_BIAS else None)
+            _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_GELU_BWD, aux=h[rr], col_sum=e.fc1b.grad if _FUSE_FC1_BIAS else None)
             if not _FUSE_FC1_BIAS:
                 ops.colsum(dh[rr], e.fc1b.grad)
             with _Side(dy2, a, dh, ln2):
                 ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
                 ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
-            ops.gemm(dh[rr], w16(e.fc1w), dln[rr], tb=True)
+            _dgrad(dh[rr], e.fc1w, dln[rr])
             ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
                               dbeta=e.n2b.grad)
         # ---- attention branch ----
@@ -394,7 +426,7 @@ class _BlockFn(torch.autograd.Function):
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
             ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad)
-            ops.gemm(dy1[rr], w16(e.projw), do[rr], tb=True)
+            _dgrad(dy1[rr], e.projw, do[rr])
             with _Side(dy1, o):
                 ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
@@ -416,7 +448,7 @@ class _BlockFn(torch.autograd.Function):
                 ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
             with _Side(dqkv, ln1):
                 ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
-            ops.gemm(dqkv[rr], w16(e.qkvw), dln1[rr], tb=True)
+            _dgrad(dqkv[rr], e.qkvw, dln1[rr])
             ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad)
         if ctx.hook is not None:
             ctx.hook(plan.layer)

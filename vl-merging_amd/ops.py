@@ -132,6 +132,30 @@ def cast_bf16(src, dst):
     return dst
 
 
+def transpose_table(pairs):
+    """Device tile table for transpose_tiles: pairs = [(src bf16 [rows, cols] contiguous, dst bf16 [cols, rows]), ...]."""
+    import numpy as np
+    recs = []
+    for src, dst in pairs:
+        L.require_cuda(src, dst)
+        if src.dtype != BF16 or dst.dtype != BF16 or not src.is_contiguous() or not dst.is_contiguous() \
+                or src.dim() != 2 or tuple(dst.shape) != (src.shape[1], src.shape[0]):
+            raise L.VlmError("transpose_table: contiguous bf16 [rows, cols] -> [cols, rows] pairs")
+        rows, cols = src.shape
+        for tr in range((rows + 63) // 64):
+            for tc in range((cols + 63) // 64):
+                recs.append((src.data_ptr(), dst.data_ptr(), rows | (cols << 32), tr | (tc << 32)))
+    arr = np.array(recs, dtype=np.uint64).reshape(-1, 4)
+    dev = pairs[0][0].device if pairs else "cuda"
+    return torch.from_numpy(arr.view(np.int64)).to(dev), len(recs)
+
+
+def transpose_tiles(table, n_tiles):
+    """Refresh every transposed bf16 shadow listed in `table` (one launch), include/vlm_hip.h."""
+    if n_tiles:
+        L.check(L.get_lib().vlm_transpose_bf16_tiles(L.ptr(table), n_tiles, L.stream_ptr()), "vlm_transpose_bf16_tiles")
+
+
 def droppath_rows(u, keep, seq, out):
     """out[row] = bernoulli(keep)/keep of the row's sample (u: one uniform draw per sample), include/vlm_hip.h."""
     L.require_cuda(u, out)

@@ -8,6 +8,8 @@ import math
 import types
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -209,6 +211,8 @@ class ViLTransformerSS(nn.Module):
             raise L.VlmError("ViLTransformerSS runs on the GPU only: call .cuda() before setup_engine()")
         L.get_lib()
         self._flat = engine.FlatParams(self, order_key=vilt_utils.flat_order_key)
+        if os.environ.get("VLM_TRANSPOSED_SHADOWS", "1") != "0":  # A/B switch for measurements
+            self._flat.enable_transposed(lambda n: n.startswith("transformer.blocks.") and n.endswith(".weight"))
         self._flat.refresh_shadow()
         self._grad_hook = grad_hook
         return self._flat

@@ -92,6 +92,7 @@ class FusedAdamW:
                 ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], f.flat_b[lo:hi],
                                g["lr"], self.betas[0], self.betas[1], self.eps, g["weight_decay"], self.step_count,
                                grad_scale=self.grad_scale, zero_grad=True)
+        f.refresh_transposed()  # W^T shadows of the block weights (one batched launch)
         f.dirty = False  # the kernel refreshed the bf16 shadows
 
 
