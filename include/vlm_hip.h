@@ -120,16 +120,29 @@ int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, c
 int vlm_layernorm_fwd(const float* x, int ldx, int M, int D, const float* gamma, const float* beta, float eps,
                       void* y, int ldy, int y_is_f32, float* stats, void* stream);
 /* workspace (optional, f32, >= VLM_ROW_WS_BYTES(D)): per-workgroup partial column sums folded by a second tiny
- * launch; without it the column sums fall back to (heavily contended) float atomics. */
+ * launch; without it the column sums fall back to (heavily contended) float atomics.
+ * deferred_blocks (optional, host int*): when non-NULL the fold is NOT launched; the call stores the number of partial
+ * rows it wrote to `workspace` and the caller folds several such workspaces later with ONE vlm_colreduce_batch
+ * (a transformer block's backward has four row kernels: three launches saved per block evaluation). */
 #define VLM_ROW_WS_BYTES(D) ((size_t)1536 * 2 * (size_t)(D) * sizeof(float))
 int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx, const float* stats,
                       const float* gamma, int M, int D, const float* dres, int lddres, float* dx, int lddx,
-                      float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes, void* stream);
+                      float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes, int* deferred_blocks,
+                      void* stream);
+#define VLM_MAX_FOLD_JOBS 8
+typedef struct {
+  const float* partials; /* workspace written by a deferred row kernel: [nblocks][2][D] */
+  int32_t nblocks;
+  int32_t D;
+  float* out0;           /* += sum_b partials[b][0][:]  (dgamma) or NULL */
+  float* out1;           /* += sum_b partials[b][1][:]  (dbeta / dbias) or NULL */
+} vlm_fold_job_t;
+int vlm_colreduce_batch(const vlm_fold_job_t* jobs_host, int n_jobs, void* stream);
 /* Backward of x_new = x + row_scale[m]*gamma[n]*y[m,n] (vision_transformer.py:586,:603) w.r.t. the branch:
  *   dy = bf16(row_scale*gamma*dx); dgamma[n] += sum_m row_scale*dx*y; dbias[n] += sum_m dy. */
 int vlm_layerscale_bwd(const float* dx, int lddx, const void* y_bf16, int ldy, const float* gamma,
                        const float* row_scale, int M, int D, void* dy_bf16, int lddy, float* dgamma, float* dbias,
-                       float* workspace, size_t workspace_bytes, void* stream);
+                       float* workspace, size_t workspace_bytes, int* deferred_blocks, void* stream);
 /* out[n] += sum_m a[m,n] (bf16 a; N % 8 == 0): bias gradients of qkv / fc1 / heads. */
 int vlm_colsum_bf16(const void* a, int lda, int M, int N, float* out, void* stream);
 

@@ -336,3 +336,32 @@ def test_transpose_tiles(ops):
     ops.transpose_tiles(table, n)
     for s_, d_ in zip(srcs, dsts):
         assert torch.equal(d_, s_.t().contiguous())
+
+
+def test_deferred_fold_batch(ops):
+    """Row kernels with a deferred fold + ONE vlm_colreduce_batch == the same kernels folding on their own."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(13)
+    M, D = 3000, 768
+    xs = torch.randn(M, D, device="cuda", generator=gen)
+    dy = bf(torch.randn(M, D, device="cuda", generator=gen))
+    gamma = torch.randn(D, device="cuda", generator=gen)
+    stats = torch.empty(M, 2, device="cuda")
+    y = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_fwd(xs, gamma, torch.zeros(D, device="cuda"), 1e-6, y, stats)
+    dxs = torch.randn(M, D, device="cuda", generator=gen)
+    ybr = bf(torch.randn(M, D, device="cuda", generator=gen))
+    outs = []
+    for use_fold in (False, True):
+        fold = ops.FoldBatch(xs.device, D) if use_fold else None
+        dg, db = torch.full((D,), 2.0, device="cuda"), torch.zeros(D, device="cuda")
+        dg2, dbias = torch.zeros(D, device="cuda"), torch.full((D,), -1.0, device="cuda")
+        dx = torch.empty(M, D, device="cuda")
+        dyo = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        ops.layernorm_bwd(dy, xs, stats, gamma, dx, dgamma=dg, dbeta=db, fold=fold)
+        ops.layerscale_bwd(dxs, ybr, gamma, None, dyo, dg2, dbias, fold=fold)
+        if use_fold:
+            assert float(db.abs().max()) == 0.0  # nothing folded yet
+            fold.flush()
+        outs.append((dg, db, dg2, dbias, dx, dyo))
+    for a, b in zip(*outs):
+        assert_close(a, b, 1e-4, 1e-3 * float(b.float().abs().max()) + 1e-6, "deferred fold")

@@ -36,6 +36,11 @@ class Epilogue(ctypes.Structure):
     ]
 
 
+class FoldJob(ctypes.Structure):
+    _fields_ = [("partials", c_void_p), ("nblocks", ctypes.c_int32), ("D", ctypes.c_int32), ("out0", c_void_p),
+                ("out1", c_void_p)]
+
+
 class AttnColsum(ctypes.Structure):
     _fields_ = [("dq", c_void_p * 2), ("dv", c_void_p * 2)]
 
@@ -77,9 +82,11 @@ SIGNATURES = {
     "vlm_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p]),
     "vlm_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
-                                  c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  ctypes.POINTER(c_int), c_void_p]),
     "vlm_layerscale_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "vlm_colreduce_batch": (c_int, [ctypes.POINTER(FoldJob), c_int, c_void_p]),
     "vlm_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_float, c_float, c_float,
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),

@@ -290,6 +290,7 @@ class GramCapture:
 
 
 # A/B switch for measurements: 0 = separate colsum launches, 1 = all fused, 2 = attention (q/v bias) fused only
+_DEFER_FOLD = os.environ.get("VLM_DEFER_FOLD", "1") != "0"
 _FUSE_MODE = int(os.environ.get("VLM_FUSE_BIAS_GRADS", "2"))
 _FUSE_BIAS_GRADS = _FUSE_MODE != 0
 _FUSE_FC1_BIAS = _FUSE_MODE == 1
@@ -407,10 +408,13 @@ class _BlockFn(torch.autograd.Function):
         dh = torch.empty(M, Fdim, device=dev, dtype=BF16)
         dln = torch.empty(M, D, device=dev, dtype=BF16)
         dx1 = torch.empty(M, D, device=dev, dtype=F32)
+        # column partials (dgamma / dbeta / dbias) of the block's four row kernels are folded by ONE launch at the end
+        fold = ops.FoldBatch(dev, D) if _DEFER_FOLD else None
         # ---- FFN branch ----
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
-            ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad)
+            ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad,
+                               fold=fold)
             # fc1 bias gradient = column sums of dh, taken in the epilogue that produces dh (no second pass over it)
             _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_GELU_BWD, aux=h[rr], col_sum=e.fc1b.grad if _FUSE_FC1_BIAS else None)
             if not _FUSE_FC1_BIAS:
@@ -420,12 +424,13 @@ class _BlockFn(torch.autograd.Function):
                 ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
             _dgrad(dh[rr], e.fc1w, dln[rr])
             ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
-                              dbeta=e.n2b.grad)
+                              dbeta=e.n2b.grad, fold=fold)
         # ---- attention branch ----
         do = torch.empty(M, D, device=dev, dtype=BF16)
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)
-            ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad)
+            ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad,
+                               fold=fold)
             _dgrad(dy1[rr], e.projw, do[rr])
             with _Side(dy1, o):
                 ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
@@ -449,7 +454,10 @@ class _BlockFn(torch.autograd.Function):
             with _Side(dqkv, ln1):
                 ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
             _dgrad(dqkv[rr], e.qkvw, dln1[rr])
-            ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad)
+            ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad,
+                              fold=fold)
+        if fold is not None:
+            fold.flush()
         if ctx.hook is not None:
             ctx.hook(plan.layer)
         dbias = None

@@ -84,26 +84,69 @@ def _row_workspace(device, D):
     return ws
 
 
-def layernorm_bwd(dy, x, stats, gamma, dx, dres=None, dgamma=None, dbeta=None):
+class FoldBatch:
+    """Deferred column-sum folds of several row kernels (vlm_colreduce_batch): each deferred call writes its
+    per-workgroup partials to its own region of one scratch tensor; flush() folds them all in ONE launch."""
+
+    MAX = 8
+
+    def __init__(self, device, D=1024):
+        self.region = 1536 * 2 * max(D, 1024)
+        key = ("fold", device.index, torch.cuda.current_stream().cuda_stream)
+        ws = _ROW_WS.get(key)
+        if ws is None or ws.numel() < self.MAX * self.region:
+            ws = _ROW_WS[key] = torch.empty(self.MAX * self.region, device=device, dtype=F32)
+        self.ws = ws
+        self.jobs = []
+
+    def next_region(self):
+        if len(self.jobs) >= self.MAX:
+            self.flush()
+        i = len(self.jobs)
+        return self.ws[i * self.region:(i + 1) * self.region]
+
+    def add(self, region, nblocks, D, out0, out1):
+        if nblocks > 0:
+            self.jobs.append((region, nblocks, D, out0, out1))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        arr = (L.FoldJob * len(self.jobs))()
+        for a, (region, nblocks, D, out0, out1) in zip(arr, self.jobs):
+            a.partials, a.nblocks, a.D = region.data_ptr(), nblocks, D
+            a.out0 = out0.data_ptr() if out0 is not None else None
+            a.out1 = out1.data_ptr() if out1 is not None else None
+        L.check(L.get_lib().vlm_colreduce_batch(arr, len(self.jobs), L.stream_ptr()), "vlm_colreduce_batch")
+        self.jobs = []
+
+
+def layernorm_bwd(dy, x, stats, gamma, dx, dres=None, dgamma=None, dbeta=None, fold=None):
     L.require_cuda(dy, x, stats, gamma, dx, dres, dgamma, dbeta)
     M, D = x.shape
-    ws = _row_workspace(x.device, D)
+    ws = fold.next_region() if fold is not None else _row_workspace(x.device, D)
+    nb = ctypes.c_int(0)
     rc = L.get_lib().vlm_layernorm_bwd(L.ptr(dy), _ld(dy), int(dy.dtype == F32), L.ptr(x), _ld(x), L.ptr(stats),
                                        L.ptr(gamma), M, D, L.ptr(dres), _ld(dres) if dres is not None else 0,
                                        L.ptr(dx), _ld(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel() * 4,
-                                       L.stream_ptr())
+                                       ctypes.byref(nb) if fold is not None else None, L.stream_ptr())
     L.check(rc, "vlm_layernorm_bwd")
+    if fold is not None:
+        fold.add(ws, nb.value, D, dgamma, dbeta)
     return dx
 
 
-def layerscale_bwd(dx, y, gamma, row_scale, dy, dgamma=None, dbias=None):
+def layerscale_bwd(dx, y, gamma, row_scale, dy, dgamma=None, dbias=None, fold=None):
     L.require_cuda(dx, y, gamma, row_scale, dy, dgamma, dbias)
     M, D = dx.shape
-    ws = _row_workspace(dx.device, D)
+    ws = fold.next_region() if fold is not None else _row_workspace(dx.device, D)
+    nb = ctypes.c_int(0)
     rc = L.get_lib().vlm_layerscale_bwd(L.ptr(dx), _ld(dx), L.ptr(y), _ld(y), L.ptr(gamma), L.ptr(row_scale), M, D,
                                         L.ptr(dy), _ld(dy), L.ptr(dgamma), L.ptr(dbias), L.ptr(ws), ws.numel() * 4,
-                                        L.stream_ptr())
+                                        ctypes.byref(nb) if fold is not None else None, L.stream_ptr())
     L.check(rc, "vlm_layerscale_bwd")
+    if fold is not None:
+        fold.add(ws, nb.value, D, dgamma, dbias)
     return dy
 
 
