@@ -225,7 +225,18 @@ typedef struct {
   int32_t B, n0, n1, base0, base1, pos1;
   float scale;
   int32_t reserved;
+  /* Optional dense bias (vlm_bias_dense): fp16 [n_cols, index_rows, ld_index] = log2(e) * bias_t[c][rel_index[q][k]/4]
+   * and the same for the transposed index.  When set, the forward / dQ / dK-dV kernels read the (layer, head) slice
+   * [head_row0 + h] directly (same 8-byte loads as the index tiles, no LDS gather: the bias is identical for every
+   * sample of the batch, so 9 MB per layer stay cache-resident); the bias-table gradient still uses the index. */
+  const void* bias_dense;
+  const void* bias_dense_t;
 } vlm_attn_desc_t;
+
+/* Dense relative-position bias for all heads and layers at once (the reference's get_rel_pos_bias,
+ * modules/vilt_module.py:1061-1064, in fp16 and pre-multiplied by log2 e): out[c][r][k] for c < n_cols. */
+int vlm_bias_dense(const float* bias_t, int n_cols, int R, const int16_t* index, int ld_index, int index_rows,
+                   void* out_f16, void* stream);
 
 int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out_bf16, int ld_out, float* lse, void* stream);
 /* Optional fused bias gradients: dq[s] / dv[s] (f32 [H*64], may be NULL) are ACCUMULATED with the column sums of dQ /

@@ -179,3 +179,39 @@ def test_attention_bwd(ops, L, ci, sep, with_bias):
         tol = 2e-2 * float(b.abs().max()) + 2e-2 * b.abs()
         assert bool((err <= tol).all()), "dbias max err %.4g (ref max %.4g)" % (float(err.max()), float(b.abs().max()))
         assert float(dbias_t[:H].abs().max()) == 0.0  # other layer's rows untouched
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+@pytest.mark.parametrize("sep", [False, True])
+def test_attention_dense_bias_matches_gather(ops, L, ci, sep):
+    """Dense fp16 bias mode (vlm_bias_dense + BIAS == 2 kernels) against the LDS-gather mode on the same inputs: same
+    scores up to the fp16 rounding of the bias (2^-11 relative), i.e. well inside the bf16 tolerance of the outputs;
+    and the dense matrix itself against table[index] * log2(e)."""
+    c = build_case(seed=300 + ci * 10 + sep, with_bias=True, **CASES[ci])
+    seq = ops.Seq(c["B"], c["n0"], c["n1"])
+    rows, H, D = seq.rows, c["H"], c["D"]
+    layer = 1
+    bias_t = c["table"].t().contiguous()
+    idx, idx_t = (c["idx"] * 4).contiguous(), make_idx_t(c).contiguous()
+    dense = (ops.bias_dense(bias_t, idx), ops.bias_dense(bias_t, idx_t))
+    want = bias_t[:, (idx.long() >> 2).clamp_(0, bias_t.shape[1] - 1)] * 1.4426950408889634
+    assert torch.allclose(dense[0].float(), want, rtol=1e-3, atol=1e-4)
+    mode = L.ATTN_SEPARATE if sep else L.ATTN_JOINT
+    g = torch.Generator(device="cuda"); g.manual_seed(11 + ci)
+    dout = torch.randn(rows, D, device="cuda", generator=g).to(torch.bfloat16)
+    res = []
+    for bd in (None, dense):
+        kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=idx, rel_index_t=idx_t, keep0=c["keep0"], mode=mode,
+                  bias_dense=bd)
+        out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(H, rows, device="cuda")
+        ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
+        dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
+        dbias_t = torch.zeros_like(bias_t)
+        ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
+        res.append((out.float(), lse, dqkv.float(), dbias_t))
+    (o0, l0, d0, b0), (o1, l1, d1, b1) = res
+    assert float((o0 - o1).abs().max()) <= 2e-2 * float(o0.abs().max()) + 1e-3
+    assert torch.allclose(l0, l1, rtol=1e-3, atol=5e-3)
+    assert float((d0 - d1).abs().max()) <= 2e-2 * float(d0.abs().max()) + 1e-3
+    assert float((b0 - b1).abs().max()) <= 2e-2 * float(b0.abs().max()) + 1e-3

@@ -47,14 +47,15 @@ def main():
         for mode, mname in ((L.ATTN_JOINT, "joint"), (L.ATTN_SEPARATE, "sep")):
             if n0 == 0 and mode == L.ATTN_SEPARATE:
                 continue
-            for wb in (True, False):
+            dense = (ops.bias_dense(bias_t, m), ops.bias_dense(bias_t, mt))
+            for wb in (True, "dense", False):
                 kw = dict(bias_t=bias_t if wb else None, head_row0=12, rel_index=m if wb else None,
-                          rel_index_t=mt if wb else None, mode=mode)
+                          rel_index_t=mt if wb else None, mode=mode, bias_dense=dense if wb == "dense" else None)
                 f = timeit(lambda: ops.attention_fwd(qkv, out, lse, seq, H, **kw))
                 b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, dqkv, seq, H,
                                                      dbias_t=dbias if wb else None, delta_ws=delta, **kw))
                 fl = flops if mode == L.ATTN_JOINT else 4.0 * B * H * 64 * (n0 * n0 + n1 * n1)
-                print("%s/%s bias=%d: fwd %.1f us (%.0f TF)  bwd %.1f us (%.0f TF of 2.5x fwd flops)" %
+                print("%s/%s bias=%s: fwd %.1f us (%.0f TF)  bwd %.1f us (%.0f TF of 2.5x fwd flops)" %
                       (name, mname, wb, f, fl / f / 1e6, b, 2.5 * fl / b / 1e6))
 
 

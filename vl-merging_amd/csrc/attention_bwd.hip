@@ -48,8 +48,9 @@ struct attn_bwd_params_t {
 };
 
 // ----------------------------------------------------------------------------------------------------- dQ kernel
-template <bool HAS_BIAS>
+template <int BIAS>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_bwd_params_t bp) {
+  constexpr bool HAS_BIAS = BIAS != 0;
   const attn_params_t& p = bp.f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsK = smem;                          // [2] row image
@@ -88,12 +89,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
   }
   const float lse2 = bp.lse[(size_t)h * p.total_rows + qrow];
   const float dl = bp.delta[(size_t)h * p.total_rows + qrow];
-  if (HAS_BIAS) {
+  if (BIAS == 1) {
     const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
     for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
   }
+  const void* mat16 = BIAS == 2 ? (const void*)(p.dense + (size_t)(p.head_row0 + h) * p.idx_rows * p.ld_idx) : (const void*)p.idx;
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int16_t*>(p.idx), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
+      const_cast<void*>(mat16), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
   const uint32_t irow = (uint32_t)qpos * p.ld_idx;
   u32x2 iw[8];
   if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)kr.pos[kr.nt[0] > 0 ? 0 : 1], hh, iw);
@@ -139,13 +141,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
       for (int g4 = 0; g4 < 4; ++g4) {
         const int kl = kb * 32 + 8 * g4 + 4 * hh;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS) {
-          const u32x2 w = iw[kb * 4 + g4];
-          bv[0] = att_tab(tab, w[0] & 0xffff);
-          bv[1] = att_tab(tab, w[0] >> 16);
-          bv[2] = att_tab(tab, w[1] & 0xffff);
-          bv[3] = att_tab(tab, w[1] >> 16);
-        }
+        if (HAS_BIAS) att_bias4<BIAS>(tab, iw[kb * 4 + g4], bv);
         f32x4 mk = {0.f, 0.f, 0.f, 0.f};
         if (need_mask) mk = *reinterpret_cast<const f32x4*>(km + kl);  // wave-uniform branch
 #pragma unroll
@@ -215,8 +211,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
 }
 
 // ------------------------------------------------------------------------------------------- dK / dV / dBias kernel
-template <bool HAS_BIAS>
+template <int BIAS>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn_bwd_params_t bp) {
+  constexpr bool HAS_BIAS = BIAS != 0;
   const attn_params_t& p = bp.f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsQ = smem;                           // row image  [64 q][64 d]
@@ -257,12 +254,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
     }
   }
-  if (HAS_BIAS) {
+  if (BIAS == 1) {
     const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
     for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
   }
+  const void* mat16 = BIAS == 2 ? (const void*)(p.dense_t + (size_t)(p.head_row0 + h) * p.idx_t_rows * p.ld_idx_t) : (const void*)p.idx_t;
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int16_t*>(p.idx_t), 0, HAS_BIAS ? p.idx_t_rows * p.ld_idx_t * 2 : 0, 0x00020000);
+      const_cast<void*>(mat16), 0, HAS_BIAS ? p.idx_t_rows * p.ld_idx_t * 2 : 0, 0x00020000);
   const uint32_t irow = (uint32_t)kpos * p.ld_idx_t;
   u32x2 iw[8];
   if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)qr.pos[qr.nt[0] > 0 ? 0 : 1], hh, iw);
@@ -322,13 +320,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       for (int g4 = 0; g4 < 4; ++g4) {
         const int ql = qb * 32 + 8 * g4 + 4 * hh;  // local query row of element 0 of this group
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS) {
-          const u32x2 w = iw[qb * 4 + g4];
-          bv[0] = att_tab(tab, w[0] & 0xffff);
-          bv[1] = att_tab(tab, w[0] >> 16);
-          bv[2] = att_tab(tab, w[1] & 0xffff);
-          bv[3] = att_tab(tab, w[1] >> 16);
-        }
+        if (HAS_BIAS) att_bias4<BIAS>(tab, iw[qb * 4 + g4], bv);
         const f32x4 ls = *reinterpret_cast<const f32x4*>(qstat + ql);
         const f32x4 dl = *reinterpret_cast<const f32x4*>(qstat + 64 + ql);
 #pragma unroll
@@ -632,14 +624,21 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   const size_t smem_db = 4 * ATT_TILE_BYTES + 2 * 4096 + 256 + Rp * 4;  // histogram aliases the K/V tiles (R*4 <= 32 KiB)
   if (smem_dq > 160 * 1024 || smem_dkv > 160 * 1024) return VLM_ERR_UNSUPPORTED;
   if (p.bias_t) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>),
+    const bool dense = p.dense && p.dense_t;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<true>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv) != hipSuccess)
       return VLM_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, smem_dq, s, bp);
+    if (dense) hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), grid, block, smem_dq, s, bp);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<1>), grid, block, smem_dq, s, bp);
     VLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, smem_dkv, s, bp);
+    if (dense) hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), grid, block, smem_dkv, s, bp);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), grid, block, smem_dkv, s, bp);
     if (dbias_t) {
       VLM_CHECK_LAUNCH();
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dbias_kernel),
@@ -649,9 +648,9 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
       hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(nt0 + nt1, p.H, ntq), block, smem_db, s, bp);
     }
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, smem_dq, s, bp);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<0>), grid, block, smem_dq, s, bp);
     VLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, block, smem_dkv, s, bp);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<0>), grid, block, smem_dkv, s, bp);
   }
   VLM_CHECK_LAUNCH();
   return VLM_OK;

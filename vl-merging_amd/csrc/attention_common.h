@@ -18,6 +18,23 @@ __device__ __forceinline__ float att_tab(const float* tab, uint32_t byte_off) {
 }
 
 typedef __attribute__((address_space(3))) s16x4 att_lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+// Bias of 4 consecutive positions from one 8-byte word pair: BIAS == 1 gathers the LDS table column through the int16
+// byte offsets, BIAS == 2 unpacks four fp16 values of the dense bias matrix (already scaled by log2 e).
+template <int BIAS>
+__device__ __forceinline__ void att_bias4(const float* tab, u32x2 w, float (&bv)[4]) {
+  if (BIAS == 2) {
+    const f16x4 hv = __builtin_bit_cast(f16x4, w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (float)hv[e];
+  } else {
+    bv[0] = att_tab(tab, w[0] & 0xffff);
+    bv[1] = att_tab(tab, w[0] >> 16);
+    bv[2] = att_tab(tab, w[1] & 0xffff);
+    bv[3] = att_tab(tab, w[1] >> 16);
+  }
+}
 
 struct attn_seq_t {
   int B, n0, n1, base0, base1, pos1;
@@ -36,6 +53,8 @@ struct attn_params_t {
   int ld_idx, idx_rows;
   const int16_t* idx_t;  // [k][q]
   int ld_idx_t, idx_t_rows;
+  const _Float16* dense;    // [n_cols][idx_rows][ld_idx] log2e * bias, or NULL
+  const _Float16* dense_t;  // [n_cols][idx_t_rows][ld_idx_t]
   const uint8_t* keep0;
   const uint8_t* keep1;
   attn_seq_t seq;
@@ -66,6 +85,9 @@ static inline int att_fill_params(const vlm_attn_desc_t* d, attn_params_t& p) {
   p.idx_t = d->rel_index_t;
   p.ld_idx_t = d->ld_index_t;
   p.idx_t_rows = d->index_t_rows;
+  p.dense = d->bias_t ? reinterpret_cast<const _Float16*>(d->bias_dense) : nullptr;
+  p.dense_t = d->bias_t ? reinterpret_cast<const _Float16*>(d->bias_dense_t) : nullptr;
+  if ((p.dense && ((uintptr_t)p.dense & 7)) || (p.dense_t && ((uintptr_t)p.dense_t & 7))) return VLM_ERR_ARG;
   p.keep0 = d->keep0;
   p.keep1 = d->keep1;
   p.seq = (attn_seq_t){d->B, d->n0, d->n1, d->base0, d->base1, d->pos1};

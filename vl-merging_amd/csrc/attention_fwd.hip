@@ -17,8 +17,9 @@
 #include "attention_common.h"
 #include <type_traits>
 
-template <bool HAS_BIAS>
+template <int BIAS>  // 0 none, 1 LDS-table gather through the int16 index, 2 dense fp16 bias
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_params_t p) {
+  constexpr bool HAS_BIAS = BIAS != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsK = smem;                                    // [2][64 keys][128 B] swizzled
   unsigned char* ldsV = smem + 2 * ATT_TILE_BYTES;               // [2][64 keys][128 B] swizzled for tr reads
@@ -53,12 +54,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_par
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
   }
-  if (HAS_BIAS) {
+  if (BIAS == 1) {
     const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
     for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
   }
+  // 16-bit matrix the per-tile 8-byte loads walk: the shared int16 index, or this head's slice of the dense fp16 bias
+  const void* mat16 = BIAS == 2 ? (const void*)(p.dense + (size_t)(p.head_row0 + h) * p.idx_rows * p.ld_idx) : (const void*)p.idx;
   const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int16_t*>(p.idx), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
+      const_cast<void*>(mat16), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
   const uint32_t irow = (uint32_t)qpos * p.ld_idx;
   u32x2 iw[8];
   if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)kr.pos[kr.nt[0] > 0 ? 0 : 1], hh, iw);
@@ -106,13 +109,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_par
         for (int g4 = 0; g4 < 4; ++g4) {
           const int kl = kb * 32 + 8 * g4 + 4 * hh;  // local key of element 0 of this group of 4
           float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (HAS_BIAS) {
-            const u32x2 w = iw[kb * 4 + g4];
-            bv[0] = att_tab(tab, w[0] & 0xffff);
-            bv[1] = att_tab(tab, w[0] >> 16);
-            bv[2] = att_tab(tab, w[1] & 0xffff);
-            bv[3] = att_tab(tab, w[1] >> 16);
-          }
+          if (HAS_BIAS) att_bias4<BIAS>(tab, iw[kb * 4 + g4], bv);
           f32x4 mk = {0.f, 0.f, 0.f, 0.f};
           if (decltype(masked)::value) mk = *reinterpret_cast<const f32x4*>(km + kl);
 #pragma unroll
@@ -213,14 +210,49 @@ extern "C" int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out, int ld_out
   if (smem > 160 * 1024) return VLM_ERR_UNSUPPORTED;
   dim3 grid(nt0 + nt1, p.H, p.seq.B), block(ATT_THREADS);
   hipStream_t s = (hipStream_t)stream;
-  if (p.bias_t) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<true>),
+  if (p.bias_t && p.dense) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return VLM_ERR_LAUNCH;
-    hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, smem, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, block, smem, s, p);
+  } else if (p.bias_t) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return VLM_ERR_LAUNCH;
+    hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, smem, s, p);
   } else {
-    hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, smem, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<0>), grid, block, smem, s, p);
   }
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------- dense bias
+__global__ __launch_bounds__(256) void bias_dense_kernel(const float* __restrict__ bias_t, int R,
+                                                         const int16_t* __restrict__ index, int ld, int rows,
+                                                         _Float16* __restrict__ out) {
+  const int r = blockIdx.x, c = blockIdx.y;
+  const float* col = bias_t + (size_t)c * R;
+  const int16_t* irow = index + (size_t)r * ld;
+  _Float16* o = out + ((size_t)c * rows + r) * ld;
+  for (int k = threadIdx.x * 4; k < ld; k += 256 * 4) {  // ld % 4 == 0
+    const s16x4 iv = *reinterpret_cast<const s16x4*>(irow + k);
+    f16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (_Float16)(col[((unsigned short)iv[e]) >> 2] * ATT_LOG2E);
+    *reinterpret_cast<f16x4*>(o + k) = v;
+  }
+}
+
+extern "C" int vlm_bias_dense(const float* bias_t, int n_cols, int R, const int16_t* index, int ld_index, int index_rows,
+                              void* out_f16, void* stream) {
+  if (n_cols == 0 || index_rows == 0) return VLM_OK;
+  if (!bias_t || !index || !out_f16 || n_cols < 0 || R <= 0 || R > 8191 || index_rows < 0 || ld_index <= 0 ||
+      (ld_index & 3) || ((uintptr_t)index & 7) || ((uintptr_t)out_f16 & 7))
+    return VLM_ERR_ARG;
+  hipLaunchKernelGGL(bias_dense_kernel, dim3(index_rows, n_cols), dim3(256), 0, (hipStream_t)stream, bias_t, R, index,
+                     ld_index, index_rows, reinterpret_cast<_Float16*>(out_f16));
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

@@ -249,7 +249,7 @@ class Seq:
         return self.B * (self.n0 + self.n1)
 
 
-def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale):
+def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale, bias_dense=None):
     L.require_cuda(qkv, bias_t, rel_index, rel_index_t, keep0, keep1)
     if qkv.dtype != BF16:
         raise L.VlmError("attention expects bf16 qkv")
@@ -283,12 +283,35 @@ def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, ke
     d.keep1 = keep1.data_ptr() if keep1 is not None else 0
     d.B, d.n0, d.n1, d.base0, d.base1, d.pos1 = seq.B, seq.n0, seq.n1, seq.base0, seq.base1, seq.pos1
     d.scale = scale
+    if bias_dense is not None and bias_t is not None:
+        dn, dt = bias_dense
+        L.require_cuda(dn, dt)
+        if dn.dtype != torch.float16 or dt.dtype != torch.float16 or rel_index is None \
+                or tuple(dn.shape[1:]) != tuple(rel_index.shape) or tuple(dt.shape[1:]) != tuple(rel_index_t.shape) \
+                or not dn.is_contiguous() or not dt.is_contiguous() or not rel_index.is_contiguous() \
+                or not rel_index_t.is_contiguous():
+            raise L.VlmError("bias_dense: (fp16 [n_cols, *rel_index.shape], fp16 [n_cols, *rel_index_t.shape]) from bias_dense()")
+        d.bias_dense, d.bias_dense_t = dn.data_ptr(), dt.data_ptr()
     return d
 
 
+def bias_dense(bias_t, index16):
+    """fp16 [n_cols, rows, ld] = log2(e) * bias_t[c][index/4]: the dense relative-position bias of every (layer, head)
+    for one int16 index matrix (include/vlm_hip.h vlm_bias_dense; the reference's get_rel_pos_bias, vilt_module.py:1061)."""
+    L.require_cuda(bias_t, index16)
+    if bias_t.dtype != F32 or not bias_t.is_contiguous() or index16.dtype != torch.int16 or not index16.is_contiguous():
+        raise L.VlmError("bias_dense: contiguous f32 bias_t [n_cols, R] and contiguous int16 index")
+    n_cols, R = bias_t.shape
+    rows, ld = index16.shape
+    out = torch.empty(n_cols, rows, ld, device=bias_t.device, dtype=torch.float16)
+    L.check(L.get_lib().vlm_bias_dense(L.ptr(bias_t), n_cols, R, L.ptr(index16), ld, rows, L.ptr(out), L.stream_ptr()),
+            "vlm_bias_dense")
+    return out
+
+
 def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None, keep0=None,
-                  keep1=None, mode=L.ATTN_JOINT, scale=0.125):
-    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale)
+                  keep1=None, mode=L.ATTN_JOINT, scale=0.125, bias_dense=None):
+    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale, bias_dense)
     L.require_cuda(out, lse)
     rc = L.get_lib().vlm_attention_fwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(lse), L.stream_ptr())
     L.check(rc, "vlm_attention_fwd")
@@ -297,11 +320,11 @@ def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=
 
 def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None,
                   keep0=None, keep1=None, mode=L.ATTN_JOINT, scale=0.125, dbias_t=None, delta_ws=None,
-                  dq_colsum=None, dv_colsum=None):
+                  dq_colsum=None, dv_colsum=None, bias_dense=None):
     """dqkv <- d(loss)/d(qkv) (bf16, same layout as qkv); dbias_t += d(loss)/d(bias_t).  dq_colsum / dv_colsum:
     optional pairs (text-segment target, image-segment target) of f32 [H*64] vectors (None entries allowed) that
     receive += column sums of dQ / dV over that segment's rows (the q_bias / v_bias gradients)."""
-    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale)
+    d = _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, keep1, mode, scale, bias_dense)
     L.require_cuda(out, dout, lse, dqkv, dbias_t, delta_ws)
     cs = None
     if dq_colsum is not None or dv_colsum is not None:
