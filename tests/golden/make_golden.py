@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
 
-Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt recall)
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt recall batch)
 Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
 expected outputs are what the reference computed); no reference source is stored.
 """
@@ -424,9 +424,53 @@ def gold_recall():
     np.savez_compressed(os.path.join(HERE, "irtr_recall_tiny.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- batch contract
+def gold_batch():
+    """The reference's BaseDataset (index mapping, get_suite, collate) over a synthetic Arrow shard written by
+    vl_merging_amd.vilt.datasets.write_synthetic_shard (seeded data, regenerated by the test), with the synthetic
+    tokenizer and transformers' DataCollatorForLanguageModeling under fixed seeds.
+    Run with PYTHONHASHSEED=1: the reference's collate() walks a Python SET of keys, so which text key reaches the MLM
+    collator first is hash-seed dependent; seed 1 gives "text" before "false_text_0" (ArrowDataset's fixed order)."""
+    import importlib
+    import random
+    import tempfile
+    import __graft_entry__ as ge
+    ge.import_package()
+    ds = importlib.import_module("vl_merging_amd.vilt.datasets")
+    import_reference()
+    from vilt.datasets.base_dataset import BaseDataset
+    from transformers import DataCollatorForLanguageModeling
+    d = tempfile.mkdtemp()
+    ds.write_synthetic_shard(os.path.join(d, "coco_caption_karpathy_train.arrow"), 6, 3, image_hw=(48, 64), seed=1)
+    ds.write_synthetic_shard(os.path.join(d, "vg.arrow"), 4, 2, image_hw=(40, 40), seed=2)
+    tok = ds.build_synthetic_tokenizer(os.path.join(d, "vocab.txt"))
+    ref = BaseDataset(d, ["square_transform"], 32, ["coco_caption_karpathy_train", "vg"], patch_size=16,
+                      num_mask_patches=0, max_mask_patches_per_block=None, min_mask_patches_per_block=0,
+                      dvae_image_size=16, text_column_name="caption", remove_duplicate=False, max_text_len=12,
+                      draw_false_image=1, draw_false_text=1)
+    ref.tokenizer = tok
+    random.seed(7)
+    items = [ref.get_suite(i) for i in (0, 4, 5, 17, 19, 25)]
+    torch.manual_seed(11)
+    batch = ref.collate(items, DataCollatorForLanguageModeling(tok, mlm=True, mlm_probability=0.4))
+    out = {"n_samples": np.array(len(ref)), "index_mapper": np.array([[i, j] for i, j in ref.index_mapper.values()]),
+           "table_names": np.array(json.dumps(ref.table_names))}
+    lists = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out["batch/" + k] = v.numpy()
+        elif isinstance(v, list) and len(v) == 1 and isinstance(v[0], torch.Tensor):
+            out["batch_img/" + k] = v[0].numpy()
+        else:
+            lists[k] = v
+    out["batch_lists"] = np.array(json.dumps(lists, sort_keys=True))
+    np.savez_compressed(os.path.join(HERE, "batch_contract.npz"), **out)
+    print("batch keys:", sorted(batch.keys()))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["index", "merge", "merge_base", "model", "irtr"]
     torch.manual_seed(0)
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
-         "irtr": gold_irtr, "ckpt": gold_ckpt, "recall": gold_recall}[w]()
+         "irtr": gold_irtr, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch}[w]()

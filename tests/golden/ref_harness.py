@@ -23,7 +23,9 @@ REF_SRC = "/root/reference/src"
 
 
 def _mod(name, **attrs):
+    import importlib.machinery
     m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)  # importlib.util.find_spec() must not choke on stubs
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m
@@ -106,12 +108,55 @@ def install_stubs():
     _mod("timm.models.registry", register_model=lambda f: f)
 
     # ---- torchvision / fairscale / torchmetrics ----------------------------------------------
+    # torchvision.transforms: the three operators the reference's `square_transform` composes
+    # (transforms/square_transform.py:12-19, transforms/utils.py:48-50), restated from torchvision's published
+    # semantics for PIL inputs: Resize = Image.resize((w, h), interpolation); ToTensor = uint8 HWC -> float32 CHW / 255;
+    # Normalize = (x - mean) / std per channel.  Everything else the transforms package imports is a named placeholder
+    # (the augmenting pipelines are never run by the fixtures).
+    import numpy as _np
+
     class Compose:
         def __init__(self, ts):
-            self.ts = ts
+            self.ts = self.transforms = list(ts)
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    class Resize:
+        def __init__(self, size, interpolation=None):
+            self.size, self.interpolation = size, interpolation
+
+        def __call__(self, img):
+            h, w = self.size
+            return img.resize((w, h), self.interpolation)
+
+    class ToTensor:
+        def __call__(self, img):
+            a = _np.asarray(img, dtype=_np.uint8)
+            return torch.from_numpy(a.transpose(2, 0, 1).copy()).to(torch.float32).div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+            self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+
+    class _Placeholder:
+        def __init__(self, *a, **k):
+            pass
 
     tv = _mod("torchvision")
-    tv.transforms = _mod("torchvision.transforms", Compose=Compose)
+    tv.transforms = _mod("torchvision.transforms", Compose=Compose, Resize=Resize, ToTensor=ToTensor,
+                         Normalize=Normalize, RandomResizedCrop=_Placeholder, RandomHorizontalFlip=_Placeholder,
+                         ColorJitter=_Placeholder, RandomCrop=_Placeholder, CenterCrop=_Placeholder)
+    _mod("torchvision.transforms.functional")
+    _mod("dall_e", load_model=lambda *a, **k: None)
+    _mod("cv2")  # transforms/randaugment.py imports it at module scope; the augmenting pipelines are never run
+    _mod("dall_e.utils", map_pixels=lambda x: x)
     _mod("fairscale")
     _mod("fairscale.nn", checkpoint_wrapper=lambda m, **k: m)
 
