@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
 
-Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt recall batch)
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt recall batch downstream)
 Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
 expected outputs are what the reference computed); no reference source is stored.
 """
@@ -468,9 +468,59 @@ def gold_batch():
     print("batch keys:", sorted(batch.keys()))
 
 
+# ----------------------------------------------------------------------------- VQA / NLVR2 heads
+def downstream_batches():
+    nb = det_batch(3, 224, 40, 1024, seed=55)
+    nb2 = det_batch(3, 224, 40, 1024, seed=56)
+    vqa = dict(nb)
+    vqa_labels = [[3, 17], [0], [5, 6, 30]]
+    vqa_scores = [[1.0, 0.3], [0.6], [0.9, 0.3, 0.3]]
+    nlvr = {k: v for k, v in nb.items() if k != "image"}
+    return nb, nb2, vqa_labels, vqa_scores, [1, 0, 1]
+
+
+def gold_downstream():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    vm, vit, obj = import_reference()
+    from vilt.modules import vilt_utils
+    nb, nb2, vqa_labels, vqa_scores, answers = downstream_batches()
+    out = {}
+    for task in ("vqa", "nlvr2"):
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_text_len=40, vocab_size=1024,
+                          vqav2_label_size=37, loss_names={task: 1}, drop_rate=0.1)
+        model, cfg = build_reference_model(cfg, "ufo")
+        meta = load_det_weights(model)
+        with open(os.path.join(HERE, f"keys_tiny_{task}_ufo.json"), "w") as f:
+            json.dump(meta, f, indent=0, sort_keys=True)
+        model.eval()
+        vilt_utils.set_task(model)
+        model.zero_grad()
+        if task == "vqa":
+            batch = to_batch(nb)
+            batch["vqa_labels"], batch["vqa_scores"] = vqa_labels, vqa_scores
+        else:
+            batch = {k: torch.from_numpy(v) for k, v in nb.items() if k != "image"}
+            batch["image_0"] = [torch.from_numpy(nb["image"])]
+            batch["image_1"] = [torch.from_numpy(nb2["image"])]
+            batch["answers"] = answers
+            batch["table_name"] = ["nlvr2_dev"] * 3
+        ret = model(batch)
+        loss = ret[task + "_loss"]
+        loss.backward()
+        out[task + "/loss"] = np.array(float(loss))
+        out[task + "/logits"] = ret[task + "_logits"].detach().numpy()
+        out[task + "/grad_summary"] = np.array(json.dumps(grads_summary(model)))
+        print(task, "loss", float(loss), tuple(ret[task + "_logits"].shape))
+    np.savez_compressed(os.path.join(HERE, "downstream_tiny_ufo.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["index", "merge", "merge_base", "model", "irtr"]
     torch.manual_seed(0)
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
-         "irtr": gold_irtr, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch}[w]()
+         "irtr": gold_irtr, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()

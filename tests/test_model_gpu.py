@@ -200,3 +200,55 @@ def test_irtr_recall_matches_reference_golden(mods, golden_dir, arch):
     want = gold[f"{arch}/recalls"]
     step = np.array([1 / 30] * 3 + [1 / 10] * 3)
     assert np.all(np.abs(got - want) <= step + 1e-6), (got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["vqa", "nlvr2"])
+def test_downstream_heads_match_reference_golden(mods, golden_dir, task):
+    """VQA (soft-target BCE over the answer vocabulary) and NLVR2 (two joint passes with image token types 1 / 2, pair
+    classifier) against the reference's loss, logits and per-parameter gradient norms on deterministic weights."""
+    cfgmod, vm = mods
+    gold = np.load(os.path.join(golden_dir, "downstream_tiny_ufo.npz"))
+    cfg = cfgmod.make_config("ufo", vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, vocab_size=1024,
+                             max_text_len=40, patch_size=16, vlffn_start_layer_index=10, image_size=224,
+                             vqav2_label_size=37, loss_names=cfgmod._loss_names({task: 1}))
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    meta = json.load(open(os.path.join(golden_dir, f"keys_tiny_{task}_ufo.json")))
+    sd = {k: torch.from_numpy(det_array(k, s)) for k, (s, dt) in meta.items()
+          if dt.startswith("float") and "index" not in k and "mask_for" not in k and not k.startswith(("train_", "val_", "dev_", "test_"))}
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert not [m for m in res.missing_keys if "index" not in m and "position_ids" not in m and "mask_for" not in m], res.missing_keys
+    model = model.cuda().eval()
+    model.setup_engine()
+    nb, nb2 = det_batch(3, 224, 40, 1024, seed=55), det_batch(3, 224, 40, 1024, seed=56)
+    if task == "vqa":
+        batch = gpu_batch(nb)
+        batch["vqa_labels"] = [[3, 17], [0], [5, 6, 30]]
+        batch["vqa_scores"] = [[1.0, 0.3], [0.6], [0.9, 0.3, 0.3]]
+    else:
+        batch = {k: torch.from_numpy(v).cuda() for k, v in nb.items() if k != "image"}
+        batch["image_0"] = [torch.from_numpy(nb["image"]).cuda()]
+        batch["image_1"] = [torch.from_numpy(nb2["image"]).cuda()]
+        batch["answers"] = [1, 0, 1]
+    mods[1].vilt_utils.set_task(model)
+    model.zero_grad()
+    ret = model(batch)
+    loss = ret[task + "_loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    want = float(gold[task + "/loss"])
+    assert abs(float(loss) - want) <= 2e-2 * max(1.0, abs(want)), (float(loss), want)
+    feat_close(ret[task + "_logits"], gold[task + "/logits"], task + " logits", tol=5e-2)
+    gs = json.loads(str(gold[task + "/grad_summary"]))
+    named = dict(model.named_parameters())
+    bad = []
+    for n, v in gs.items():
+        g = named[n].grad
+        if v is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        nrm = float(g.double().norm())
+        if not grad_norm_ok(nrm, v[0]):
+            bad.append((n, nrm, v[0]))
+    assert not bad, bad[:10]

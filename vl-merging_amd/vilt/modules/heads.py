@@ -1,6 +1,7 @@
 """Heads of the hot-path losses (reference src/vilt/modules/heads.py:8-53), GEMMs on the MFMA kernel."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import engine
 
@@ -54,3 +55,17 @@ class MLMHead(nn.Module):
 
     def forward(self, x):
         return engine.linear(self.transform(x), self.decoder.weight, self.bias)
+
+
+class MLPClassifier(nn.Sequential):
+    """Linear -> LayerNorm -> GELU -> Linear, the VQA / NLVR2 classifier of vilt_module.py:300-327.  An nn.Sequential so
+    that the parameter names (`<head>.0.weight`, `.1.weight`, `.3.weight`) are the reference's; both linears run on the
+    MFMA GEMM, the [B, hidden] GELU stays in torch."""
+
+    def __init__(self, in_features, hidden, out_features):
+        super().__init__(nn.Linear(in_features, hidden), nn.LayerNorm(hidden), nn.GELU(), nn.Linear(hidden, out_features))
+
+    def forward(self, x):
+        h = engine.linear(x, self[0].weight, self[0].bias)
+        h = engine.layer_norm(h, self[1].weight, self[1].bias, self[1].eps, out_f32=True)
+        return engine.linear(F.gelu(h), self[3].weight, self[3].bias)

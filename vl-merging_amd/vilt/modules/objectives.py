@@ -166,6 +166,33 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
     return {"itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
 
 
+# ---------------------------------------------------------------------------------------------------- VQA / NLVR2
+def compute_vqa(pl_module, batch):
+    """objectives.py:446-486: soft-target BCE over the answer vocabulary, scaled by its size (ban-vqa convention)."""
+    infer = pl_module.infer(batch, mask_text=False, mask_image=False)
+    logits = pl_module.vqa_classifier(infer["cls_feats"]).float()
+    targets = torch.zeros(len(logits), pl_module.hparams.config["vqav2_label_size"], device=logits.device)
+    rows = [i for i, labels in enumerate(batch["vqa_labels"]) for _ in labels]
+    if rows:  # one scatter instead of the reference's per-answer python loop (:458-460)
+        cols = [int(l) for labels in batch["vqa_labels"] for l in labels]
+        vals = [float(s) for scores in batch["vqa_scores"] for s in scores]
+        targets[torch.tensor(rows, device=logits.device), torch.tensor(cols, device=logits.device)] = \
+            torch.tensor(vals, device=logits.device)
+    loss = F.binary_cross_entropy_with_logits(logits, targets) * targets.shape[1]
+    return {"vqa_loss": loss, "vqa_logits": logits, "vqa_targets": targets, "vqa_labels": batch["vqa_labels"],
+            "vqa_scores": batch["vqa_scores"]}
+
+
+def compute_nlvr2(pl_module, batch):
+    """objectives.py:512-532: the sentence with each of the two images (token types 1 and 2, keys image_0 / image_1),
+    the two pooled features concatenated into the pair classifier."""
+    infer1 = pl_module.infer(batch, mask_text=False, mask_image=False, image_token_type_idx=1)
+    infer2 = pl_module.infer(batch, mask_text=False, mask_image=False, image_token_type_idx=2)
+    logits = pl_module.nlvr2_classifier(torch.cat([infer1["cls_feats"], infer2["cls_feats"]], dim=-1)).float()
+    labels = torch.as_tensor(batch["answers"], device=logits.device).long()
+    return {"nlvr2_loss": F.cross_entropy(logits, labels), "nlvr2_logits": logits, "nlvr2_labels": labels}
+
+
 # ---------------------------------------------------------------------------------------------------- retrieval recall
 def recall_at_k(scores, iids, tiids, ks=(1, 5, 10)):
     """(ir_r1, ir_r5, ir_r10, tr_r1, tr_r5, tr_r10) from the image x text score matrix, objectives.py:683-710:

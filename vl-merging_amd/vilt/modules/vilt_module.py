@@ -136,7 +136,19 @@ class ViLTransformerSS(nn.Module):
                 setattr(self, nm, heads.IFMHead(hs))
                 getattr(self, nm).apply(objectives.init_weights)
             self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
-        for k in ("mim", "image_only_mim", "vqa", "nlvr2", "img_cls"):
+        if ln_.get("vqa", 0) > 0:  # vilt_module.py:300-308
+            self.vqa_classifier = heads.MLPClassifier(hs, hs * 2, config["vqav2_label_size"])
+            self.vqa_classifier.apply(objectives.init_weights)
+        if ln_.get("nlvr2", 0) > 0:  # vilt_module.py:323-337: pair classifier + a third token-type row (second image)
+            self.nlvr2_classifier = heads.MLPClassifier(hs * 2, hs * 2, 2)
+            self.nlvr2_classifier.apply(objectives.init_weights)
+            emb_data = self.token_type_embeddings.weight.data
+            self.token_type_embeddings = nn.Embedding(3, hs)
+            self.token_type_embeddings.apply(objectives.init_weights)
+            self.token_type_embeddings.weight.data[0, :] = emb_data[0, :]
+            self.token_type_embeddings.weight.data[1, :] = emb_data[1, :]
+            self.token_type_embeddings.weight.data[2, :] = emb_data[1, :]
+        for k in ("mim", "image_only_mim", "img_cls"):
             if ln_.get(k, 0) > 0:
                 raise NotImplementedError("loss %r is outside the MI355X hot path (SURVEY.md 2.1 #3/#13)" % k)
 
@@ -479,6 +491,10 @@ class ViLTransformerSS(nn.Module):
             ret.update(objectives.compute_ifm(self, batch))
         if "irtr" in self.current_tasks:
             ret.update(objectives.compute_irtr(self, batch))
+        if "vqa" in self.current_tasks:
+            ret.update(objectives.compute_vqa(self, batch))
+        if "nlvr2" in self.current_tasks:
+            ret.update(objectives.compute_nlvr2(self, batch))
         if fuse:
             # the four joint passes of mlm + itm as one 4B-sample pass (same losses, see compute_mlm_itm_fused)
             ret.update(objectives.compute_mlm_itm_fused(self, batch, ret["ifm_i2t_logits"], ret["ifm_t2i_logits"]))
