@@ -262,6 +262,7 @@ def main():
         loss = step()
     fence()
     use_timer = rank == 0 and not args.no_gemm_timer
+    reducer.measure = True
     t0 = time.perf_counter()
     for it in range(args.steps):
         timer.on = use_timer and it % max(1, args.gemm_timer_every) == 0
@@ -269,6 +270,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.on = False
+    exposed_comm_ms = reducer.exposed_wait_ms() / max(1, args.steps)
     loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -288,6 +290,8 @@ def main():
                                    "train mode (BASELINE configs[%d])" % (args.arch, args.image_size, args.batch,
                                                                           1 if args.arch == "ufo" else 2),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss_val},
+            # time the compute stream waits for the tail of the gradient all-reduce (rank 0), per step
+            "exposed_comm_ms_per_step": exposed_comm_ms,
         }
         flop_per_sample = FLOP_PER_SAMPLE_384 if args.image_size == 384 else 657.5e9
         out["model_tflops"] = value * flop_per_sample / 1e12 / world

@@ -46,7 +46,8 @@ class FlatGradReducer:
         self.comm_stream = torch.cuda.Stream() if self.flat.flat_g.is_cuda else None
         self.counting = True
         model._grad_hook = self.on_block_backward
-        self.exposed_wait_s = 0.0
+        self.measure = False      # bench.py turns this on for the timed steps
+        self._wait_events = []
 
     @property
     def grad_scale(self):
@@ -97,7 +98,23 @@ class FlatGradReducer:
                                        % (i, n, self.expected[i]))
         for lo, hi in self.tail_slices:
             self._launch(lo, hi)
+        timed = self.comm_stream is not None and self.measure and (self.world > 1 or self.force)
+        if timed:  # how long the compute stream sits waiting for the last buckets = the exposed (non-overlapped) part
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self.handles:
             h.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
+
+    def exposed_wait_ms(self):
+        """Total milliseconds the compute stream waited for gradient all-reduces since the last call (synchronises)."""
+        if not self._wait_events:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        self._wait_events = []
+        return ms
