@@ -696,13 +696,17 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   p.splits = 1;
   p.ksteps_per_split = 0;
-  static int group_m = -1;  // 0 = by shape (measured at M = 54 296, tools/bench_gemm.py): wide outputs want tall groups
+  // 0 = by shape.  Fabric-side fetch per launch at M = 54 296 (rocprofv3 FETCH_SIZE x 2, tools/pmc_gemm.py), group height
+  // 1 / 4 / 8 / 16 / 32:  qkv fwd (operands 87 MB) 523 / 485 / 346 / 526 / 906 MB;  fc1 fwd 879 / 623 / 431 / 663 / 1277;
+  // fc2 dgrad 1462 / 626 / 460 / 676 / 1143;  fc2 fwd (N = 768, K = 3072, operands 338 MB) 534 / 620 / 851 / 1023 / 1323.
+  // Times differ by < 3 %, so the choice follows the traffic: 8 for wide outputs, row-major for N = 768.
+  static int group_m = -1;
   if (group_m < 0) {
     const char* e = getenv("VLM_GEMM_GROUP_M");
     group_m = e ? atoi(e) : 0;
     if (group_m < 0) group_m = 0;
   }
-  p.group_m = group_m ? group_m : (p.tiles_n >= 12 ? 16 : 4);
+  p.group_m = group_m ? group_m : (p.tiles_n >= 12 ? 8 : 1);
 #ifdef VLM_GEMM_STAMPS
   p.stamps = g_stamp_buffer;
 #endif
@@ -719,7 +723,7 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     if (splits > 1) {
       p.ksteps_per_split = (nk + splits - 1) / splits;
       p.splits = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
-      if (!group_m && p.tiles_n >= 12) p.group_m = 1;  // split-K: co-resident blocks already share tiles across K slices
+      if (!group_m) p.group_m = p.tiles_n >= 12 ? 1 : 4;  // split-K (timed): co-resident blocks already share tiles across K slices
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
   }
