@@ -634,6 +634,8 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 //    2088 cycles per 32-deep step (two waves of ONE workgroup on a SIMD run in lock step behind the same barrier and
 //    do not overlap each other's LDS phase) and a 17.7k-cycle store-issue-bound epilogue (~7 B/clk/CU, as
 //    MI355X_MICROARCH.md reports for store tails) that no partner workgroup hides.
+//  * 64x128 tiles (waves of 32x64) for launches with < 1536 tiles (text pass, image pass N = 768, to fill the 512
+//    workgroup slots): slower everywhere (proj fwd M = 13 574: 37 vs 32 us; 4096^3: 813 vs 1153 TFLOP/s).
 // With staging switched off (tools/stamp_gemm.py, variant _noload) this kernel's loop runs at the MFMA bound (993 of
 // 1024 cycles per K step); with staging and no MFMAs it takes as long as the full loop: what remains is the vector-memory
 // issue path (8 LDS-DMA instructions per wave and K step) overlapped only by the partner workgroup's MFMAs.
