@@ -252,3 +252,41 @@ def test_downstream_heads_match_reference_golden(mods, golden_dir, task):
         if not grad_norm_ok(nrm, v[0]):
             bad.append((n, nrm, v[0]))
     assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_unimodal_pair_pass_equals_separate_passes(mods, golden_dir, arch):
+    """infer_unimodal_pair (image-only + text-only pass as one block-diagonal pass) against infer_image + infer_text on
+    the same model and batch (eval mode): every row runs the same kernels on the same values, only the launch is shared,
+    so the features agree to bf16 rounding of the differently tiled attention (1e-2 of the feature scale)."""
+    model = build(mods, arch, f"tiny_{arch}", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})
+    batch = gpu_batch(det_batch(3, 224, 40, 1024, seed=321))
+    with torch.no_grad():
+        ri, rt = model.infer_image(batch), model.infer_text(batch)
+        pi, pt = model.infer_unimodal_pair(batch, with_vlffn=True)
+        for k in ("image_feats", "cls_feats", "cls_vlffn_feats", "raw_cls_feats"):
+            feat_close(pi[k], ri[k].float().cpu(), "pair image " + k, tol=1e-2)
+        for k in ("text_feats", "cls_feats", "cls_vlffn_feats", "raw_cls_feats"):
+            feat_close(pt[k], rt[k].float().cpu(), "pair text " + k, tol=1e-2)
+        fi, ft = model.infer_unimodal_pair(batch, with_vlffn=False)
+        assert fi["cls_vlffn_feats"] is None and ft["cls_vlffn_feats"] is None
+        feat_close(fi["cls_feats"], model.infer_image_ft(batch)["cls_feats"].float().cpu(), "pair ft image cls", tol=1e-2)
+
+
+@pytest.mark.gpu
+def test_pair_pass_droppath_draws_are_independent(mods):
+    engine = importlib.import_module("vl_merging_amd.engine")
+    ops = importlib.import_module("vl_merging_amd.ops")
+    pc = engine.PassCtx(ops.Seq(64, 3, 5), 2, None)
+    pc.independent_segments = True
+    torch.manual_seed(0)
+    rs = pc.drop_path_rows(0.5, True, torch.device("cuda"))
+    t = rs[: 64 * 3].view(64, 3)
+    i = rs[64 * 3:].view(64, 5)
+    assert bool((t == t[:, :1]).all()) and bool((i == i[:, :1]).all())       # one draw per sample and segment
+    assert set(rs.unique().tolist()) <= {0.0, 2.0}
+    assert int(((t[:, 0] > 0) != (i[:, 0] > 0)).sum()) > 8                   # ... and the two segments differ
+    pc2 = engine.PassCtx(ops.Seq(64, 3, 5), 2, None)
+    rs2 = pc2.drop_path_rows(0.5, True, torch.device("cuda"))
+    assert bool(((rs2[: 64 * 3].view(64, 3)[:, 0] > 0) == (rs2[64 * 3:].view(64, 5)[:, 0] > 0)).all())  # joint pass: shared

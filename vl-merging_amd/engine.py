@@ -239,6 +239,7 @@ class PassCtx:
         self.gram = None  # GramCapture when the Gram cache is being recorded
         self._row2sample = None
         self._dp_pool, self._dp_next = None, 0
+        self.independent_segments = False  # True: the two segments are separate passes of the reference (own DropPath draws)
 
     def row2sample(self, device):
         if self._row2sample is None:
@@ -261,7 +262,17 @@ class PassCtx:
         self._dp_next += 1
         s = self.seq
         rows = max(s.base0 + s.B * s.n0, s.base1 + s.B * s.n1)
-        return ops.droppath_rows(u, 1.0 - prob, s, torch.empty(rows, device=device, dtype=F32))
+        out = torch.empty(rows, device=device, dtype=F32)
+        if self.independent_segments and s.n0 and s.n1:
+            # two unimodal passes riding in one launch keep their own DropPath draws (one per pass in the reference)
+            if self._dp_next >= self._dp_pool.shape[0]:
+                self._dp_pool = torch.rand(64, s.B, device=device, dtype=F32)
+                self._dp_next = 0
+            u1 = self._dp_pool[self._dp_next]
+            self._dp_next += 1
+            ops.droppath_rows(u, 1.0 - prob, ops.Seq(s.B, s.n0, 0, base0=s.base0, base1=s.base1), out)
+            return ops.droppath_rows(u1, 1.0 - prob, ops.Seq(s.B, 0, s.n1, base0=s.base0, base1=s.base1), out)
+        return ops.droppath_rows(u, 1.0 - prob, s, out)
 
 
 class ExpertWeights:

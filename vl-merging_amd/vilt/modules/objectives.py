@@ -58,8 +58,11 @@ def _sym_ce(li, lt):
 
 
 def compute_ifm(pl_module, batch, aggregate=True):
-    infer_imag = pl_module.infer_image(batch, mask_image=False)
-    infer_text = pl_module.infer_text(batch, mask_text=False)
+    if getattr(pl_module, "fuse_unimodal_passes", False):
+        infer_imag, infer_text = pl_module.infer_unimodal_pair(batch, with_vlffn=True)
+    else:
+        infer_imag = pl_module.infer_image(batch, mask_image=False)
+        infer_text = pl_module.infer_text(batch, mask_text=False)
     logit_scale = pl_module.logit_scale.exp().mean()
     logit_vl_scale = pl_module.logit_vl_scale.exp().mean()
     li, lt = _contrastive(infer_imag["cls_feats"], infer_text["cls_feats"], logit_scale)
@@ -72,8 +75,11 @@ def compute_ifm(pl_module, batch, aggregate=True):
 
 
 def compute_irtr(pl_module, batch, aggregate=True):
-    infer_imag = pl_module.infer_image_ft(batch, mask_image=False)
-    infer_text = pl_module.infer_text_ft(batch, mask_text=False)
+    if getattr(pl_module, "fuse_unimodal_passes", False):
+        infer_imag, infer_text = pl_module.infer_unimodal_pair(batch, with_vlffn=False)
+    else:
+        infer_imag = pl_module.infer_image_ft(batch, mask_image=False)
+        infer_text = pl_module.infer_text_ft(batch, mask_text=False)
     logit_scale = pl_module.logit_scale.exp().mean()
     li, lt = _contrastive(infer_imag["cls_feats"], infer_text["cls_feats"], logit_scale)
     loss, gt = _sym_ce(li, lt)

@@ -191,6 +191,8 @@ class ViLTransformerSS(nn.Module):
         self.num_layers = config["num_layers"]
         self.current_tasks = []
         self.fuse_joint_passes = True  # engine option, not a reference config key
+        # engine option: image-only + text-only pass of a batch as one block-diagonal pass (infer_unimodal_pair)
+        self.fuse_unimodal_passes = os.environ.get("VLM_FUSE_UNIMODAL", "1") != "0"
         self._flat = None
         self._idx_cache = {}
         self._grad_hook = None
@@ -426,14 +428,66 @@ class ViLTransformerSS(nn.Module):
                             keep0=text_masks.to(torch.uint8).contiguous())
         l, v = self._unimodal(x, pc, 1, with_vlffn)
         D = l.shape[-1]
-        l = l.view(B, T, D)
-        cls = self._l2(self.ifm_text_proj(l[:, 0])) if getattr(self, "ifm_text_proj", None) is not None else None
-        cls_v = None
+        return self._text_result(l.view(B, T, D), v.view(B, T, D) if v is not None else None, text_labels, text_ids,
+                                 text_masks)
+
+    def infer_unimodal_pair(self, batch, with_vlffn=True, mask_text=False, mask_image=False, image_token_type_idx=1,
+                            bool_masked_pos=None):
+        """(infer_image*, infer_text*) of one batch as ONE pass: text rows and image rows share every launch, block-
+        diagonal attention (SEPARATE mode on the joint index, whose diagonal blocks ARE the unimodal indices) keeps
+        them apart.  Each row computes exactly what its own unimodal pass computes (reference :1159-1464), the 880-row
+        text pass no longer costs ~150 tiny launches per step.  Returns (image result dict, text result dict)."""
+        self._ensure_engine()
+        do_mlm = "_mlm" if mask_text else ""
+        text_ids, text_labels, text_masks = batch[f"text_ids{do_mlm}"], batch[f"text_labels{do_mlm}"], batch["text_masks"]
+        imgkey = f"image_{image_token_type_idx - 1}" if f"image_{image_token_type_idx - 1}" in batch else "image"
+        img = batch[imgkey][0]
+        B, T = text_ids.shape
+        trows = self._text_rows(text_ids, text_masks)
+        irows, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+        image_masks = image_masks.type_as(text_masks)
+        index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
+            else self.text_imag_relative_position_index
+        pc = self._pass_ctx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
+                            keep0=text_masks.to(torch.uint8).contiguous())
+        pc.independent_segments = True
+        x = torch.cat([trows, irows], 0)
+        hs = None
+        for i, blk in enumerate(self.transformer.blocks):
+            x = blk.run(x, pc, 3, self._hook())
+            if i == self.vlffn_start_layer_index - 1:
+                hs = x
+        v = None
         if with_vlffn:
-            cls_v = self._l2(self.ifm_vl_text_proj(v.view(B, T, D)[:, 0]))
+            v = hs
+            for i in range(self.vlffn_start_layer_index, self.num_layers):
+                v = self.transformer.blocks[i].run(v, pc, 4, self._hook())
+            v = self._final_norm(v)
+        x = self._final_norm(x)
+        D = x.shape[-1]
+        nt = B * T
+        text = self._text_result(x[:nt].view(B, T, D), v[:nt].view(B, T, D) if v is not None else None, text_labels,
+                                 text_ids, text_masks)
+        image = self._image_result(x[nt:].view(B, I, D), v[nt:].view(B, I, D) if v is not None else None, image_masks,
+                                   text_masks)
+        return image, text
+
+    def _text_result(self, l, v, text_labels, text_ids, text_masks):
+        cls = self._l2(self.ifm_text_proj(l[:, 0])) if getattr(self, "ifm_text_proj", None) is not None else None
+        cls_v = self._l2(self.ifm_vl_text_proj(v[:, 0])) if v is not None else None
         return {"text_feats": l, "image_feats": None, "cls_feats": cls, "cls_vlffn_feats": cls_v,
                 "raw_cls_feats": l[:, 0], "image_labels": None, "image_masks": None, "text_labels": text_labels,
                 "text_ids": text_ids, "text_masks": text_masks, "patch_index": None}
+
+    def _image_result(self, vf, v, image_masks, text_masks):
+        if getattr(self, "ifm_image_proj", None) is not None:
+            cls = self._l2(self.ifm_image_proj(vf[:, 0]))
+        else:
+            cls = self.pooler(vf)
+        cls_v = self._l2(self.ifm_vl_image_proj(v[:, 0])) if v is not None else None
+        return {"text_feats": None, "image_feats": vf, "cls_feats": cls, "cls_vlffn_feats": cls_v,
+                "raw_cls_feats": vf[:, 0], "image_labels": None, "image_masks": image_masks, "text_labels": None,
+                "text_ids": None, "text_masks": text_masks, "patch_index": None}
 
     def infer_text(self, batch, mask_text=False):  # :1159-1223
         return self._infer_text(batch, mask_text, True)
@@ -453,17 +507,7 @@ class ViLTransformerSS(nn.Module):
                             self.get_rel_pos_bias(self.relative_position_index, 0))
         vf, v = self._unimodal(x, pc, 0, with_vlffn)
         D = vf.shape[-1]
-        vf = vf.view(B, I, D)
-        if getattr(self, "ifm_image_proj", None) is not None:
-            cls = self._l2(self.ifm_image_proj(vf[:, 0]))
-        else:
-            cls = self.pooler(vf)
-        cls_v = None
-        if with_vlffn:
-            cls_v = self._l2(self.ifm_vl_image_proj(v.view(B, I, D)[:, 0]))
-        return {"text_feats": None, "image_feats": vf, "cls_feats": cls, "cls_vlffn_feats": cls_v,
-                "raw_cls_feats": vf[:, 0], "image_labels": None, "image_masks": image_masks, "text_labels": None,
-                "text_ids": None, "text_masks": text_masks, "patch_index": None}
+        return self._image_result(vf.view(B, I, D), v.view(B, I, D) if v is not None else None, image_masks, text_masks)
 
     def infer_image(self, batch, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None,
                     bool_masked_pos=None):  # :1287-1375

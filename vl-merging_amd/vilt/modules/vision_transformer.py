@@ -141,7 +141,20 @@ class Block(nn.Module):
         hi = rows1[1] if seq.n1 else rows0[1]
         any_dict = any(isinstance(m, nn.ModuleDict) for m in (self.attn, self.mlp, self.norm1, self.norm2))
         mode = L.ATTN_JOINT
-        if type_id == 0:
+        if type_id in (3, 4):
+            # The image-only and the text-only pass of one batch run as ONE pass: block-diagonal attention keeps the two
+            # modalities apart, every other op is per row, so each row sees exactly what its own unimodal pass computes
+            # (type 3: modality experts l / v, reference type_id 1 / 0; type 4: the vl expert on both, the vlffn branch).
+            mode = L.ATTN_SEPARATE
+            if type_id == 4 or not any_dict:
+                ranges = [(lo, hi, self._expert("vl" if type_id == 4 else "v"))]
+            else:
+                ranges = []
+                if seq.n0:
+                    ranges.append((rows0[0], rows0[1], self._expert("l")))
+                if seq.n1:
+                    ranges.append((rows1[0], rows1[1], self._expert("v")))
+        elif type_id == 0:
             ranges = [(lo, hi, self._expert("v"))]
         elif type_id == 1:
             ranges = [(lo, hi, self._expert("l"))]
