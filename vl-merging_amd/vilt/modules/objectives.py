@@ -87,6 +87,17 @@ def compute_irtr(pl_module, batch, aggregate=True):
             "irtr_logit_scale": logit_scale}
 
 
+def _gather_images(img):
+    """_gather_cat for the fp32 image batch (the candidates of hard-negative sampling, objectives.py:176-178): over RCCL
+    the images travel as bf16 and come back as fp32.  The patch embedding rounds its input to bf16 anyway (im2col feeds
+    the MFMA GEMM), so the negatives' features are bit-identical to gathering fp32, at half the xGMI bytes
+    (39 MB -> 19 MB per rank and step at 384^2, B = 22)."""
+    world, _ = _world()
+    if world == 1 or not img.is_cuda or img.dtype != torch.float32:
+        return _gather_cat(img)
+    return _gather_cat(img.to(torch.bfloat16)).float()
+
+
 def _gather_cat(t):
     world, rank = _world()
     if world == 1:
@@ -102,7 +113,7 @@ def _sample_hard_negatives(pl_module, batch, sim_i2t, sim_t2i):
     with torch.no_grad():
         all_text_ids = _gather_cat(batch["text_ids"])
         all_text_masks = _gather_cat(batch["text_masks"])
-        all_image = _gather_cat(batch["image"][0])
+        all_image = _gather_images(batch["image"][0])
         weights_i2t = F.softmax(sim_i2t[:bsz, :].float(), dim=1)
         weights_t2i = F.softmax(sim_t2i[:bsz, :].float(), dim=1)
         weights_i2t.fill_diagonal_(0)
@@ -150,7 +161,7 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
     with torch.no_grad():
         all_text_ids = _gather_cat(infer_pos["text_ids"])
         all_text_masks = _gather_cat(infer_pos["text_masks"])
-        all_image = _gather_cat(infer_pos["image"])
+        all_image = _gather_images(infer_pos["image"])
         weights_i2t = F.softmax(sim_i2t[:bsz, :].float(), dim=1)
         weights_t2i = F.softmax(sim_t2i[:bsz, :].float(), dim=1)
         weights_i2t.fill_diagonal_(0)
