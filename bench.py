@@ -216,13 +216,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if rank != 0:  # RCCL prints a version banner on stdout in every process: only rank 0 may write there
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    # VLM_BENCH_ONE_DEVICE=1 + VLM_DIST_BACKEND=gloo: several ranks on ONE GPU (a functional test of the multi-rank
+    # path on a single-GPU box; RCCL itself refuses two ranks per device, gloo stages CUDA tensors through the host)
+    if os.environ.get("VLM_BENCH_ONE_DEVICE", "0") != "0":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dist = os.environ.get("VLM_BENCH_FORCE_DIST", "0") != "0"  # 1-GPU smoke test of the RCCL code path
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("VLM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     ge.import_package()
     cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
     vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
