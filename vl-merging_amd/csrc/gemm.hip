@@ -580,7 +580,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+#ifdef VLM_GEMM_EXP_NOATOMIC  // diagnostic timing build only (wrong results): what the split-K atomics cost
+          if (m < p.M && n < p.N) C[(size_t)m * p.ldc + n] = acc[i][j][r] * p.epi.alpha;
+#else
           if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.epi.alpha);
+#endif
         }
       }
     return;
@@ -720,7 +724,17 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   if (gemm_splitk_enabled() && ta && tb && plain_acc && ntile < 512 && nk >= 32) {
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;
-    int splits = (3 * cus + ntile - 1) / ntile;          // ~3 workgroups per CU in flight
+    // Slices so that the launch is ONE round of the 2 x CUs resident workgroups, never a little more: measured at
+    // K = 13 574 / 54 296 (tools/bench_gemm.py): 432 workgroups 97 / 332 us, 576 (1.125 rounds) 118 / 402 us, 864 113 / 337 us
+    // -- fewer slices also mean fewer fp32 atomics (25 us of a 113-us launch at K = 13 574).
+    static int slots_override = -1;
+    if (slots_override < 0) {
+      const char* e = getenv("VLM_GEMM_SPLITK_SLOTS");
+      slots_override = e ? atoi(e) : 0;
+    }
+    const int slots = slots_override > 0 ? slots_override : 2 * cus;
+    int splits = slots / ntile;
+    if (splits < 1) splits = 1;
     if (splits > nk / 8) splits = nk / 8;                // keep >= 8 K-steps per slice
     if (splits > 1) {
       p.ksteps_per_split = (nk + splits - 1) / splits;
