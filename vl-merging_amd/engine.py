@@ -107,6 +107,9 @@ class FlatParams:
 # weight-gradient side stream: wgrad GEMMs (reduction over tokens, only 100-150 output tiles) are off the critical
 # path of backward and under-fill 256 CUs on their own; they run on a second HIP stream so the hardware co-schedules
 # them with the dgrad / attention kernels of the main stream.  The main stream re-joins at the end of backward.
+# Off by default: +1.0 % on one GPU (241 -> 243.4 samples/s), but the gradient all-reduce of a block then also waits for
+# the side stream, and two ranks time-sharing ONE GPU over gloo (the only multi-rank run available this round) fell to
+# 9 s per step with it on; not enabled until it is measured on a real multi-GPU node (VLM_WGRAD_STREAM=1).
 _WGRAD = {"stream": None, "enabled": os.environ.get("VLM_WGRAD_STREAM", "0") != "0", "pending": False}
 
 
