@@ -39,7 +39,11 @@ class FlatGradReducer:
             else:
                 late.append(n)
         self.block_slices = {i: self.flat.slice_of(ns) for i, ns in names_by_block.items()}
-        self.tail_slices = [self.flat.slice_of(ns) for ns in (late, early) if ns]
+        # heads (everything downstream of the last block in every pass) are final once the last block's last backward
+        # has run: their slice goes out with that block's, under the rest of backward; embeddings come at the very end
+        self.late_slices = [self.flat.slice_of(late)] if late else []
+        self.tail_slices = [self.flat.slice_of(early)] if early else []
+        self.last_layer = max(names_by_block) if names_by_block else None
         self.expected = {i: 0 for i in self.block_slices}
         self.seen = {i: 0 for i in self.block_slices}
         self.handles = []
@@ -82,6 +86,9 @@ class FlatGradReducer:
             return
         if self.seen[layer] == self.expected[layer]:
             self._launch(*self.block_slices[layer])
+            if layer == self.last_layer:
+                for lo, hi in self.late_slices:
+                    self._launch(lo, hi)
 
     def finish_backward(self):
         """After loss.backward(): reduce what is left, then make the compute stream wait for all buckets."""
@@ -91,6 +98,8 @@ class FlatGradReducer:
             self.counting = False
             for i in sorted(self.block_slices, reverse=True):
                 self._launch(*self.block_slices[i])
+            for lo, hi in self.late_slices:
+                self._launch(lo, hi)
         else:
             for i, n in self.seen.items():
                 if n != self.expected[i]:
