@@ -122,7 +122,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
     const float* km = kmask + cur * 64;
     int rng, k0;
     att_tile_origin(kr, t, rng, k0);
-    const int kpos0 = kr.pos[rng] + k0;
     const bool need_mask = (k0 + ATT_BK > kr.n[rng]) || (kr.keep[rng] != nullptr);
 
 #pragma unroll
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
     if (t + 1 < ntiles) stage_load(t + 1);
     int rng, q0;
     att_tile_origin(qr, t, rng, q0);
-    const int qpos0 = qr.pos[rng] + q0;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s, dp;

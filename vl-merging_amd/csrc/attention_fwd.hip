@@ -85,7 +85,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const attn_par
     const float* km = kmask + cur * 64;
     int rng, k0;
     att_tile_origin(kr, t, rng, k0);
-    const int kpos0 = kr.pos[rng] + k0;
 
     // ---- S^T = K Q^T : two 32-key chains -----------------------------------------------------------------
     f32x16 s[2];
