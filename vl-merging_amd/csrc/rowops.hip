@@ -97,7 +97,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const float* __rest
 // dx[m,:] = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; dx_out = dx (+ dres) ; column sums by
 // one atomicAdd per column per block (fp32 grads are accumulated across passes anyway).
 template <int MAXU, bool DY_BF16>
-__global__ __launch_bounds__(ROW_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
+__global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? 4 : 2) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
                                                              const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, int M, int D,
@@ -349,6 +349,7 @@ extern "C" int vlm_layernorm_fwd(const float* x, int ldx, int M, int D, const fl
   hipStream_t s = (hipStream_t)stream;
 #define LN_FWD(U, F) hipLaunchKernelGGL((ln_fwd_kernel<U, F>), grid, block, 0, s, x, ldx, M, D, gamma, beta, eps, y, ldy, stats)
   if (D <= 256) { if (y_is_f32) LN_FWD(1, true); else LN_FWD(1, false); }
+  else if (D <= 768) { if (y_is_f32) LN_FWD(3, true); else LN_FWD(3, false); }  // D = 768: no dead fourth register slot
   else { if (y_is_f32) LN_FWD(4, true); else LN_FWD(4, false); }
 #undef LN_FWD
   VLM_CHECK_LAUNCH();
@@ -365,12 +366,15 @@ extern "C" int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const 
     return VLM_ERR_ARG;
   if (D > 1024) return VLM_ERR_UNSUPPORTED;
   int g = row_grid(M);
-  if (g > 1536) g = 1536;  // measured best (1280 = exactly-resident grid was 15 % slower)
+  // one round of resident workgroups: D <= 768 runs at 4 waves/SIMD (<= 128 VGPRs) = 4 workgroups per CU
+  const int resident = (D <= 768 ? 4 : 2) * (vlm_device_cus() > 0 ? vlm_device_cus() : 256);
+  if (g > resident) g = resident;
   float* part = (workspace && workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && (dgamma || dbeta)) ? workspace : nullptr;
   dim3 grid(g), block(ROW_THREADS);
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD(U, B) hipLaunchKernelGGL((ln_bwd_kernel<U, B>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part)
   if (D <= 256) { if (dy_is_f32) LN_BWD(1, false); else LN_BWD(1, true); }
+  else if (D <= 768) { if (dy_is_f32) LN_BWD(3, false); else LN_BWD(3, true); }
   else { if (dy_is_f32) LN_BWD(4, false); else LN_BWD(4, true); }
 #undef LN_BWD
   VLM_CHECK_LAUNCH();
@@ -396,12 +400,12 @@ extern "C" int vlm_layerscale_bwd(const float* dx, int lddx, const void* y, int 
   float* part = (workspace && workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && (dgamma || dbias)) ? workspace : nullptr;
   dim3 grid(g), block(ROW_THREADS);
   hipStream_t s = (hipStream_t)stream;
-  if (D <= 256)
-    hipLaunchKernelGGL((scale_bwd_kernel<1>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M,
-                       D, (bf16_t*)dy, lddy, dgamma, dbias, part);
-  else
-    hipLaunchKernelGGL((scale_bwd_kernel<4>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M,
-                       D, (bf16_t*)dy, lddy, dgamma, dbias, part);
+#define SC_BWD(U) hipLaunchKernelGGL((scale_bwd_kernel<U>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M, \
+                                    D, (bf16_t*)dy, lddy, dgamma, dbias, part)
+  if (D <= 256) SC_BWD(1);
+  else if (D <= 768) SC_BWD(3);
+  else SC_BWD(4);
+#undef SC_BWD
   VLM_CHECK_LAUNCH();
   if (deferred_blocks) {
     if (!part && (dgamma || dbias)) return VLM_ERR_ARG;
