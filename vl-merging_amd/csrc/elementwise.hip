@@ -179,7 +179,19 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const vlm_transpos
     bf16_t* dst = reinterpret_cast<bf16_t*>(j.dst);
     const int r0 = j.tile_row * 64, c0 = j.tile_col * 64;
     const int lr = threadIdx.x >> 2, lc = (threadIdx.x & 3) * 16;
-    {
+    // whole tiles of 16-B aligned matrices move as 16-B vectors on the global side (the LDS side stays 2-B: the
+    // padded row stride of 66 elements is what makes the column walk conflict-free); ragged tiles go element-wise
+    const bool fast = r0 + 64 <= j.rows && c0 + 64 <= j.cols && (j.cols & 7) == 0 && (j.rows & 7) == 0 &&
+                      ((j.src | j.dst) & 15) == 0;
+    if (fast) {
+      const bf16x8* sp = reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + lr) * j.cols + c0 + lc);
+      const bf16x8 v0 = sp[0], v1 = sp[1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        tile[lr][lc + e] = v0[e];
+        tile[lr][lc + 8 + e] = v1[e];
+      }
+    } else {
       const int r = r0 + lr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -188,14 +200,22 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const vlm_transpos
       }
     }
     __syncthreads();
-    {
-      const int c = c0 + lr;  // output row = source column
-      if (c < j.cols) {
+    const int c = c0 + lr;  // output row = source column
+    if (fast) {
+      bf16x8 o0, o1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = r0 + lc + e;
-          if (r < j.rows) dst[(size_t)c * j.rows + r] = tile[lc + e][lr];
-        }
+      for (int e = 0; e < 8; ++e) {
+        o0[e] = tile[lc + e][lr];
+        o1[e] = tile[lc + 8 + e][lr];
+      }
+      bf16x8* dp = reinterpret_cast<bf16x8*>(dst + (size_t)c * j.rows + r0 + lc);
+      dp[0] = o0;
+      dp[1] = o1;
+    } else if (c < j.cols) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = r0 + lc + e;
+        if (r < j.rows) dst[(size_t)c * j.rows + r] = tile[lc + e][lr];
       }
     }
     __syncthreads();
