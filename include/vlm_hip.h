@@ -175,6 +175,10 @@ int vlm_transpose_bf16_tiles(const vlm_transpose_tile_t* tiles_dev, int n_tiles,
  * for every token row of sample b in the segment-major layout (text rows base0 + b*n0 + t, image rows
  * base1 + b*n1 + i); u = one uniform [0,1) draw per sample.  The result is the GEMM epilogue's row_scale. */
 int vlm_droppath_rows(const float* u, float keep, int B, int n0, int n1, int base0, int base1, float* out, void* stream);
+/* Every DropPath site of a pass at once: out[s][row] = u0[s][b] < keep[s] ? 1/keep[s] : 0 (image rows take u1[s][b] when u1
+ * is given: two unimodal passes sharing one launch keep their own draws).  out is [n_sites, rows]. */
+int vlm_droppath_sites(const float* u0, const float* u1, const float* keep, int n_sites, int B, int n0, int n1, int base0,
+                       int base1, int rows, float* out, void* stream);
 int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W, int P, int lead_rows, void* stream);
 /* Gram cache (K15, src/cache_gram_matrices.py:246-254: G += X^T X in float64 for the input X of every hooked linear):
  * the product runs on the MFMA GEMM (vlm_gemm_bf16 ta=1 tb=1 over the bf16 activations the linear consumed, fp32

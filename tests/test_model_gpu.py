@@ -290,3 +290,32 @@ def test_pair_pass_droppath_draws_are_independent(mods):
     pc2 = engine.PassCtx(ops.Seq(64, 3, 5), 2, None)
     rs2 = pc2.drop_path_rows(0.5, True, torch.device("cuda"))
     assert bool(((rs2[: 64 * 3].view(64, 3)[:, 0] > 0) == (rs2[64 * 3:].view(64, 5)[:, 0] > 0)).all())  # joint pass: shared
+
+
+@pytest.mark.gpu
+def test_planned_droppath_sites(mods):
+    """PassCtx.plan_drop_path: all sites of a pass from ONE launch; same contract as the per-site kernel (one draw per
+    sample [and segment], values in {0, 1/keep}, a zero-probability site returns None but keeps its slot)."""
+    engine = importlib.import_module("vl_merging_amd.engine")
+    ops = importlib.import_module("vl_merging_amd.ops")
+    for indep in (False, True):
+        pc = engine.PassCtx(ops.Seq(64, 3, 5), 2, None)
+        pc.independent_segments = indep
+        pc.plan_drop_path([0.0, 0.0, 0.5, 0.5, 0.2, 0.2])
+        dev = torch.device("cuda")
+        assert pc.drop_path_rows(0.0, True, dev) is None and pc.drop_path_rows(0.0, True, dev) is None
+        a, b = pc.drop_path_rows(0.5, True, dev), pc.drop_path_rows(0.5, True, dev)
+        c = pc.drop_path_rows(0.2, True, dev)
+        assert a.data_ptr() != b.data_ptr() and pc._dp_all.shape == (6, 64 * 8)
+        for r, keep in ((a, 0.5), (b, 0.5), (c, 0.8)):
+            t, i = r[: 64 * 3].view(64, 3), r[64 * 3:].view(64, 5)
+            assert bool((t == t[:, :1]).all()) and bool((i == i[:, :1]).all())
+            vals = set(round(v, 5) for v in r.unique().tolist())
+            assert vals <= {0.0, round(1.0 / keep, 5)}
+            same = bool(((t[:, 0] > 0) == (i[:, 0] > 0)).all())
+            assert same != indep or (indep and not same)
+        assert not torch.equal(a, b)  # different sites, different draws
+        assert 0.6 < float((c > 0).float().mean()) < 0.95
+        # a probability that does not match the plan falls back to the single-site kernel
+        d = pc.drop_path_rows(0.3, True, dev)
+        assert d.shape == (64 * 8,)

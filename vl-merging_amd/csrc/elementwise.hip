@@ -169,6 +169,41 @@ extern "C" int vlm_droppath_rows(const float* u, float keep, int B, int n0, int 
   return VLM_OK;
 }
 
+// All DropPath sites of a pass in ONE launch: out[site][row] from u[site][b] and keep[site] (blockIdx.y = site).
+// u1 (optional) supplies the image segment's own draws (two unimodal passes sharing a launch keep independent masks).
+__global__ __launch_bounds__(EW_THREADS) void droppath_sites_kernel(const float* __restrict__ u0, const float* __restrict__ u1,
+                                                                    const float* __restrict__ keep, int B, int n0, int n1,
+                                                                    int base0, int base1, int rows, float* __restrict__ out) {
+  const int site = blockIdx.y;
+  const float kp = keep[site], inv = 1.0f / kp;
+  const float* ua = u0 + (size_t)site * B;
+  const float* ub = (u1 ? u1 : u0) + (size_t)site * B;
+  float* o = out + (size_t)site * rows;
+  const int nt = B * n0, total = nt + B * n1;
+  for (int i = blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += gridDim.x * EW_THREADS) {
+    if (i < nt) {
+      o[base0 + i] = ua[i / n0] < kp ? inv : 0.0f;
+    } else {
+      const int j = i - nt;
+      o[base1 + j] = ub[j / n1] < kp ? inv : 0.0f;
+    }
+  }
+}
+
+extern "C" int vlm_droppath_sites(const float* u0, const float* u1, const float* keep, int n_sites, int B, int n0, int n1,
+                                  int base0, int base1, int rows, float* out, void* stream) {
+  if (n_sites <= 0 || B <= 0 || n0 + n1 <= 0) return VLM_OK;
+  if (!u0 || !keep || !out || n0 < 0 || n1 < 0 || base0 < 0 || base1 < 0 || rows < base0 + B * n0 || rows < base1 + B * n1)
+    return VLM_ERR_ARG;
+  const size_t total = (size_t)B * (n0 + n1);
+  int gx = (int)((total + EW_THREADS - 1) / EW_THREADS);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(droppath_sites_kernel, dim3(gx, n_sites), dim3(EW_THREADS), 0, (hipStream_t)stream, u0, u1, keep, B,
+                     n0, n1, base0, base1, rows, out);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
 // Batched bf16 transpose (weights -> K-contiguous operands of the dgrad GEMMs): one workgroup per 64x64 tile of any of
 // the listed matrices, through LDS (row stride 66 elements: the column gather walks 33 banks).  Ragged edges guarded.
 __global__ __launch_bounds__(256) void transpose_tiles_kernel(const vlm_transpose_tile_t* __restrict__ tiles, int n_tiles) {

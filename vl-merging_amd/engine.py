@@ -230,6 +230,9 @@ def make_relpos(table, index16, index16_t):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+_KEEPS_CACHE = {}
+
+
 class PassCtx:
     """Static description of one pass (one `infer*` call) shared by its 12(+2) block evaluations."""
 
@@ -242,6 +245,7 @@ class PassCtx:
         self.gram = None  # GramCapture when the Gram cache is being recorded
         self._row2sample = None
         self._dp_pool, self._dp_next = None, 0
+        self._dp_sites, self._dp_all, self._dp_call = None, None, 0
         self.independent_segments = False  # True: the two segments are separate passes of the reference (own DropPath draws)
 
     def row2sample(self, device):
@@ -252,25 +256,40 @@ class PassCtx:
             self._row2sample = torch.cat([a, b])
         return self._row2sample
 
+    def plan_drop_path(self, probs):
+        """Tell the pass the DropPath probabilities of its sites in call order (two per block evaluation): all row
+        scales are then produced by ONE launch (two for a unimodal pair) at the first site instead of one per site."""
+        self._dp_sites = [float(p) for p in probs]
+
     def drop_path_rows(self, prob, training, device):
-        """Per-row scale of timm's DropPath (per-sample bernoulli(keep)/keep), or None when inactive.  One uniform
-        draw per pass feeds up to 64 DropPath sites; each site is ONE launch (vlm_droppath_rows) instead of
-        bernoulli_ + div_ + index + contiguous."""
+        """Per-row scale of timm's DropPath (per-sample bernoulli(keep)/keep), or None when inactive."""
         if not training or prob <= 0.0:
+            self._dp_call += 1
             return None
-        if self._dp_pool is None or self._dp_next >= self._dp_pool.shape[0]:
-            self._dp_pool = torch.rand(64, self.seq.B, device=device, dtype=F32)
+        s = self.seq
+        rows = max(s.base0 + s.B * s.n0, s.base1 + s.B * s.n1)
+        i = self._dp_call
+        self._dp_call += 1
+        if self._dp_sites is not None and i < len(self._dp_sites) and abs(self._dp_sites[i] - prob) < 1e-12:
+            if self._dp_all is None:
+                S = len(self._dp_sites)
+                key = (tuple(self._dp_sites), str(device))
+                keeps = _KEEPS_CACHE.get(key)
+                if keeps is None:  # uploaded once per schedule: a pageable H2D copy inside a step would stall the queue
+                    keeps = _KEEPS_CACHE[key] = torch.tensor([1.0 - p if p > 0.0 else 1.0 for p in self._dp_sites],
+                                                             dtype=F32).to(device)
+                u = torch.rand(2 if (self.independent_segments and s.n0 and s.n1) else 1, S, s.B, device=device, dtype=F32)
+                self._dp_all = ops.droppath_sites(u[0], u[1] if u.shape[0] == 2 else None, keeps, s,
+                                                  torch.empty(S, rows, device=device, dtype=F32))
+            return self._dp_all[i]
+        # unplanned site: one launch (two for independent segments) from a pooled uniform draw
+        if self._dp_pool is None or self._dp_next + 2 > self._dp_pool.shape[0]:
+            self._dp_pool = torch.rand(64, s.B, device=device, dtype=F32)
             self._dp_next = 0
         u = self._dp_pool[self._dp_next]
         self._dp_next += 1
-        s = self.seq
-        rows = max(s.base0 + s.B * s.n0, s.base1 + s.B * s.n1)
         out = torch.empty(rows, device=device, dtype=F32)
         if self.independent_segments and s.n0 and s.n1:
-            # two unimodal passes riding in one launch keep their own DropPath draws (one per pass in the reference)
-            if self._dp_next >= self._dp_pool.shape[0]:
-                self._dp_pool = torch.rand(64, s.B, device=device, dtype=F32)
-                self._dp_next = 0
             u1 = self._dp_pool[self._dp_next]
             self._dp_next += 1
             ops.droppath_rows(u, 1.0 - prob, ops.Seq(s.B, s.n0, 0, base0=s.base0, base1=s.base1), out)

@@ -199,6 +199,18 @@ def transpose_tiles(table, n_tiles):
         L.check(L.get_lib().vlm_transpose_bf16_tiles(L.ptr(table), n_tiles, L.stream_ptr()), "vlm_transpose_bf16_tiles")
 
 
+def droppath_sites(u0, u1, keeps, seq, out):
+    """out[s][row] for every DropPath site s of a pass in one launch (include/vlm_hip.h vlm_droppath_sites)."""
+    L.require_cuda(u0, u1, keeps, out)
+    S = keeps.numel()
+    if u0.dtype != F32 or keeps.dtype != F32 or out.dtype != F32 or tuple(u0.shape) != (S, seq.B) or not out.is_contiguous() \
+            or out.shape[0] != S or (u1 is not None and tuple(u1.shape) != (S, seq.B)):
+        raise L.VlmError("droppath_sites: u [S, B] f32, keeps [S] f32, out [S, rows] f32")
+    L.check(L.get_lib().vlm_droppath_sites(L.ptr(u0), L.ptr(u1), L.ptr(keeps), S, seq.B, seq.n0, seq.n1, seq.base0, seq.base1,
+                                           out.shape[1], L.ptr(out), L.stream_ptr()), "vlm_droppath_sites")
+    return out
+
+
 def droppath_rows(u, keep, seq, out):
     """out[row] = bernoulli(keep)/keep of the row's sample (u: one uniform draw per sample), include/vlm_hip.h."""
     L.require_cuda(u, out)

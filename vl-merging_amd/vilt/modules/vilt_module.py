@@ -361,6 +361,15 @@ class ViLTransformerSS(nn.Module):
         pc.gram = getattr(self, "_gram", None)
         return pc
 
+    def _drop_sites(self, with_vlffn):
+        """DropPath probabilities of a pass in call order: two sites per block evaluation, the vlffn branch re-runs the
+        last layers."""
+        p = [b.drop_path_prob for b in self.transformer.blocks]
+        sites = [q for q in p for _ in (0, 1)]
+        if with_vlffn:
+            sites += [q for q in p[self.vlffn_start_layer_index:] for _ in (0, 1)]
+        return sites
+
     # ---- passes ----------------------------------------------------------------------------------------------------------
     def infer(self, batch, mask_text=False, mask_image=False, bool_masked_pos=None, image_token_type_idx=1,
               image_embeds=None, image_masks=None):
@@ -383,6 +392,7 @@ class ViLTransformerSS(nn.Module):
             else self.text_imag_relative_position_index
         pc = self._pass_ctx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
                             keep0=text_masks.to(torch.uint8).contiguous())
+        pc.plan_drop_path(self._drop_sites(False))
         for blk in self.transformer.blocks:
             x = blk.run(x, pc, 2, self._hook())
         x = self._final_norm(x)
@@ -395,6 +405,7 @@ class ViLTransformerSS(nn.Module):
                 "text_labels": text_labels, "text_ids": text_ids, "text_masks": text_masks, "patch_index": None}
 
     def _unimodal(self, x, pc, type_id, with_vlffn):
+        pc.plan_drop_path(self._drop_sites(with_vlffn))
         hs = None
         for i, blk in enumerate(self.transformer.blocks):
             x = blk.run(x, pc, type_id, self._hook())
@@ -451,6 +462,7 @@ class ViLTransformerSS(nn.Module):
         pc = self._pass_ctx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
                             keep0=text_masks.to(torch.uint8).contiguous())
         pc.independent_segments = True
+        pc.plan_drop_path(self._drop_sites(with_vlffn))
         x = torch.cat([trows, irows], 0)
         hs = None
         for i, blk in enumerate(self.transformer.blocks):
