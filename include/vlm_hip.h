@@ -103,6 +103,9 @@ typedef struct {
   int32_t accumulate;
   int32_t reserved;
   float* col_sum;          /* f32 [N] or NULL: accumulated column sums of the values written to C */
+  float* col_sum_ws;       /* optional with col_sum (N % 128 == 0): f32 [M/128][2][N]; complete 128-row tiles store their
+                              column sums at [tile][0][:] instead of adding them to col_sum -- the caller folds rows
+                              0 .. M/128-1 into col_sum with vlm_colreduce_batch; the ragged last tile still adds directly */
 } vlm_epilogue_t;
 
 int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,

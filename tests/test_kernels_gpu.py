@@ -365,3 +365,28 @@ def test_deferred_fold_batch(ops):
         outs.append((dg, db, dg2, dbias, dx, dyo))
     for a, b in zip(*outs):
         assert_close(a, b, 1e-4, 1e-3 * float(b.float().abs().max()) + 1e-6, "deferred fold")
+
+
+def test_gemm_col_sum_through_fold_workspace(ops, L):
+    """col_sum with a FoldBatch: complete 128-row tiles park their column sums in the workspace, the ragged last tile adds
+    directly, one vlm_colreduce_batch folds -- same result as the direct col_sum and as a torch column sum."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(31)
+    M, N, K = 128 * 9 + 50, 256, 128
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    B = bf(torch.randn(N, K, device="cuda", generator=gen))
+    h = bf(torch.randn(M, N, device="cuda", generator=gen))
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    direct = torch.full((N,), 1.5, device="cuda")
+    ops.gemm(A, B, out, act=L.ACT_GELU_BWD, aux=h, alpha=0.1, col_sum=direct)
+    fold = ops.FoldBatch(A.device, N)
+    viafold = torch.full((N,), 1.5, device="cuda")
+    ops.gemm(A, B, out, act=L.ACT_GELU_BWD, aux=h, alpha=0.1, col_sum=viafold, col_sum_fold=fold)
+    assert len(fold.jobs) == 1 and fold.jobs[0][1] == 9
+    part = viafold.clone()
+    fold.flush()
+    hh = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward((A.float() @ B.float().t()) * 0.1)
+    want = hh.grad.sum(0) + 1.5
+    assert_close(direct, want, 2e-3, 2e-2, "direct col_sum")
+    assert_close(viafold, want, 2e-3, 2e-2, "col_sum through the fold workspace")
+    assert float((part - 1.5).abs().max()) < float((want - 1.5).abs().max())  # before the fold: only the ragged tile's 50 rows

@@ -598,7 +598,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     gemm_epilogue<OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, lds_sum ? red : nullptr, wm * 128 + wn * 64);
     if (lds_sum) {
       __syncthreads();
-      if (tid < 128) atomicAdd(p.epi.col_sum + n0 + tid, red[tid] + red[128 + tid]);
+      if (tid < 128) {
+        const float part = red[tid] + red[128 + tid];
+        // workspace mode: plain store of this tile's column sums, folded later by vlm_colreduce_batch (no atomics: the
+        // memory-side float atomics of 425 tile rows on the same 12 KiB cost +75 us per launch); else accumulate directly
+        if (p.epi.col_sum_ws) p.epi.col_sum_ws[((size_t)tm * 2) * p.N + n0 + tid] = part;
+        else atomicAdd(p.epi.col_sum + n0 + tid, part);
+      }
     }
   }
 #ifdef VLM_GEMM_STAMPS
@@ -684,6 +690,7 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   if (((ldc & 3) == 0) && ((uintptr_t)C & 15)) return VLM_ERR_ARG;
   if (epi->accumulate && !c_is_f32) return VLM_ERR_ARG;
   if (epi->act == VLM_ACT_GELU_BWD && !epi->aux) return VLM_ERR_ARG;
+  if (epi->col_sum_ws && (!epi->col_sum || (N % GEMM_BN) != 0 || ta)) return VLM_ERR_ARG;
   const uint64_t a_bytes = (uint64_t)(ta ? K : M) * lda * 2, b_bytes = (uint64_t)(tb ? K : N) * ldb * 2;
   if (a_bytes >= (1ull << 31) || b_bytes >= (1ull << 31)) return VLM_ERR_UNSUPPORTED;
   gemm_params_t p;
@@ -697,6 +704,7 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
                     (!epi->residual || ((uintptr_t)epi->residual & 15) == 0) && (!epi->bias || ((uintptr_t)epi->bias & 15) == 0) &&
                     (!epi->col_scale || ((uintptr_t)epi->col_scale & 15) == 0);
     p.epi.reserved = v8 ? 1 : 0;
+    if (epi->col_sum_ws && !v8) return VLM_ERR_ARG;  // workspace mode exists only on the 16-B epilogue path
   }
   p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;

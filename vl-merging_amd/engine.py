@@ -330,12 +330,13 @@ class GramCapture:
         return {k: v.cpu() for k, v in self.grams.items()}
 
 
-# A/B switch for measurements: 0 = separate colsum launches, 1 = all fused, 2 = attention (q/v bias) fused only
+# A/B switch for measurements: 0 = separate colsum launches, 1/2 = q/v bias inside the attention backward and fc1 bias
+# through the GELU-backward GEMM epilogue + fold workspace
 _DEFER_FOLD = os.environ.get("VLM_DEFER_FOLD", "1") != "0"
 _DENSE_BIAS = os.environ.get("VLM_DENSE_BIAS", "1") != "0"
 _FUSE_MODE = int(os.environ.get("VLM_FUSE_BIAS_GRADS", "2"))
 _FUSE_BIAS_GRADS = _FUSE_MODE != 0
-_FUSE_FC1_BIAS = _FUSE_MODE == 1
+_FUSE_FC1_BIAS = _FUSE_MODE in (1, 2)  # through the fold workspace (mode 0: separate colsum launch)
 
 
 def _segment_bias_grads(ranges, seq):
@@ -458,8 +459,12 @@ class _BlockFn(torch.autograd.Function):
             ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad,
                                fold=fold)
             # fc1 bias gradient = column sums of dh, taken in the epilogue that produces dh (no second pass over it)
-            _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_GELU_BWD, aux=h[rr], col_sum=e.fc1b.grad if _FUSE_FC1_BIAS else None)
-            if not _FUSE_FC1_BIAS:
+            # fc1 bias gradient = column sums of dh: per-tile sums from the epilogue that produces dh, folded with the
+            # block's other column partials (no atomics, no second pass over dh); without a fold batch: colsum kernel
+            fuse_b1 = _FUSE_FC1_BIAS and fold is not None
+            _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_GELU_BWD, aux=h[rr], col_sum=e.fc1b.grad if fuse_b1 else None,
+                   col_sum_fold=fold if fuse_b1 else None)
+            if not fuse_b1:
                 ops.colsum(dh[rr], e.fc1b.grad)
             with _Side(dy2, a, dh, ln2):
                 ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)

@@ -22,7 +22,7 @@ def _ld(t):
 
 
 def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, col_scale=None, row_scale=None,
-         residual=None, alpha=1.0, accumulate=False, col_sum=None):
+         residual=None, alpha=1.0, accumulate=False, col_sum=None, col_sum_fold=None):
     """out[M,N] = epilogue(op(a)[M,K] @ op(b)[K,N]); see include/vlm_hip.h for the epilogue algebra.
 
     a: bf16 [M,K] (ta=False) or [K,M] (ta=True);  b: bf16 [N,K] (tb=False, nn.Linear layout) or [K,N] (tb=True).
@@ -49,6 +49,15 @@ def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, 
     e.alpha = alpha
     e.accumulate = 1 if accumulate else 0
     e.col_sum = col_sum.data_ptr() if col_sum is not None else 0
+    region = None
+    if col_sum is not None and col_sum_fold is not None and not ta and N % 128 == 0 and M >= 128:
+        # complete 128-row tiles park their column sums in the fold batch's scratch (plain stores), one
+        # vlm_colreduce_batch later adds them to col_sum together with the block's other column partials
+        region = col_sum_fold.next_region()
+        if region.numel() >= (M // 128) * 2 * N:
+            e.col_sum_ws = region.data_ptr()
+        else:
+            region = None
     if col_sum is not None and (col_sum.numel() < N or not col_sum.is_contiguous()):
         raise L.VlmError("gemm: col_sum must be a contiguous f32 vector of at least N elements")
     for t, dt in ((bias, F32), (col_scale, F32), (row_scale, F32), (residual, F32), (aux, BF16), (col_sum, F32)):
@@ -59,6 +68,8 @@ def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, 
     rc = L.get_lib().vlm_gemm_bf16(int(ta), int(tb), M, N, K, L.ptr(a), _ld(a), L.ptr(b), _ld(b), L.ptr(out), _ld(out),
                                    int(out.dtype == F32), ctypes.byref(e), L.stream_ptr())
     L.check(rc, "vlm_gemm_bf16")
+    if region is not None:
+        col_sum_fold.add(region, M // 128, N, col_sum, None)
     return out
 
 
