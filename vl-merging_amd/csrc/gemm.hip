@@ -646,6 +646,8 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 //    MI355X_MICROARCH.md reports for store tails) that no partner workgroup hides.
 //  * 64x128 tiles (waves of 32x64) for launches with < 1536 tiles (text pass, image pass N = 768, to fill the 512
 //    workgroup slots): slower everywhere (proj fwd M = 13 574: 37 vs 32 us; 4096^3: 813 vs 1153 TFLOP/s).
+//  * 128x128x32, three 16-KiB stages with counted vmcnt, THREE workgroups per CU (168 VGPRs): 328 vs 287 us (qkv
+//    forward), 338 vs 271 us (K = 3072): a barrier every 16 MFMAs costs more than the third workgroup hides.
 // With staging switched off (tools/stamp_gemm.py, variant _noload) this kernel's loop runs at the MFMA bound (993 of
 // 1024 cycles per K step); with staging and no MFMAs it takes as long as the full loop: what remains is the vector-memory
 // issue path (8 LDS-DMA instructions per wave and K step) overlapped only by the partner workgroup's MFMAs.
