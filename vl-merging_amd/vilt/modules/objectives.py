@@ -98,6 +98,41 @@ def _gather_images(img):
     return _gather_cat(img.to(torch.bfloat16)).float()
 
 
+class _CandidatePrefetch:
+    """The hard-negative candidates (text ids, masks, images of every rank) depend only on the input batch: their
+    all-gathers are issued asynchronously at the top of the step and consumed after the contrastive pass, so the
+    156 MB image gather (8 ranks, bf16) overlaps ~12 ms of compute instead of sitting between two passes."""
+
+    def __init__(self, batch):
+        world, rank = _world()
+        self.rank = rank
+        img = batch["image"][0]
+        self.as_bf16 = img.is_cuda and img.dtype == torch.float32
+        self.src = [batch["text_ids"].contiguous(), batch["text_masks"].contiguous(),
+                    (img.to(torch.bfloat16) if self.as_bf16 else img).contiguous()]
+        self.bufs, self.works = [], []
+        for t in self.src:
+            g = [torch.zeros_like(t) for _ in range(world)]
+            self.bufs.append(g)
+            self.works.append(dist.all_gather(g, t, async_op=True))
+
+    def result(self):
+        out = []
+        for t, g, w in zip(self.src, self.bufs, self.works):
+            w.wait()
+            out.append(torch.cat([t] + g[:self.rank] + g[self.rank + 1:]))
+        if self.as_bf16:
+            out[2] = out[2].float()
+        return out
+
+
+def prefetch_negative_candidates(batch):
+    """Start the candidate all-gathers of compute_itm_hardneg / compute_mlm_itm_fused early (no-op on one rank)."""
+    world, _ = _world()
+    if world > 1 and "_neg_candidates" not in batch:
+        batch["_neg_candidates"] = _CandidatePrefetch(batch)
+
+
 def _gather_cat(t):
     world, rank = _world()
     if world == 1:
@@ -111,9 +146,13 @@ def _sample_hard_negatives(pl_module, batch, sim_i2t, sim_t2i):
     """ONE batched multinomial per direction over the (gathered) candidates, device-side gathers (:176-229)."""
     bsz = batch["text_ids"].size(0)
     with torch.no_grad():
-        all_text_ids = _gather_cat(batch["text_ids"])
-        all_text_masks = _gather_cat(batch["text_masks"])
-        all_image = _gather_images(batch["image"][0])
+        pre = batch.pop("_neg_candidates", None)
+        if pre is not None:
+            all_text_ids, all_text_masks, all_image = pre.result()
+        else:
+            all_text_ids = _gather_cat(batch["text_ids"])
+            all_text_masks = _gather_cat(batch["text_masks"])
+            all_image = _gather_images(batch["image"][0])
         weights_i2t = F.softmax(sim_i2t[:bsz, :].float(), dim=1)
         weights_t2i = F.softmax(sim_t2i[:bsz, :].float(), dim=1)
         weights_i2t.fill_diagonal_(0)

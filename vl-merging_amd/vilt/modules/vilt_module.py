@@ -541,6 +541,8 @@ class ViLTransformerSS(nn.Module):
             else:
                 return ret
         fuse = self.fuse_joint_passes and all(t in self.current_tasks for t in ("mlm", "itm", "ifm"))
+        if fuse:
+            objectives.prefetch_negative_candidates(batch)  # multi-rank: candidate all-gathers fly under the ifm pass
         if "mlm" in self.current_tasks and not fuse:
             ret.update(objectives.compute_mlm(self, batch))
         if "ifm" in self.current_tasks:
