@@ -49,7 +49,13 @@ def _worker(rank, world, port, q):
             # backward order: block 2 is used twice per step (two passes), blocks 1, 0 once
             for layer in (2, 2, 1, 0):
                 m._grad_hook(layer)
+            red.defer_tail = step == 2  # last step: the embeddings' all-reduce stays in flight until wait_tail()
             red.finish_backward()
+            if red.defer_tail:
+                lo, hi = red.tail_range()
+                assert (lo, hi) == red.tail_slices[0] and len(red._tail_handles) == 1
+                red.wait_tail()
+                assert red._tail_handles == []
             want = sum(r + 1 + step for r in range(world))
             for n, p in m.named_parameters():
                 assert torch.all(p.grad == want), (step, n, p.grad.flatten()[:3], want)

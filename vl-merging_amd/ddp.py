@@ -51,6 +51,8 @@ class FlatGradReducer:
         self.counting = True
         model._grad_hook = self.on_block_backward
         self.measure = False      # bench.py turns this on for the timed steps
+        self.defer_tail = False   # True: finish_backward leaves the last (embeddings) all-reduce in flight, see wait_tail
+        self._tail_handles = []
         self._wait_events = []
 
     @property
@@ -105,19 +107,34 @@ class FlatGradReducer:
                 if n != self.expected[i]:
                     raise RuntimeError("block %d ran %d backward passes, expected %d: static use counts changed"
                                        % (i, n, self.expected[i]))
+        n_before_tail = len(self.handles)
         for lo, hi in self.tail_slices:
             self._launch(lo, hi)
+        self._tail_handles = self.handles[n_before_tail:] if self.defer_tail else []
+        self._wait(self.handles[:n_before_tail] if self.defer_tail else self.handles)
+
+    def _wait(self, handles):
         timed = self.comm_stream is not None and self.measure and (self.world > 1 or self.force)
-        if timed:  # how long the compute stream sits waiting for the last buckets = the exposed (non-overlapped) part
+        if timed:  # how long the compute stream sits waiting for the buckets = the exposed (non-overlapped) part
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for h in self.handles:
-            h.wait()
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for h in handles:
+            h.wait()  # the current (compute) stream waits for this collective only
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))
+
+    def tail_range(self):
+        """Flat range [lo, hi) of the slice whose all-reduce finish_backward leaves in flight (defer_tail), or None."""
+        if not self.defer_tail or not self.tail_slices:
+            return None
+        return min(lo for lo, _ in self.tail_slices), max(hi for _, hi in self.tail_slices)
+
+    def wait_tail(self):
+        """Make the compute stream wait for the embeddings' all-reduce: called by the optimizer after it has updated
+        everything else (FusedAdamW.tail_sync), so ~1 ms of AdamW runs under the last collective."""
+        self._wait(self._tail_handles)
+        self._tail_handles = []
 
     def exposed_wait_ms(self):
         """Total milliseconds the compute stream waited for gradient all-reduces since the last call (synchronises)."""

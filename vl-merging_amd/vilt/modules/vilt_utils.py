@@ -79,6 +79,7 @@ class FusedAdamW:
         self.m = torch.zeros_like(self.flat.flat_p)
         self.v = torch.zeros_like(self.flat.flat_p)
         self.grad_scale = 1.0
+        self.tail_sync = None
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -87,11 +88,30 @@ class FusedAdamW:
         self.step_count += 1
         engine.sync_wgrad()
         f = self.flat
+
+        def update(g, lo, hi):
+            ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], f.flat_b[lo:hi],
+                           g["lr"], self.betas[0], self.betas[1], self.eps, g["weight_decay"], self.step_count,
+                           grad_scale=self.grad_scale, zero_grad=True)
+
+        # tail_sync = (lo, hi, wait): the gradient all-reduce of flat range [lo, hi) may still be in flight (DDP reducer
+        # with defer_tail); everything outside it is updated first, then `wait()`, then the range itself
+        tail = self.tail_sync
+        late = []
         for g in self.param_groups:
             for lo, hi in g["ranges"]:
-                ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], f.flat_b[lo:hi],
-                               g["lr"], self.betas[0], self.betas[1], self.eps, g["weight_decay"], self.step_count,
-                               grad_scale=self.grad_scale, zero_grad=True)
+                if tail is None or hi <= tail[0] or lo >= tail[1]:
+                    update(g, lo, hi)
+                    continue
+                if lo < tail[0]:
+                    update(g, lo, tail[0])
+                if hi > tail[1]:
+                    update(g, tail[1], hi)
+                late.append((g, max(lo, tail[0]), min(hi, tail[1])))
+        if tail is not None:
+            tail[2]()
+        for g, lo, hi in late:
+            update(g, lo, hi)
         f.refresh_transposed()  # W^T shadows of the block weights (one batched launch)
         f.dirty = False  # the kernel refreshed the bf16 shadows
 
