@@ -247,12 +247,8 @@ def main():
     model.setup_engine()
     (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"])
     reducer = ddp.FlatGradReducer(model, force_collectives=force_dist)
-    opt.grad_scale = reducer.grad_scale
-    if (world > 1 or force_dist) and os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0":
-        reducer.defer_tail = True  # the embeddings' all-reduce overlaps the AdamW update of everything else
-        tr = reducer.tail_range()
-        if tr is not None:
-            opt.tail_sync = (tr[0], tr[1], reducer.wait_tail)
+    # the embeddings' all-reduce overlaps the AdamW update of everything else (same wiring as run.py)
+    reducer.attach(opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
     batch = synthetic_batch(args.batch, args.image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
     timer = GemmTimer(ops)
     timer.install()

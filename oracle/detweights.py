@@ -73,3 +73,17 @@ def det_gram(key: str, D: int, salt: int = 0) -> np.ndarray:
     """SPD fp64 gram X^T X with X ~ N(0,1) [D+64, D]."""
     X = _rng("gram:" + key, salt).standard_normal((D + 64, D))
     return X.T @ X
+
+
+def det_keep(tag: str, site: int, B: int, keep_prob: float) -> np.ndarray:
+    """Injected DropPath draw of one site of one pass: float32 [B] of 0/1 (1 = the sample's branch is kept).
+    `tag` names the reference pass (mlm / img / txt / pos / negimg / negtxt), `site` counts the pass's DropPath calls
+    (two per block evaluation, the vlffn re-run of the last layers continues the count)."""
+    u = _rng("droppath:" + tag, site).uniform(size=64)[:B]
+    return (u < keep_prob).astype(np.float32)
+
+
+def det_dropout_mask(tag: str, b: int, T: int, D: int, keep_prob: float) -> np.ndarray:
+    """Injected nn.Dropout mask of the text embeddings of sample b of pass `tag`: float32 [T, D] of 0/1."""
+    u = _rng("dropout:" + tag, b).uniform(size=(T, D))
+    return (u < keep_prob).astype(np.float32)

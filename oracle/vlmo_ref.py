@@ -10,10 +10,14 @@ Follows /root/reference/src/vilt/modules:
   objectives.py          compute_mlm :88, compute_ifm :248, compute_itm_hardneg :146, compute_irtr :372
   heads.py               Pooler :8, ITMHead :21, IFMHead :30, MLMHead :40
 BertEmbeddings uses the transformers-4.x semantics the reference was written for (no absolute position embedding
-for position_embedding_type="rel_pos").  Dropout / DropPath are identities (eval-mode parity).
+for position_embedding_type="rel_pos").  Dropout / DropPath are identities unless a TrainMasks object is
+passed: then timm's DropPath (x * keep_b / keep_prob, two sites per block evaluation, vision_transformer.py:527-528)
+and the text-embedding dropout (BertEmbeddings, p = drop_rate) use the INJECTED masks of oracle/detweights.py, the
+same ones tests/golden/ref_harness.py::inject_train_masks feeds the reference (train-mode parity).
 
-parity: PINNED against tests/golden/model_tiny_{ufo,all_moe}.npz and irtr_tiny_*.npz (outputs of the reference
-itself on the same deterministic weights and batch; tests/test_oracle_model.py).
+parity: PINNED against tests/golden/model_tiny_{ufo,all_moe}.npz and irtr_tiny_*.npz, model_base_*.npz (the benchmarked
+width) and train_tiny_*.npz (train mode, injected masks): outputs of the reference itself on the same deterministic
+weights and batch; tests/test_oracle_model.py.
 """
 import torch
 import torch.nn.functional as F
@@ -24,6 +28,41 @@ class Arch:
         assert arch in ("ufo", "all_moe")
         self.arch, self.D, self.H, self.L = arch, hidden, heads, layers
         self.S, self.T, self.P = vlffn_start, max_text_len, patch
+
+
+class TrainMasks:
+    """Train-mode randomness as data.  drop_path_rate / dropout p = config["drop_rate"]; per-layer DropPath
+    probabilities = linspace(0, rate, L) (vision_transformer.py:855).  begin(tag) starts a pass."""
+
+    def __init__(self, drop_rate, layers=12):
+        from oracle.detweights import det_keep, det_dropout_mask
+        self._keep, self._mask = det_keep, det_dropout_mask
+        self.p = float(drop_rate)
+        self.dpr = [float(x) for x in torch.linspace(0, drop_rate, layers)]
+        self.tag, self.site = None, 0
+
+    def begin(self, tag):
+        self.tag, self.site = tag, 0
+
+    def drop_path(self, i, x):
+        prob = self.dpr[i]
+        if prob == 0.0:
+            return x
+        keep = 1.0 - prob
+        k = torch.from_numpy(self._keep(self.tag, self.site, x.shape[0], keep)).to(x.dtype)
+        self.site += 1
+        return x * k.view(-1, 1, 1) / keep
+
+    def dropout(self, x):
+        if self.p == 0.0:
+            return x
+        B, T, D = x.shape
+        m = torch.stack([torch.from_numpy(self._mask(self.tag, b, T, D, 1.0 - self.p)) for b in range(B)])
+        return x * m / (1.0 - self.p)
+
+
+def _dp(tm, i, x):
+    return x if tm is None else tm.drop_path(i, x)
 
 
 def _k(i, mod, leaf, m):
@@ -59,7 +98,7 @@ def ln(sd, i, which, m, x):
     return F.layer_norm(x, (x.shape[-1],), sd[_k(i, which, "weight", m)], sd[_k(i, which, "bias", m)], 1e-6)
 
 
-def block(sd, a: Arch, i, x, mask, type_id, bias):
+def block(sd, a: Arch, i, x, mask, type_id, bias, tm=None):
     """type_id 0 image / 1 text / 2 vl.  ufo: shared weights, text/image attention separated below layer S in vl
     passes; all_moe: per-modality LN/attn/MLP, 'vl' expert from layer S on."""
     g1, g2 = sd[f"transformer.blocks.{i}.gamma_1"], sd[f"transformer.blocks.{i}.gamma_2"]
@@ -68,18 +107,18 @@ def block(sd, a: Arch, i, x, mask, type_id, bias):
     T = a.T
     if type_id in (0, 1) or deep:
         m = "" if not moe else ("v" if type_id == 0 else "l" if type_id == 1 else "vl")
-        x = x + g1 * attention(sd, a, i, m, ln(sd, i, "norm1", m, x), mask, bias)
-        x = x + g2 * mlp(sd, i, m, ln(sd, i, "norm2", m, x))
+        x = x + _dp(tm, i, g1 * attention(sd, a, i, m, ln(sd, i, "norm1", m, x), mask, bias))
+        x = x + _dp(tm, i, g2 * mlp(sd, i, m, ln(sd, i, "norm2", m, x)))
         return x
     ml, mv = ("l", "v") if moe else ("", "")
     xt = ln(sd, i, "norm1", ml, x[:, :T])
     xi = ln(sd, i, "norm1", mv, x[:, T:])
     at = attention(sd, a, i, ml, xt, mask[:, :T], bias[:, :T, :T])
     ai = attention(sd, a, i, mv, xi, mask[:, T:], bias[:, T:, T:])
-    x = x + g1 * torch.cat([at, ai], 1)
+    x = x + _dp(tm, i, g1 * torch.cat([at, ai], 1))
     xt = mlp(sd, i, ml, ln(sd, i, "norm2", ml, x[:, :T]))
     xi = mlp(sd, i, mv, ln(sd, i, "norm2", mv, x[:, T:]))
-    return x + g2 * torch.cat([xt, xi], 1)
+    return x + _dp(tm, i, g2 * torch.cat([xt, xi], 1))
 
 
 def rel_pos_bias(sd, index, a: Arch):
@@ -87,9 +126,11 @@ def rel_pos_bias(sd, index, a: Arch):
     return torch.chunk(b, a.L, dim=0)
 
 
-def text_embed(sd, ids, masks):
+def text_embed(sd, ids, masks, tm=None):
     e = F.embedding(ids, sd["text_embeddings.word_embeddings.weight"]) + sd["text_embeddings.token_type_embeddings.weight"][0]
     e = F.layer_norm(e, (e.shape[-1],), sd["text_embeddings.LayerNorm.weight"], sd["text_embeddings.LayerNorm.bias"], 1e-12)
+    if tm is not None:
+        e = tm.dropout(e)
     return e + F.embedding(torch.zeros_like(masks), sd["token_type_embeddings.weight"])
 
 
@@ -104,31 +145,33 @@ def final_norm(sd, x):
     return F.layer_norm(x, (x.shape[-1],), sd["transformer.norm.weight"], sd["transformer.norm.bias"], 1e-6)
 
 
-def infer(sd, a: Arch, idx, text_ids, text_masks, img):
-    te = text_embed(sd, text_ids, text_masks)
+def infer(sd, a: Arch, idx, text_ids, text_masks, img, tm=None, tag=None):
+    if tm is not None:
+        tm.begin(tag)
+    te = text_embed(sd, text_ids, text_masks, tm)
     ie = image_embed(sd, a, img)
     x = torch.cat([te, ie], 1)
     mask = torch.cat([text_masks, torch.ones(ie.shape[0], ie.shape[1], dtype=text_masks.dtype)], 1)
     bl = rel_pos_bias(sd, idx["text_imag_relative_position_index"], a)
     for i in range(a.L):
-        x = block(sd, a, i, x, mask, 2, bl[i])
+        x = block(sd, a, i, x, mask, 2, bl[i], tm)
     x = final_norm(sd, x)
     T = te.shape[1]
     cls = torch.tanh(F.linear(x[:, 0], sd["pooler.dense.weight"], sd["pooler.dense.bias"]))
     return {"text_feats": x[:, :T], "image_feats": x[:, T:], "cls_feats": cls, "raw_cls_feats": x[:, 0]}
 
 
-def _unimodal(sd, a, x, mask, type_id, bl, vlffn):
+def _unimodal(sd, a, x, mask, type_id, bl, vlffn, tm=None):
     hs = None
     for i in range(a.L):
-        x = block(sd, a, i, x, mask, type_id, bl[i])
+        x = block(sd, a, i, x, mask, type_id, bl[i], tm)
         if i == a.S - 1:
             hs = x
     v = None
     if vlffn:
         v = hs
         for i in range(a.S, a.L):
-            v = block(sd, a, i, v, mask, 2, bl[i])
+            v = block(sd, a, i, v, mask, 2, bl[i], tm)
         v = final_norm(sd, v)
     return final_norm(sd, x), v
 
@@ -137,21 +180,25 @@ def _l2(x):
     return x / x.norm(dim=-1, keepdim=True)
 
 
-def infer_text(sd, a, idx, text_ids, text_masks, vlffn=True):
-    x = text_embed(sd, text_ids, text_masks)
+def infer_text(sd, a, idx, text_ids, text_masks, vlffn=True, tm=None):
+    if tm is not None:
+        tm.begin("txt")
+    x = text_embed(sd, text_ids, text_masks, tm)
     bl = rel_pos_bias(sd, idx["text_relative_position_index"], a)
-    l, v = _unimodal(sd, a, x, text_masks, 1, bl, vlffn)
+    l, v = _unimodal(sd, a, x, text_masks, 1, bl, vlffn, tm)
     out = {"text_feats": l, "cls_feats": _l2(F.linear(l[:, 0], sd["ifm_text_proj.fc.weight"]))}
     if vlffn:
         out["cls_vlffn_feats"] = _l2(F.linear(v[:, 0], sd["ifm_vl_text_proj.fc.weight"]))
     return out
 
 
-def infer_image(sd, a, idx, img, vlffn=True):
+def infer_image(sd, a, idx, img, vlffn=True, tm=None):
+    if tm is not None:
+        tm.begin("img")
     x = image_embed(sd, a, img)
     mask = torch.ones(x.shape[0], x.shape[1], dtype=torch.long)
     bl = rel_pos_bias(sd, idx["relative_position_index"], a)
-    vf, v = _unimodal(sd, a, x, mask, 0, bl, vlffn)
+    vf, v = _unimodal(sd, a, x, mask, 0, bl, vlffn, tm)
     out = {"image_feats": vf, "cls_feats": _l2(F.linear(vf[:, 0], sd["ifm_image_proj.fc.weight"]))}
     if vlffn:
         out["cls_vlffn_feats"] = _l2(F.linear(v[:, 0], sd["ifm_vl_image_proj.fc.weight"]))
@@ -169,16 +216,16 @@ def _sym_ce(li):
     return (F.cross_entropy(li, gt) + F.cross_entropy(li.t(), gt)) / 2
 
 
-def pretrain_step(sd, a: Arch, idx, batch, neg_img=None, neg_txt=None):
+def pretrain_step(sd, a: Arch, idx, batch, neg_img=None, neg_txt=None, tm=None):
     """One training_step (mlm + ifm + itm, single process).  neg_img / neg_txt: indices of the hard negatives; the
     reference samples them with torch.multinomial, for B == 2 the draw is forced (the other sample)."""
     out = {}
-    r = infer(sd, a, idx, batch["text_ids_mlm"], batch["text_masks"], batch["image"])
+    r = infer(sd, a, idx, batch["text_ids_mlm"], batch["text_masks"], batch["image"], tm, "mlm")
     logits = mlm_head(sd, r["text_feats"])
     out["mlm_logits"] = logits
     out["mlm_loss"] = F.cross_entropy(logits.view(-1, logits.shape[-1]), batch["text_labels_mlm"].view(-1), ignore_index=-100)
-    im = infer_image(sd, a, idx, batch["image"])
-    tx = infer_text(sd, a, idx, batch["text_ids"], batch["text_masks"])
+    im = infer_image(sd, a, idx, batch["image"], tm=tm)
+    tx = infer_text(sd, a, idx, batch["text_ids"], batch["text_masks"], tm=tm)
     li = sd["logit_scale"].exp() * im["cls_feats"] @ tx["cls_feats"].t()
     lv = sd["logit_vl_scale"].exp() * im["cls_vlffn_feats"] @ tx["cls_vlffn_feats"].t()
     out["ifm_i2t_logits"] = li
@@ -193,9 +240,9 @@ def pretrain_step(sd, a: Arch, idx, batch, neg_img=None, neg_txt=None):
             neg_img = torch.multinomial(wt, 1).squeeze(1)
         if neg_txt is None:
             neg_txt = torch.multinomial(wi, 1).squeeze(1)
-    pos = infer(sd, a, idx, batch["text_ids"], batch["text_masks"], batch["image"])
-    ni = infer(sd, a, idx, batch["text_ids"], batch["text_masks"], batch["image"][neg_img])
-    nt = infer(sd, a, idx, batch["text_ids"][neg_txt], batch["text_masks"][neg_txt], batch["image"])
+    pos = infer(sd, a, idx, batch["text_ids"], batch["text_masks"], batch["image"], tm, "pos")
+    ni = infer(sd, a, idx, batch["text_ids"], batch["text_masks"], batch["image"][neg_img], tm, "negimg")
+    nt = infer(sd, a, idx, batch["text_ids"][neg_txt], batch["text_masks"][neg_txt], batch["image"], tm, "negtxt")
     cls = torch.cat([pos["cls_feats"], ni["cls_feats"], nt["cls_feats"]], 0)
     itm_logits = F.linear(cls, sd["itm_score.fc.weight"], sd["itm_score.fc.bias"])
     labels = torch.cat([torch.ones(B), torch.zeros(B), torch.zeros(B)]).long()

@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
 
-Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr ckpt recall batch downstream)
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr model_base irtr_merged_base train_tiny ckpt recall batch downstream vlmo_resize schedule)
 Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
 expected outputs are what the reference computed); no reference source is stored.
 """
@@ -279,6 +279,183 @@ def gold_irtr():
         np.savez_compressed(os.path.join(HERE, f"irtr_tiny_{arch}.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- base width (the benchmarked size)
+BASE = dict(vit="vit_base_patch16_384", image_size=384, hidden_size=768, num_heads=12, max_text_len=40,
+            vocab_size=1024, drop_rate=0.1)
+IMG_ROWS = 16   # image_feats rows kept: every 16th token (the fixture stays small; cls row 0 included)
+MLM_COLS = 8    # mlm logits kept: every 8th vocabulary column
+
+
+def _dist_once():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+
+def _step_record(model, batch, out, prefix, picks):
+    """One training_step of the reference (whatever mode the model is in) + backward; losses, logits, per-parameter
+    gradient (norm, sum), a few whole gradients."""
+    from vilt.modules import vilt_utils
+    model.zero_grad()
+    vilt_utils.set_task(model)
+    ret = model({"vl": batch})
+    total = sum(v for k, v in ret.items() if "loss" in k)
+    total.backward()
+    for k in ("mlm_loss", "ifm_loss", "itm_loss"):
+        out[prefix + k] = np.array(float(ret[k]))
+    out[prefix + "total_loss"] = np.array(float(total))
+    out[prefix + "mlm_logits"] = ret["mlm_logits"].detach().numpy()[..., ::MLM_COLS]
+    out[prefix + "itm_logits"] = ret["itm_logits"].detach().numpy()
+    out[prefix + "ifm_i2t_logits"] = ret["ifm_i2t_logits"].detach().numpy()
+    gs = grads_summary(model)
+    out[prefix + "grad_summary"] = np.array(json.dumps(gs))
+    named = dict(model.named_parameters())
+    for n in picks:
+        if named[n].grad is not None:
+            g = named[n].grad.numpy()
+            out[prefix + "grad/" + n] = g[::8] if n == "relative_position_bias_table" else g
+    return ret, total, gs
+
+
+def gold_model_base():
+    """The benchmarked configuration (hidden 768, 12 heads, 384^2: N = 617, R = 2294) through the reference, eval
+    mode, B = 2 (hard negatives forced): features of every pass, one training_step with backward.  Also the same step
+    under the reference's own training precision (fp16 autocast, run.py precision=16) -> amp_reference_errors.json:
+    what the reference's AMP path deviates from its fp32 path on exactly the quantities the GPU tests compare."""
+    _dist_once()
+    vm, vit, obj = import_reference()
+    amp = {}
+    for arch in ("ufo", "all_moe"):
+        cfg = base_config(max_vl_text_len=40, loss_names={"itm": 1, "mlm": 1, "ifm": 1}, tasks=["vl"], **BASE)
+        model, cfg = build_reference_model(cfg, arch)
+        meta = load_det_weights(model)
+        with open(os.path.join(HERE, f"keys_base_{arch}.json"), "w") as f:
+            json.dump(meta, f, indent=0, sort_keys=True)
+        model.eval()
+        batch = to_batch(det_batch(2, 384, 40, 1024, seed=4321))
+        out = {"img_rows": np.array(IMG_ROWS), "mlm_cols": np.array(MLM_COLS)}
+
+        def feats():
+            o = {}
+            r = model.infer(batch, mask_text=False)
+            o["infer/text_feats"] = r["text_feats"].numpy()
+            o["infer/image_feats"] = r["image_feats"].numpy()[:, ::IMG_ROWS]
+            o["infer/cls_feats"] = r["cls_feats"].numpy()
+            r = model.infer_image(batch)
+            o["infer_image/image_feats"] = r["image_feats"].numpy()[:, ::IMG_ROWS]
+            for k in ("cls_feats", "cls_vlffn_feats"):
+                o["infer_image/" + k] = r[k].numpy()
+            r = model.infer_text(batch)
+            o["infer_text/text_feats"] = r["text_feats"].numpy()
+            for k in ("cls_feats", "cls_vlffn_feats"):
+                o["infer_text/" + k] = r[k].numpy()
+            return o
+
+        with torch.no_grad():
+            out.update(feats())
+        named = dict(model.named_parameters())
+        picks = ["relative_position_bias_table", "token_type_embeddings.weight", "transformer.cls_token",
+                 "transformer.blocks.0.gamma_1", "transformer.blocks.11.gamma_2", "transformer.norm.weight",
+                 "transformer.patch_embed.proj.bias", "logit_scale", "logit_vl_scale"]
+        picks += [n for n in named if n.startswith("transformer.blocks.5.") and named[n].dim() == 1]
+        ret, total, gs = _step_record(model, batch, out, "step/", picks)
+        print(arch, "base", {k: float(out["step/" + k]) for k in ("mlm_loss", "ifm_loss", "itm_loss", "total_loss")})
+        np.savez_compressed(os.path.join(HERE, f"model_base_{arch}.npz"), **out)
+        # ---- the reference's own fp16-AMP path on the same check (errors only, nothing else is kept)
+        a = {}
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+            fa = feats()
+        for k, v in fa.items():
+            ref = out[k]
+            a["feat/" + k] = float(np.abs(v.astype(np.float32) - ref).max() / np.abs(ref).max())
+        o2 = {}
+        with torch.autocast("cpu", dtype=torch.float16):
+            _step_record(model, batch, o2, "step/", picks)
+        for k in ("mlm_loss", "ifm_loss", "itm_loss", "total_loss"):
+            a["loss/" + k] = abs(float(o2["step/" + k]) - float(out["step/" + k]))
+        for k in ("mlm_logits", "itm_logits", "ifm_i2t_logits"):
+            a["logits/" + k] = float(np.abs(o2["step/" + k].astype(np.float32) - out["step/" + k]).max()
+                                     / np.abs(out["step/" + k]).max())
+        g2 = json.loads(str(o2["step/grad_summary"]))
+        rel = {n: abs(g2[n][0] - v[0]) / (v[0] + 1e-12) for n, v in gs.items() if v is not None and g2[n] is not None}
+        big = [r for n, r in rel.items() if gs[n][0] > 0.05]
+        small = [r for n, r in rel.items() if gs[n][0] <= 0.05]
+        a["grad_norm_rel/max_norm_gt_0.05"] = max(big)
+        a["grad_norm_rel/median_norm_gt_0.05"] = float(np.median(big))
+        a["grad_norm_rel/max_norm_le_0.05"] = max(small) if small else 0.0
+        full = []
+        for k in out:
+            if k.startswith("step/grad/"):
+                mx = float(np.abs(out[k]).max())
+                full.append(float(np.abs(o2[k] - out[k]).max()) / (mx + 1e-12))
+        a["grad_full_rel_to_max/max"] = max(full)
+        amp[arch] = a
+        print(arch, "fp16-AMP reference vs fp32 reference:", json.dumps(a, indent=0))
+    with open(os.path.join(HERE, "amp_reference_errors.json"), "w") as f:
+        json.dump(amp, f, indent=1, sort_keys=True)
+
+
+def gold_irtr_merged_base():
+    """configs[4] at base size: two-expert all_moe weights -> the reference's merge_weights (ratio 0.5) -> ufo model
+    with the irtr objective at 384^2, one step with backward (B = 3).  The test redoes the merge with the HIP kernel."""
+    _dist_once()
+    vm, vit, obj = import_reference()
+    from vilt.modules import vilt_utils
+    cfg = base_config(loss_names={"irtr": 1}, **BASE)
+    moe, _ = build_reference_model(cfg, "all_moe")
+    meta_moe = load_det_weights(moe)
+    with open(os.path.join(HERE, "keys_base_irtr_all_moe.json"), "w") as f:
+        json.dump(meta_moe, f, indent=0, sort_keys=True)
+    merged = vm.ViLTransformerSS.merge_weights(fake_self(merge_ratio=0.5), {k: v.clone() for k, v in moe.state_dict().items()})
+    ufo, _ = build_reference_model(cfg, "ufo")
+    res = ufo.load_state_dict(merged, strict=False)
+    print("merged -> ufo: missing", [k for k in res.missing_keys][:8], "unexpected", len(res.unexpected_keys))
+    ufo.eval()
+    vilt_utils.set_task(ufo)
+    batch = to_batch(det_batch(3, 384, 40, 1024, seed=99))
+    ufo.zero_grad()
+    ret = ufo(batch)
+    ret["irtr_loss"].backward()
+    out = {"irtr_loss": np.array(float(ret["irtr_loss"])), "irtr_i2t_logits": ret["irtr_i2t_logits"].detach().numpy(),
+           "grad_summary": np.array(json.dumps(grads_summary(ufo))),
+           "merged_sha/transformer.blocks.3.mlp.fc1.weight": np.array(sha(merged["transformer.blocks.3.mlp.fc1.weight"].numpy())),
+           "merged_sha/transformer.blocks.11.attn.qkv.weight": np.array(sha(merged["transformer.blocks.11.attn.qkv.weight"].numpy()))}
+    with torch.no_grad():
+        out["img_cls_feats"] = ufo.infer_image_ft(batch)["cls_feats"].numpy()
+        out["txt_cls_feats"] = ufo.infer_text_ft(batch)["cls_feats"].numpy()
+    print("irtr merged base: loss", float(ret["irtr_loss"]))
+    np.savez_compressed(os.path.join(HERE, "irtr_merged_base.npz"), **out)
+
+
+def gold_train_tiny():
+    """TRAIN mode (DropPath + text-embedding dropout live) with injected masks (ref_harness.inject_train_masks):
+    one training_step of the reference at tiny width, B = 2."""
+    _dist_once()
+    vm, vit, obj = import_reference()
+    from ref_harness import inject_train_masks, INJECT
+    for arch in ("ufo", "all_moe"):
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_vl_text_len=40,
+                          max_text_len=40, vocab_size=1024, loss_names={"itm": 1, "mlm": 1, "ifm": 1},
+                          tasks=["vl"], drop_rate=0.1)
+        model, cfg = build_reference_model(cfg, arch)
+        load_det_weights(model)  # same weights as model_tiny_<arch>.npz / keys_tiny_<arch>.json
+        model.train()
+        st = inject_train_masks(model)
+        batch = to_batch(det_batch(2, 224, 40, 1024, seed=1234))
+        out = {"mlm_cols": np.array(MLM_COLS),
+               "drop_path_probs": np.array([float(getattr(b.drop_path, "drop_prob", 0.0)) for b in model.transformer.blocks])}
+        named = dict(model.named_parameters())
+        picks = ["transformer.blocks.0.gamma_1", "transformer.blocks.11.gamma_2", "transformer.norm.weight",
+                 "token_type_embeddings.weight"]
+        _step_record(model, batch, out, "step/", picks)
+        INJECT["keep"] = None
+        print(arch, "train-mode", {k: float(out["step/" + k]) for k in ("mlm_loss", "ifm_loss", "itm_loss", "total_loss")},
+              "infer calls", st["n_infer"])
+        np.savez_compressed(os.path.join(HERE, f"train_tiny_{arch}.npz"), **out)
+
+
 # ----------------------------------------------------------------------------- checkpoint re-keying (SURVEY.md 8f rank 2)
 def beit_state(D, F, heads, layers, src_window, shared_table, salt=3):
     """A BEiT-format state_dict as the reference expects it at vilt_module.py:808 (keys already under "transformer."):
@@ -523,4 +700,5 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
-         "irtr": gold_irtr, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()
+         "irtr": gold_irtr, "model_base": gold_model_base, "irtr_merged_base": gold_irtr_merged_base,
+         "train_tiny": gold_train_tiny, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 
 REF_SRC = "/root/reference/src"
+# train-mode goldens: the DropPath stub below asks INJECT["keep"](B, keep_prob) for its 0/1 draw when it is set
+INJECT = {"keep": None}
 
 
 def _mod(name, **attrs):
@@ -88,6 +90,9 @@ def install_stubs():
                 return x
             keep = 1 - self.drop_prob
             shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+            if INJECT["keep"] is not None:  # fixed keep masks (train-mode goldens): see inject_train_masks()
+                rnd = INJECT["keep"](x.shape[0], keep).to(x.dtype).view(shape)
+                return x * rnd / keep
             rnd = x.new_empty(shape).bernoulli_(keep)
             return x * rnd.div_(keep)
 
@@ -244,3 +249,50 @@ def build_reference_model(cfg, arch):
         raise ValueError(arch)
     model = vm.ViLTransformerSS(cfg, ufo, ln, moe)
     return model, cfg
+
+
+def inject_train_masks(model):
+    """Make a train-mode step of the reference deterministic: every DropPath call and the text-embedding dropout use
+    oracle.detweights.det_keep / det_dropout_mask, keyed by (pass tag, site or sample).  Pass tags follow the order
+    in which forward() runs its passes for mlm + ifm + itm (vilt_module.py:1493-1510, objectives.py:146-245):
+    infer -> mlm, pos, negimg, negtxt; infer_image -> img; infer_text -> txt.  Only the wrapping is added here; the
+    reference's arithmetic (x * mask / keep) is untouched."""
+    from oracle.detweights import det_keep, det_dropout_mask
+    state = {"tag": None, "site": 0, "n_infer": 0}
+
+    def keep(B, keep_prob):
+        k = det_keep(state["tag"], state["site"], B, keep_prob)
+        state["site"] += 1
+        return torch.from_numpy(k)
+
+    INJECT["keep"] = keep
+
+    def wrap(name, tagger):
+        fn = getattr(model, name)
+
+        def wrapped(*a, **k):
+            state["tag"], state["site"] = tagger(), 0
+            return fn(*a, **k)
+
+        setattr(model, name, wrapped)
+
+    def infer_tag():
+        t = ("mlm", "pos", "negimg", "negtxt")[state["n_infer"] % 4]
+        state["n_infer"] += 1
+        return t
+
+    wrap("infer", infer_tag)
+    wrap("infer_image", lambda: "img")
+    wrap("infer_text", lambda: "txt")
+    p = model.text_embeddings.dropout.p
+
+    class DetDropout(nn.Module):
+        def forward(self, x):
+            if not self.training or p == 0.0:
+                return x
+            B, T, D = x.shape
+            m = torch.stack([torch.from_numpy(det_dropout_mask(state["tag"], b, T, D, 1.0 - p)) for b in range(B)])
+            return x * m / (1.0 - p)
+
+    model.text_embeddings.dropout = DetDropout()
+    return state

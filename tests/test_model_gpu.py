@@ -64,6 +64,8 @@ def feat_close(got, ref, what, tol=3e-2):
     ref = torch.as_tensor(ref)
     err = float((got - ref).abs().max())
     scale = float(ref.abs().max())
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    MEASURED.setdefault(test, {})[what] = err / (scale + 1e-30)
     assert err <= tol * scale, "%s: max err %.4g vs scale %.4g" % (what, err, scale)
 
 
@@ -319,3 +321,302 @@ def test_planned_droppath_sites(mods):
         # a probability that does not match the plan falls back to the single-site kernel
         d = pc.drop_path_rows(0.3, True, dev)
         assert d.shape == (64 * 8,)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The benchmarked width (hidden 768, 12 heads, 384^2: N = 617 tokens, R = 2294 table rows) against the reference, with
+# the shipped engine options ON (fused 4B-sample joint pass, unimodal pair pass, dense fp16 bias, transposed shadows).
+#
+# Tolerances, next to what the reference's OWN reduced-precision path (fp16 autocast, run.py precision=16; run on the
+# CPU by make_golden.py model_base -> tests/golden/amp_reference_errors.json) deviates from its fp32 path on the same
+# quantities at this width:
+#   quantity                                 fp16-autocast reference    this engine's bound
+#   features (max err / max |ref|)           <= 1.7e-3                  3e-2
+#   losses (absolute)                        <= 6e-4                    3e-2 (total 5e-2)
+#   logits (max err / max |ref|)             <= 1e-3                    3e-2 (itm 5e-2)
+#   gradient norm per tensor, norm > 0.05    <= 0.5 %  (median 5e-5)    6 %
+#   gradient norm per tensor, norm <= 0.05   up to 6 % (ufo) / 114 % (all_moe: the near-zero contrastive gradients)   20 %
+# fp16 keeps 11 significant bits, the engine's bf16 activations 8 (8x coarser per rounding), and the engine rounds
+# between every pair of kernels where autocast only rounds GEMM operands; what the engine actually reaches is written
+# to gpurun_out/parity_errors.json by every run of this file (MEASURED below) and quoted in DESIGN.md.
+MEASURED = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_measured():
+    yield
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "parity_errors.json"), "w") as f:
+            json.dump(MEASURED, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def build_base(mods, arch, golden_dir, losses, tag=None, max_vl=40, train=False, **over):
+    cfgmod, vm = mods
+    cfg = cfgmod.make_config(arch, vit="vit_base_patch16_384", hidden_size=768, num_heads=12, vocab_size=1024,
+                             max_text_len=40, patch_size=16, vlffn_start_layer_index=10, image_size=384,
+                             max_vl_text_len=max_vl, tasks=["vl"] if max_vl else None,
+                             loss_names=cfgmod._loss_names(losses), **over)
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    if tag is not None:
+        meta = json.load(open(os.path.join(golden_dir, f"keys_{tag}.json")))
+        sd = {k: torch.from_numpy(det_array(k, s)) for k, (s, dt) in meta.items()
+              if dt.startswith("float") and "index" not in k and "mask_for" not in k and not k.startswith(("train_", "val_"))}
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys
+    model = model.cuda()
+    model.train(train)
+    model.setup_engine()
+    return model
+
+
+def check_grad_summary(model, gs):
+    named = dict(model.named_parameters())
+    bad, rels = [], []
+    for n, v in gs.items():
+        g = named[n].grad
+        if v is None:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        nrm = float(g.double().norm())
+        rels.append((abs(nrm - v[0]) / (v[0] + 1e-12), v[0]))
+        if not grad_norm_ok(nrm, v[0]):
+            bad.append((n, nrm, v[0]))
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    big = [r for r, n0 in rels if n0 > 0.05]
+    small = [r for r, n0 in rels if n0 <= 0.05]
+    MEASURED.setdefault(test, {}).update({"grad_norm_rel_max(norm>0.05)": max(big) if big else 0.0,
+                                          "grad_norm_rel_median(norm>0.05)": float(np.median(big)) if big else 0.0,
+                                          "grad_norm_rel_max(norm<=0.05)": max(small) if small else 0.0})
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_base_width_matches_reference_golden(mods, golden_dir, arch):
+    gold = np.load(os.path.join(golden_dir, f"model_base_{arch}.npz"))
+    model = build_base(mods, arch, golden_dir, {"itm": 1, "mlm": 1, "ifm": 1}, tag=f"base_{arch}")
+    assert model.fuse_joint_passes and model.fuse_unimodal_passes  # the shipped defaults are what is checked
+    engine = importlib.import_module("vl_merging_amd.engine")
+    assert engine._DENSE_BIAS
+    batch = gpu_batch(det_batch(2, 384, 40, 1024, seed=4321))
+    step = int(gold["img_rows"])
+    with torch.no_grad():
+        r = model.infer(batch, mask_text=False)
+        feat_close(r["text_feats"], gold["infer/text_feats"], "text_feats")
+        feat_close(r["image_feats"][:, ::step], gold["infer/image_feats"], "image_feats")
+        feat_close(r["cls_feats"], gold["infer/cls_feats"], "cls_feats")
+        pi, pt = model.infer_unimodal_pair(batch, with_vlffn=True)   # what compute_ifm runs by default
+        feat_close(pi["image_feats"][:, ::step], gold["infer_image/image_feats"], "pair image_feats")
+        feat_close(pt["text_feats"], gold["infer_text/text_feats"], "pair text_feats")
+        for k in ("cls_feats", "cls_vlffn_feats"):
+            feat_close(pi[k], gold["infer_image/" + k], "pair image " + k)
+            feat_close(pt[k], gold["infer_text/" + k], "pair text " + k)
+        ri, rt = model.infer_image(batch), model.infer_text(batch)   # the reference-shaped separate passes
+        feat_close(ri["image_feats"][:, ::step], gold["infer_image/image_feats"], "image_feats (separate)")
+        feat_close(rt["text_feats"], gold["infer_text/text_feats"], "text_feats (separate)")
+    model.zero_grad()
+    mods[1].vilt_utils.set_task(model)
+    ret = model({"vl": batch})       # ifm through the pair pass, mlm + itm through ONE 4B-sample pass
+    total = sum(v for k, v in ret.items() if "loss" in k)
+    total.backward()
+    torch.cuda.synchronize()
+    for k in ("mlm_loss", "ifm_loss", "itm_loss"):
+        assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
+    assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
+    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits")
+    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
+    feat_close(ret["ifm_i2t_logits"], gold["step/ifm_i2t_logits"], "ifm logits")
+    check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))
+    named = dict(model.named_parameters())
+    for key in gold.files:
+        if key.startswith("step/grad/"):
+            n = key[len("step/grad/"):]
+            ref = torch.from_numpy(gold[key])
+            got = named[n].grad.float().cpu()
+            if n == "relative_position_bias_table":
+                got = got[::8]
+            err = float((got - ref).abs().max())
+            mx = float(ref.abs().max())
+            floor = 1e-4 if ref.numel() == 1 else 1e-6
+            assert err <= (0.2 if mx <= 0.05 else 0.15) * mx + floor, (n, err, mx)
+
+
+def test_tolerances_are_stated_next_to_amp(golden_dir):
+    """The table above quotes tests/golden/amp_reference_errors.json: keep the two in step."""
+    amp = json.load(open(os.path.join(golden_dir, "amp_reference_errors.json")))
+    for arch, a in amp.items():
+        assert max(v for k, v in a.items() if k.startswith("feat/")) <= 1.7e-3
+        assert max(v for k, v in a.items() if k.startswith("loss/")) <= 6e-4
+        assert max(v for k, v in a.items() if k.startswith("logits/")) <= 1e-3
+        assert a["grad_norm_rel/max_norm_gt_0.05"] <= 5e-3 and a["grad_norm_rel/median_norm_gt_0.05"] <= 1e-4
+    assert amp["ufo"]["grad_norm_rel/max_norm_le_0.05"] <= 0.07 and amp["all_moe"]["grad_norm_rel/max_norm_le_0.05"] <= 1.2
+
+
+def test_irtr_on_merged_weights_base_width(mods, golden_dir):
+    """configs[4] at base size: all_moe weights -> merge_weights on the HIP kernel (bit-exact vs the reference's merged
+    tensors) -> ufo model, irtr objective at 384^2 (B = 3): loss, logits, features, gradient norms vs the reference."""
+    cfgmod, vm = mods
+    gold = np.load(os.path.join(golden_dir, "irtr_merged_base.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "keys_base_irtr_all_moe.json")))
+    import hashlib
+    sd = {k: torch.from_numpy(det_array(k, s)).cuda() for k, (s, dt) in meta.items()
+          if dt.startswith("float") and "index" not in k and "mask_for" not in k and not k.startswith(("train_", "val_"))}
+    model = build_base(mods, "ufo", golden_dir, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0}, max_vl=None, merge_ratio=0.5)
+    merged = model.merge_weights(sd)
+    torch.cuda.synchronize()
+    for k in gold.files:
+        if k.startswith("merged_sha/"):
+            n = k[len("merged_sha/"):]
+            assert hashlib.sha256(merged[n].cpu().numpy().tobytes()).hexdigest() == str(gold[k]), n
+    res = model.load_state_dict(merged, strict=False)
+    assert not [m for m in res.missing_keys if "index" not in m and "position_ids" not in m and "mask_for" not in m], res.missing_keys
+    model._ensure_engine()
+    batch = gpu_batch(det_batch(3, 384, 40, 1024, seed=99))
+    model.zero_grad()
+    mods[1].vilt_utils.set_task(model)
+    ret = model(batch)
+    ret["irtr_loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(float(ret["irtr_loss"]) - float(gold["irtr_loss"])) <= 2e-2
+    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits")
+    with torch.no_grad():
+        feat_close(model.infer_image_ft(batch)["cls_feats"], gold["img_cls_feats"], "img cls")
+        feat_close(model.infer_text_ft(batch)["cls_feats"], gold["txt_cls_feats"], "txt cls")
+    check_grad_summary(model, json.loads(str(gold["grad_summary"])))
+
+
+def _oracle_state(model):
+    return {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
+
+
+def _oracle_index(model):
+    return {k: getattr(model, k).cpu() for k in ("relative_position_index", "text_relative_position_index",
+                                                 "text_imag_relative_position_index")}
+
+
+@pytest.mark.parametrize("arch,B,losses", [("all_moe", 22, {"itm": 1, "mlm": 1, "ifm": 1}),
+                                           ("ufo", 20, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0})])
+def test_full_size_step_properties(mods, golden_dir, arch, B, losses):
+    """configs[2] (all_moe 384^2, B = 22, mlm + itm + ifm) and configs[4] (irtr 384^2, B = 20) at FULL size, train mode,
+    two optimizer steps.  Size-independent properties: (1) batch independence - rows of the full-batch eval pass equal
+    the CPU oracle run on two of its samples alone (fp tolerance 3e-2 of the feature scale); (2) losses finite and,
+    at random init on a fixed batch, lower after two AdamW steps; (3) every parameter the step's passes use receives a
+    finite non-zero gradient, unused experts receive none and stay bit-identical (HF AdamW skips grad-less params)."""
+    from oracle import vlmo_ref as R
+    irtr = "irtr" in losses and losses["irtr"]
+    model = build_base(mods, arch, golden_dir, losses, tag=None, max_vl=None if irtr else 40, train=False)
+    torch.manual_seed(3)
+    nb = det_batch(B, 384, 40, 1024, seed=2024 + B)
+    batch = gpu_batch(nb)
+    # (1) batch independence against the oracle on samples {0, B-1}
+    pick = [0, B - 1]
+    osd, oidx = _oracle_state(model), _oracle_index(model)
+    with torch.no_grad():
+        sub = {k: torch.from_numpy(v[pick]) for k, v in nb.items()}
+        if irtr:
+            got_i, got_t = model.infer_unimodal_pair(batch, with_vlffn=False)
+            want_i = R.infer_image(osd, R.Arch(arch), oidx, sub["image"], vlffn=False)["cls_feats"]
+            want_t = R.infer_text(osd, R.Arch(arch), oidx, sub["text_ids"], sub["text_masks"], vlffn=False)["cls_feats"]
+            feat_close(got_i["cls_feats"][pick], want_i, "image cls of samples 0 / B-1")
+            feat_close(got_t["cls_feats"][pick], want_t, "text cls of samples 0 / B-1")
+        else:
+            got = model.infer(batch)
+            want = R.infer(osd, R.Arch(arch), oidx, sub["text_ids"], sub["text_masks"], sub["image"])
+            feat_close(got["text_feats"][pick], want["text_feats"], "text_feats of samples 0 / B-1")
+            feat_close(got["image_feats"][pick], want["image_feats"], "image_feats of samples 0 / B-1")
+    # (2) + (3) two train-mode steps
+    model.train()
+    (opt,), (sch,) = mods[1].vilt_utils.set_schedule(model, max_steps=100)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    losses_seen = []
+    for it in range(3):
+        loss = model.training_step(batch if irtr else {"vl": batch})
+        loss.backward()
+        if it == 0:
+            torch.cuda.synchronize()
+            gn = {n: float(p.grad.double().norm()) for n, p in model.named_parameters()}
+        opt.step()
+        sch["scheduler"].step()
+        losses_seen.append(float(loss))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses_seen)), losses_seen
+    assert losses_seen[-1] < losses_seen[0], losses_seen
+    assert all(np.isfinite(v) for v in gn.values())
+    used = [n for n, v in gn.items() if v > 0]
+    unused = [n for n, v in gn.items() if v == 0]
+    if irtr:   # text-only + image-only passes of a ufo model: every block tensor is used, the joint-pass heads are not
+        assert all(n in used for n in gn if n.startswith("transformer.blocks."))
+        assert "pooler.dense.weight" in unused
+    else:      # all_moe pre-training: v / l experts in every layer, vl experts from layer 10 on
+        assert "transformer.blocks.3.mlp.v.fc1.weight" in used and "transformer.blocks.3.mlp.l.fc1.weight" in used
+        assert "transformer.blocks.11.mlp.vl.fc2.weight" in used
+        assert "transformer.mask_token" in unused
+    for n in unused:
+        assert torch.equal(dict(model.named_parameters())[n].detach(), before[n]), n + " moved without a gradient"
+    moved = [n for n in used if not torch.equal(dict(model.named_parameters())[n].detach(), before[n])]
+    assert len(moved) >= 0.95 * len(used)
+
+
+@pytest.mark.parametrize("arch", ["ufo", "all_moe"])
+def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
+    """TRAIN mode (DropPath + text-embedding dropout live) against the REFERENCE's train-mode step on the same injected
+    masks (tests/golden/train_tiny_*.npz, oracle/detweights.py::det_keep / det_dropout_mask).  The engine runs its
+    shipped pass structure (pair pass + fused 4B pass), so the masks are re-keyed from the reference's
+    (pass tag, site, sample) to the engine's (pass, site, stream, sample)."""
+    from oracle.detweights import det_keep, det_dropout_mask
+    gold = np.load(os.path.join(golden_dir, f"train_tiny_{arch}.npz"))
+    model = build(mods, arch, f"tiny_{arch}", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1}, train=True)
+    B, T, D = 2, 40, 192
+
+    def tags_of(pc):
+        if pc.independent_segments:
+            return [["txt"] * pc.seq.B, ["img"] * pc.seq.B]           # stream 0 = text rows, stream 1 = image rows
+        assert pc.seq.B == 4 * B
+        return [[t for t in ("mlm", "pos", "negimg", "negtxt") for _ in range(B)]]
+
+    def uniforms(pc, S, streams):
+        tags = tags_of(pc)
+        assert len(tags) == streams
+        u = torch.ones(streams, S, pc.seq.B)
+        ref_site = 0
+        for s, prob in enumerate(pc._dp_sites):
+            if prob <= 0.0:
+                continue            # nn.Identity in the reference: no draw, no site number
+            for st in range(streams):
+                for b in range(pc.seq.B):
+                    k = det_keep(tags[st][b], ref_site, B, 1.0 - prob)[b % B]
+                    u[st, s, b] = 0.0 if k > 0 else 1.0
+            ref_site += 1
+        return u
+
+    model.droppath_uniform_source = uniforms
+    p = model.text_embeddings.dropout.p
+    calls = []
+
+    class DetDropout(torch.nn.Module):
+        def forward(self, x):
+            n = x.shape[0]
+            tags = ["txt"] * n if n == B else [t for t in ("mlm", "pos", "negimg", "negtxt") for _ in range(B)]
+            calls.append(n)
+            m = torch.stack([torch.from_numpy(det_dropout_mask(tags[b], b % B, T, D, 1.0 - p)) for b in range(n)])
+            return x * m.to(x.device) / (1.0 - p)
+
+    model.text_embeddings.dropout = DetDropout()
+    batch = gpu_batch(det_batch(2, 224, 40, 1024, seed=1234))
+    model.zero_grad()
+    mods[1].vilt_utils.set_task(model)
+    ret = model({"vl": batch})
+    total = sum(v for k, v in ret.items() if "loss" in k)
+    total.backward()
+    torch.cuda.synchronize()
+    assert calls == [B, 4 * B], calls
+    for k in ("mlm_loss", "ifm_loss", "itm_loss"):
+        assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
+    assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
+    eval_gold = np.load(os.path.join(golden_dir, f"model_tiny_{arch}.npz"))
+    assert abs(float(gold["step/total_loss"]) - float(eval_gold["step/total_loss"])) > 1e-3
+    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits")
+    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
+    check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))

@@ -139,6 +139,13 @@ def save_ckpt(path, model, global_step=0, epoch=0, extra=None):
     return ckpt
 
 
+def load_file(path):
+    """torch.load of a user-supplied LOCAL artefact of the reference repo (a Lightning .ckpt with AttributeDict
+    hyper-parameters and callback class keys, or the Gram cache's defaultdict(float), cache_gram_matrices.py:349):
+    these are pickles of non-tensor objects, so torch >= 2.6's weights_only default cannot read them."""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_ckpt(path):
     """state_dict of a Lightning `.ckpt` (or of a bare state_dict file) on the CPU."""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)

@@ -5,8 +5,9 @@ contiguous slice of engine.FlatParams.flat_g: {heads}, {block 11} ... {block 0},
 slice is final once every pass that used the block has run its backward (weights are shared by up to six passes per
 step); the fused block function reports each backward through `on_block_backward`, and the slice's all-reduce is
 launched on a side stream as soon as the count is complete, overlapping the remaining backward.  Parameters that get
-no gradient in a step (position_embeddings, mask_token, ...) stay zero in the flat buffer: no
-unused-parameter discovery is needed.  The 1/world average is folded into the fused AdamW kernel (grad_scale).
+no gradient in a step (position_embeddings, mask_token, ...) stay zero in the flat buffer: the
+reducer needs no unused-parameter discovery (the optimizer does its own, once: FusedAdamW._discover_active skips tensors
+that never received a gradient, as HF AdamW skips p.grad is None).  The 1/world average is folded into the fused AdamW kernel (grad_scale).
 """
 import re
 
@@ -52,6 +53,8 @@ class FlatGradReducer:
         model._grad_hook = self.on_block_backward
         self.measure = False      # bench.py turns this on for the timed steps
         self.defer_tail = False   # True: finish_backward leaves the last (embeddings) all-reduce in flight, see wait_tail
+        self.accumulate = False   # True: this backward is a non-final micro-batch, keep the gradients local
+        self._attached = None
         self._tail_handles = []
         self._wait_events = []
 
@@ -59,7 +62,22 @@ class FlatGradReducer:
     def grad_scale(self):
         return 1.0 / self.world
 
+    def attach(self, optimizer, defer_tail=True):
+        """Wire an optimizer to this reducer: the 1/world gradient average, and (defer_tail) the embeddings' slice whose
+        all-reduce stays in flight while AdamW updates everything else.  The reducer owns both halves of that contract,
+        so a caller cannot enable the deferral without the wait (bench.py and run.py both go through here)."""
+        optimizer.grad_scale = self.grad_scale
+        self.defer_tail = bool(defer_tail) and (self.world > 1 or self.force)
+        tr = self.tail_range()
+        optimizer.tail_sync = (tr[0], tr[1], self.wait_tail) if tr is not None else None
+        self._attached = optimizer
+        return self
+
     def begin_step(self):
+        # a deferred tail all-reduce nobody waited for (optimizer step skipped, or defer_tail set by hand without
+        # tail_sync) must land before the gradient buffer is written again
+        if self._tail_handles:
+            self.wait_tail()
         for i in self.seen:
             self.seen[i] = 0
         self.handles = []
@@ -84,7 +102,7 @@ class FlatGradReducer:
 
     def on_block_backward(self, layer):
         self.seen[layer] += 1
-        if self.counting:
+        if self.counting or self.accumulate:
             return
         if self.seen[layer] == self.expected[layer]:
             self._launch(*self.block_slices[layer])
@@ -93,7 +111,14 @@ class FlatGradReducer:
                     self._launch(lo, hi)
 
     def finish_backward(self):
-        """After loss.backward(): reduce what is left, then make the compute stream wait for all buckets."""
+        """After loss.backward(): reduce what is left, then make the compute stream wait for all buckets.
+        With `accumulate` set (a non-final micro-batch of gradient accumulation, run.py grad_steps) nothing is sent: the
+        flat buffer keeps summing local gradients and the final micro-batch reduces the sum once."""
+        if self.accumulate:
+            if self.counting:
+                self.expected = dict(self.seen)
+                self.counting = False
+            return
         if self.counting:
             # first step: use counts were unknown during backward -> reduce every block now, remember the counts
             self.expected = dict(self.seen)

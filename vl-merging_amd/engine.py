@@ -247,6 +247,7 @@ class PassCtx:
         self._dp_pool, self._dp_next = None, 0
         self._dp_sites, self._dp_all, self._dp_call = None, None, 0
         self.independent_segments = False  # True: the two segments are separate passes of the reference (own DropPath draws)
+        self.uniform_source = None  # callable(pass_ctx, n_sites, n_streams) -> uniforms; None = torch.rand
 
     def row2sample(self, device):
         if self._row2sample is None:
@@ -278,7 +279,14 @@ class PassCtx:
                 if keeps is None:  # uploaded once per schedule: a pageable H2D copy inside a step would stall the queue
                     keeps = _KEEPS_CACHE[key] = torch.tensor([1.0 - p if p > 0.0 else 1.0 for p in self._dp_sites],
                                                              dtype=F32).to(device)
-                u = torch.rand(2 if (self.independent_segments and s.n0 and s.n1) else 1, S, s.B, device=device, dtype=F32)
+                streams = 2 if (self.independent_segments and s.n0 and s.n1) else 1
+                if self.uniform_source is not None:
+                    # injected draws (parity tests): fp32 [streams, S, B] in [0, 1); a sample's branch is kept where
+                    # u < keep.  Stream 0 drives segment 0 (text rows), stream 1 segment 1 (image rows).
+                    u = self.uniform_source(self, S, streams).to(device=device, dtype=F32).contiguous()
+                    assert u.shape == (streams, S, s.B), (u.shape, streams, S, s.B)
+                else:
+                    u = torch.rand(streams, S, s.B, device=device, dtype=F32)
                 self._dp_all = ops.droppath_sites(u[0], u[1] if u.shape[0] == 2 else None, keeps, s,
                                                   torch.empty(S, rows, device=device, dtype=F32))
             return self._dp_all[i]

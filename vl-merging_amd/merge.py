@@ -171,7 +171,8 @@ def sum_task_vectors(state_dict, config, central_weight=None, device="cuda", pla
     """Task-vector merge (vilt_module.py:640-746).  `central_weight` defaults to torch.load(config[...])."""
     out = _passthrough(state_dict)
     if central_weight is None:
-        central_weight = torch.load(config["central_weight"], map_location="cpu")
+        from . import checkpoint
+        central_weight = checkpoint.load_file(config["central_weight"])
     if "state_dict" in central_weight:
         central_weight = central_weight["state_dict"]
     plan = MergePlan(device)

@@ -20,7 +20,8 @@ def scale_gram(G, alpha):
 def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None):
     out = M._passthrough(state_dict)
     if gram_matrices is None:
-        gram_matrices = torch.load(config["gram_matrices"], map_location="cpu")
+        from . import checkpoint
+        gram_matrices = checkpoint.load_file(config["gram_matrices"])
     alpha = config["scaling_for_non_diag"]
     plan = M.MergePlan(device)
     dev = plan.device

@@ -45,18 +45,30 @@ def main(argv):
     model.train()
     model.setup_engine()
     (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"] or 100000)
-    red = ddp.FlatGradReducer(model)
-    opt.grad_scale = red.grad_scale
+    red = ddp.FlatGradReducer(model).attach(opt)  # same reducer set-up as bench.py
     B = cfg["per_gpu_batchsize"] or 2
+    # run.py:155-158 of the reference: accumulate_grad_batches = batch_size // (per_gpu_batchsize * gpus * nodes)
+    grad_steps = max(1, int(cfg["batch_size"]) // (B * world * max(1, int(cfg["num_nodes"]))))
+    if os.environ.get("VLM_GRAD_STEPS"):
+        grad_steps = int(os.environ["VLM_GRAD_STEPS"])
+    opt.grad_scale = red.grad_scale / grad_steps  # mean over micro-batches and ranks, folded into AdamW
     batch = synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, "cuda")
     if cfg["tasks"] is None:
         batch = batch["vl"]
+    if rank == 0:
+        print("global batch %d = %d per GPU x %d ranks x %d accumulated micro-batches" % (B * world * grad_steps, B, world, grad_steps),
+              flush=True)
     for it in range(steps):
         t0 = time.time()
         red.begin_step()
-        loss = model.training_step(batch, it)
-        loss.backward()
-        red.finish_backward()
+        for micro in range(grad_steps):
+            red.accumulate = micro + 1 < grad_steps  # only the last micro-batch's backward sends gradients
+            if micro:
+                for i in red.seen:
+                    red.seen[i] = 0
+            loss = model.training_step(batch, it)
+            loss.backward()
+            red.finish_backward()
         opt.step()
         sch["scheduler"].step()
         if rank == 0:

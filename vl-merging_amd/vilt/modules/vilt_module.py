@@ -201,11 +201,15 @@ class ViLTransformerSS(nn.Module):
 
         # ---- checkpoint load / merge (vilt_module.py:270-295 and :345-364) -------------------------------------------
         if config["load_path"] != "":
-            ckpt = torch.load(config["load_path"], map_location="cpu")
+            from ... import checkpoint
+            ckpt = checkpoint.load_file(config["load_path"])
             eval_only = config["test_only"] or config["validation_only"]
-            if config["use_beit_weight"] or config["use_self_weight"]:
-                raise NotImplementedError("BEiT / self checkpoint adaptation is a 'next' row (SURVEY.md 8f-2)")
-            state_dict = ckpt["state_dict"] if eval_only else self.modify_checkpoint_vlmo(ckpt)
+            if config["use_beit_weight"]:
+                state_dict = self.modify_checkpoint_beit(ckpt)
+            elif config["use_self_weight"]:
+                state_dict = self.modify_checkpoint_self(ckpt)
+            else:
+                state_dict = ckpt["state_dict"] if eval_only else self.modify_checkpoint_vlmo(ckpt)
             if config["merge_weights"]:
                 state_dict = self.merge_weights(state_dict)
             elif config["sum_task_vectors"]:
@@ -359,6 +363,7 @@ class ViLTransformerSS(nn.Module):
     def _pass_ctx(self, *a, **k):
         pc = engine.PassCtx(*a, **k)
         pc.gram = getattr(self, "_gram", None)
+        pc.uniform_source = getattr(self, "droppath_uniform_source", None)
         return pc
 
     def _drop_sites(self, with_vlffn):

@@ -80,6 +80,44 @@ class FusedAdamW:
         self.v = torch.zeros_like(self.flat.flat_p)
         self.grad_scale = 1.0
         self.tail_sync = None
+        # HF AdamW skips parameters whose .grad is None (`if p.grad is None: continue`): tensors no pass of the current
+        # task set touches (deep v / l experts under VQA, vl experts under irtr, mask_token, position_embeddings ...)
+        # get neither an Adam update nor weight decay and stay bit-constant.  Here every gradient lives in the flat
+        # buffer, so "has a gradient" is discovered once per task set from the first step's (all-reduced) gradients:
+        # a tensor whose slice is entirely zero after backward was not reached.  Once reached a tensor stays active
+        # (torch keeps a zeroed .grad after zero_grad()).
+        self._group_of = {}
+        for gi, g in enumerate(groups):
+            for lo, hi in g["ranges"]:
+                for n in self.flat.names:
+                    o, _ = self.flat.offsets[n]
+                    if lo <= o < hi:
+                        self._group_of[n] = gi
+        self._all_ranges = [list(g["ranges"]) for g in groups]
+        self._active = set()
+        self._active_key = None
+
+    def _discover_active(self):
+        """Re-derive each group's ranges from the parameters that have received a gradient so far."""
+        f = self.flat
+        # one device pass: per-parameter max |g| through a segmented reduction over the flat buffer
+        starts = torch.tensor([f.offsets[n][0] for n in f.names], device=f.flat_g.device)
+        bounds = torch.cat([starts, torch.tensor([f.numel], device=starts.device)])
+        seg = torch.bucketize(torch.arange(f.numel, device=starts.device), bounds[1:], right=True)
+        mx = torch.zeros(len(f.names), device=starts.device, dtype=f.flat_g.dtype)
+        mx.scatter_reduce_(0, seg, f.flat_g[:f.numel].abs(), reduce="amax", include_self=True)
+        hit = (mx > 0).cpu().tolist()
+        self._active |= {n for n, h in zip(f.names, hit) if h}
+        per_group = [[] for _ in self.param_groups]
+        for n in f.names:
+            if n in self._active and n in self._group_of:
+                o, _ = f.offsets[n]
+                per_group[self._group_of[n]].append((o, o + f.extent[n]))
+        for g, r in zip(self.param_groups, per_group):
+            g["ranges"] = _merge_ranges(r)
+
+    def inactive_parameters(self):
+        return [n for n in self.flat.names if n not in self._active]
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -88,6 +126,12 @@ class FusedAdamW:
         self.step_count += 1
         engine.sync_wgrad()
         f = self.flat
+        key = tuple(getattr(self.model, "current_tasks", ()))
+        if key != self._active_key:
+            if self.tail_sync is not None:
+                self.tail_sync[2]()      # discovery reads the whole gradient buffer: every all-reduce must have landed
+            self._discover_active()
+            self._active_key = key
 
         def update(g, lo, hi):
             ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], f.flat_b[lo:hi],
