@@ -3,9 +3,10 @@ fp32 oracle on the same deterministic weights and batch.
 
 Stated tolerance (north star: "fp within a stated tol for attention/FFN"): activations are rounded to bf16 between
 kernels (8 significant bits, like the reference's fp16 AMP path rounds to 11), so
-   features after 12 blocks : max |err| <= 3e-2 * max|ref|
-   logits / losses          : |err| <= 3e-2 (absolute, values are O(1..10))
-   parameter-gradient norms : relative error <= 6e-2 per tensor (bf16 operands of the wgrad GEMMs)
+   features after 12 blocks : max |err| <= 2e-2 * max|ref|   (measured: <= 1.0e-2 at base width, <= 0.7e-2 at tiny width)
+   logits                   : max |err| <= 3e-2 * max|ref|   (measured: <= 1.9e-2, the B = 3 contrastive logits)
+   losses                   : |err| <= 3e-2 (absolute, values are O(1..10))
+   parameter-gradient norms : relative error <= 4e-2 per tensor (measured: <= 1.3e-2; bf16 operands of the wgrad GEMMs)
 """
 import importlib
 import json
@@ -51,15 +52,18 @@ def gpu_batch(nb):
 
 
 def grad_norm_ok(got, ref):
-    """6 % per tensor.  Tensors with a small gradient (norm <= 0.05: here those fed only by the B=2 contrastive
+    """4 % per tensor (measured at base width: max 1.3 %, median 0.1 %).  Gradients whose norm is below 2.5e-4 in
+    absolute terms (logit_vl_scale at B = 2: 3.9e-5) are below the noise floor of ANY reduced-precision path: the
+    reference's own fp16-autocast run moves that one by 114 % (tests/golden/amp_reference_errors.json).
+    Tensors with a small gradient (norm <= 0.05: here those fed only by the B=2 contrastive
     losses, i.e. by the DIFFERENCE of two nearly identical L2-normalised features scaled by exp(logit_scale) ~ 14,
     ill-conditioned in any 8-bit-mantissa activation format, and run-to-run sensitive to the order of the fp32 atomic
     accumulations) get 20 %; near-zero scalar gradients an absolute 1e-4."""
     rel = abs(got - ref) / (ref + 1e-12)
-    return rel <= 6e-2 or (ref <= 0.05 and rel <= 0.20) or abs(got - ref) <= 1e-4
+    return rel <= 4e-2 or (ref <= 0.05 and rel <= 0.20) or abs(got - ref) <= 2.5e-4
 
 
-def feat_close(got, ref, what, tol=3e-2):
+def feat_close(got, ref, what, tol=2e-2):
     got = got.float().cpu()
     ref = torch.as_tensor(ref)
     err = float((got - ref).abs().max())
@@ -109,7 +113,7 @@ def test_training_step_matches_reference_golden(mods, golden_dir, arch):
     for k in ("mlm_loss", "ifm_loss", "itm_loss"):
         assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
     assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
-    feat_close(ret["mlm_logits"], gold["step/mlm_logits"], "mlm logits")
+    feat_close(ret["mlm_logits"], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
     feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
     gs = json.loads(str(gold["step/grad_summary"]))
     named = dict(model.named_parameters())
@@ -144,7 +148,7 @@ def test_irtr_matches_reference_golden(mods, golden_dir, arch):
     ret = model(batch)
     ret["irtr_loss"].backward()
     assert abs(float(ret["irtr_loss"]) - float(gold["irtr_loss"])) <= 2e-2
-    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits")
+    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits", tol=3e-2)
     gs = json.loads(str(gold["grad_summary"]))
     named = dict(model.named_parameters())
     bad = [(n, float(named[n].grad.double().norm()), v[0]) for n, v in gs.items()
@@ -331,10 +335,10 @@ def test_planned_droppath_sites(mods):
 # CPU by make_golden.py model_base -> tests/golden/amp_reference_errors.json) deviates from its fp32 path on the same
 # quantities at this width:
 #   quantity                                 fp16-autocast reference    this engine's bound
-#   features (max err / max |ref|)           <= 1.7e-3                  3e-2
+#   features (max err / max |ref|)           <= 1.7e-3                  2e-2   (measured <= 1.0e-2)
 #   losses (absolute)                        <= 6e-4                    3e-2 (total 5e-2)
-#   logits (max err / max |ref|)             <= 1e-3                    3e-2 (itm 5e-2)
-#   gradient norm per tensor, norm > 0.05    <= 0.5 %  (median 5e-5)    6 %
+#   logits (max err / max |ref|)             <= 1e-3                    3e-2 (itm 5e-2; measured <= 1.1e-2)
+#   gradient norm per tensor, norm > 0.05    <= 0.5 %  (median 5e-5)    4 %    (measured max 1.3 %, median 0.1 %)
 #   gradient norm per tensor, norm <= 0.05   up to 6 % (ufo) / 114 % (all_moe: the near-zero contrastive gradients)   20 %
 # fp16 keeps 11 significant bits, the engine's bf16 activations 8 (8x coarser per rounding), and the engine rounds
 # between every pair of kernels where autocast only rounds GEMM operands; what the engine actually reaches is written
@@ -425,9 +429,9 @@ def test_base_width_matches_reference_golden(mods, golden_dir, arch):
     for k in ("mlm_loss", "ifm_loss", "itm_loss"):
         assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
     assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
-    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits")
+    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
     feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
-    feat_close(ret["ifm_i2t_logits"], gold["step/ifm_i2t_logits"], "ifm logits")
+    feat_close(ret["ifm_i2t_logits"], gold["step/ifm_i2t_logits"], "ifm logits", tol=3e-2)
     check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))
     named = dict(model.named_parameters())
     for key in gold.files:
@@ -439,7 +443,7 @@ def test_base_width_matches_reference_golden(mods, golden_dir, arch):
                 got = got[::8]
             err = float((got - ref).abs().max())
             mx = float(ref.abs().max())
-            floor = 1e-4 if ref.numel() == 1 else 1e-6
+            floor = 2.5e-4 if ref.numel() == 1 else 1e-6  # near-zero scalar gradients: see grad_norm_ok
             assert err <= (0.2 if mx <= 0.05 else 0.15) * mx + floor, (n, err, mx)
 
 
@@ -480,7 +484,7 @@ def test_irtr_on_merged_weights_base_width(mods, golden_dir):
     ret["irtr_loss"].backward()
     torch.cuda.synchronize()
     assert abs(float(ret["irtr_loss"]) - float(gold["irtr_loss"])) <= 2e-2
-    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits")
+    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits", tol=3e-2)
     with torch.no_grad():
         feat_close(model.infer_image_ft(batch)["cls_feats"], gold["img_cls_feats"], "img cls")
         feat_close(model.infer_text_ft(batch)["cls_feats"], gold["txt_cls_feats"], "txt cls")
@@ -526,8 +530,21 @@ def test_full_size_step_properties(mods, golden_dir, arch, B, losses):
             want = R.infer(osd, R.Arch(arch), oidx, sub["text_ids"], sub["text_masks"], sub["image"])
             feat_close(got["text_feats"][pick], want["text_feats"], "text_feats of samples 0 / B-1")
             feat_close(got["image_feats"][pick], want["image_feats"], "image_feats of samples 0 / B-1")
-    # (2) + (3) two train-mode steps
+    # (2) + (3) three train-mode steps (constant lr: the configs' warm-up starts at lr = 0), judged by the deterministic
+    # eval-mode loss of the same batch before and after (mlm for pre-training: no sampled negatives in it)
+    probe = "irtr_loss" if irtr else "mlm_loss"
+
+    def eval_loss():
+        model.eval()
+        mods[1].vilt_utils.set_task(model)
+        with torch.no_grad():
+            out = model(batch if irtr else {"vl": batch})
+        model.train()
+        return float(out[probe])
+
+    loss_before = eval_loss()
     model.train()
+    model.hparams.config["warmup_steps"] = 0
     (opt,), (sch,) = mods[1].vilt_utils.set_schedule(model, max_steps=100)
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     losses_seen = []
@@ -542,7 +559,8 @@ def test_full_size_step_properties(mods, golden_dir, arch, B, losses):
         losses_seen.append(float(loss))
     torch.cuda.synchronize()
     assert all(np.isfinite(losses_seen)), losses_seen
-    assert losses_seen[-1] < losses_seen[0], losses_seen
+    loss_after = eval_loss()
+    assert loss_after < loss_before, (probe, loss_before, loss_after, losses_seen)
     assert all(np.isfinite(v) for v in gn.values())
     used = [n for n, v in gn.items() if v > 0]
     unused = [n for n, v in gn.items() if v == 0]
@@ -617,6 +635,6 @@ def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
     assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
     eval_gold = np.load(os.path.join(golden_dir, f"model_tiny_{arch}.npz"))
     assert abs(float(gold["step/total_loss"]) - float(eval_gold["step/total_loss"])) > 1e-3
-    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits")
+    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
     feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
     check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))
