@@ -28,7 +28,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 2
+#define VLM_ABI_VERSION 3
 int vlm_abi_version(void);
 /* Number of compute units of the current device (grid sizing), or negative error. */
 int vlm_device_cus(void);
@@ -201,7 +201,7 @@ int vlm_accumulate_f32_f64(const float* src, double* dst_f64, uint64_t n, void* 
  *             orientation whose fast axis runs along its lanes, so every index load is a coalesced 64-B row piece;
  *             the forward reads only rel_index_t): 4 x relative-position index (= byte offset into the fp32 table column,
  *             R <= 8191) in "index coordinates": text token t is position t, image token i is position pos1 + i
- *             (pos1 % 4 == 0, ld_index % 4 == 0).
+ *             (pos1 % 8 == 0, ld_index % 4 == 0).
  *   keep0/1   uint8 [B, n0] / [B, n1] key keep flags (text_masks; NULL = keep all), masked_fill(-inf) of :354.
  *   rows      segment-major: text (b,t) -> base0 + b*n0 + t ; image (b,i) -> base1 + b*n1 + i.
  *   mode      JOINT: every query sees text then image keys.  SEPARATE: queries see their own segment only.
@@ -232,18 +232,26 @@ typedef struct {
   int32_t B, n0, n1, base0, base1, pos1;
   float scale;
   int32_t reserved;
-  /* Optional dense bias (vlm_bias_dense): fp16 [n_cols, index_rows, ld_index] = log2(e) * bias_t[c][rel_index[q][k]/4]
-   * and the same for the transposed index.  When set, the forward / dQ / dK-dV kernels read the (layer, head) slice
-   * [head_row0 + h] directly (same 8-byte loads as the index tiles, no LDS gather: the bias is identical for every
-   * sample of the batch, so 9 MB per layer stay cache-resident); the bias-table gradient still uses the index. */
+  /* Dense bias (vlm_bias_dense), REQUIRED when bias_t is set: fp16 log2(e) * bias_t[c][rel_index[q][k]/4] (the
+   * kernels' score accumulators are base-2 exponents) for every (layer, head) column c, stored as 4-KiB tiles in MFMA operand order (one tile
+   * per 32 stationary x 64 streamed positions, vlm_bias_dense_bytes() per column); positions that are not valid
+   * members of a tile's segment hold a large negative value, so ragged tiles, the text/image gap and -- in SEPARATE
+   * mode -- the foreign segment mask themselves.  bias_dense: stationary = query (forward, dQ); bias_dense_t:
+   * stationary = key (dK/dV).  The tables depend on (n0, n1, pos1, mode); the kernels add the slice
+   * [head_row0 + h] to the score accumulators on the matrix pipe.  The bias is identical for every sample of the
+   * batch, so a layer's slices stay cache-resident.  The bias-table GRADIENT still goes through rel_index. */
   const void* bias_dense;
   const void* bias_dense_t;
+  int32_t dense_tiles; /* vlm_bias_dense_bytes(n0, n1, pos1, mode) / 4096 */
+  int32_t reserved2;
 } vlm_attn_desc_t;
 
 /* Dense relative-position bias for all heads and layers at once (the reference's get_rel_pos_bias,
- * modules/vilt_module.py:1061-1064, in fp16 and pre-multiplied by log2 e): out[c][r][k] for c < n_cols. */
-int vlm_bias_dense(const float* bias_t, int n_cols, int R, const int16_t* index, int ld_index, int index_rows,
-                   void* out_f16, void* stream);
+ * modules/vilt_module.py:1061-1064): out = n_cols columns of vlm_bias_dense_bytes() each.  index: int16 [pos1 + n1,
+ * ld_index] relative-position index (4 x index, as in vlm_attn_desc_t.rel_index); k_major selects bias_dense_t. */
+size_t vlm_bias_dense_bytes(int n0, int n1, int pos1, int mode);
+int vlm_bias_dense(const float* bias_t, int n_cols, int R, const int16_t* index, int ld_index, int n0, int n1, int pos1,
+                   int mode, int k_major, void* out_f16, void* stream);
 
 int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out_bf16, int ld_out, float* lse, void* stream);
 /* Optional fused bias gradients: dq[s] / dv[s] (f32 [H*64], may be NULL) are ACCUMULATED with the column sums of dQ /

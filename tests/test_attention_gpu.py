@@ -26,7 +26,7 @@ def build_case(B, n0, n1, H, seed, with_bias=True, with_mask=True):
     D = H * 64
     rows = B * (n0 + n1)
     qkv = (torch.randn(rows, 3 * D, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
-    pos1 = (n0 + 3) // 4 * 4
+    pos1 = (n0 + 7) // 8 * 8
     NP = pos1 + n1
     ld = (NP + 3) // 4 * 4
     R = 300
@@ -124,7 +124,9 @@ def test_attention_fwd(ops, L, ci, sep, with_bias):
     assert bool((err <= tol).all()), "max err %.4g" % float(err.max())
     # lse (log2 domain) against the reference's logsumexp
     ref_lse = from_seq(torch.logsumexp(s, -1).permute(0, 2, 1), c).t() * 1.4426950408889634
-    assert torch.allclose(lse, ref_lse, rtol=1e-4, atol=2e-3)
+    # the kernel multiplies Q by scale*log2(e) before the MFMA (one more bf16 rounding of q: 2^-9 relative on scores of
+    # magnitude <= ~20 here) and adds the bias as fp16(bias*log2 e)
+    assert torch.allclose(lse, ref_lse, rtol=1e-3, atol=3e-2)
 
 
 @pytest.mark.parametrize("ci", range(len(CASES)))
@@ -183,35 +185,42 @@ def test_attention_bwd(ops, L, ci, sep, with_bias):
 
 @pytest.mark.parametrize("ci", range(len(CASES)))
 @pytest.mark.parametrize("sep", [False, True])
-def test_attention_dense_bias_matches_gather(ops, L, ci, sep):
-    """Dense fp16 bias mode (vlm_bias_dense + BIAS == 2 kernels) against the LDS-gather mode on the same inputs: same
-    scores up to the fp16 rounding of the bias (2^-11 relative), i.e. well inside the bf16 tolerance of the outputs;
-    and the dense matrix itself against table[index] * log2(e)."""
-    c = build_case(seed=300 + ci * 10 + sep, with_bias=True, **CASES[ci])
-    seq = ops.Seq(c["B"], c["n0"], c["n1"])
-    rows, H, D = seq.rows, c["H"], c["D"]
-    layer = 1
+def test_bias_dense_tables(ops, L, ci, sep):
+    """vlm_bias_dense: fp16 table[index] * log2(e) in the tiled MFMA-operand order documented in attention_common.h
+    (one 4-KiB tile per 32 stationary x 64 streamed positions: [blk][j][lane][8]), both orientations; positions that
+    are not members of the tile's segment (gap, past the end, SEPARATE: the other segment) hold a large negative value."""
+    c = build_case(seed=300 + ci * 10, with_bias=True, **CASES[ci])
     bias_t = c["table"].t().contiguous()
-    idx, idx_t = (c["idx"] * 4).contiguous(), make_idx_t(c).contiguous()
-    dense = (ops.bias_dense(bias_t, idx), ops.bias_dense(bias_t, idx_t))
-    want = bias_t[:, (idx.long() >> 2).clamp_(0, bias_t.shape[1] - 1)] * 1.4426950408889634
-    assert torch.allclose(dense[0].float(), want, rtol=1e-3, atol=1e-4)
+    idx = (c["idx"] * 4).contiguous()
+    n0, n1, pos1 = c["n0"], c["n1"], c["pos1"]
+    NP = pos1 + n1
+    seq = ops.Seq(c["B"], n0, n1)
     mode = L.ATTN_SEPARATE if sep else L.ATTN_JOINT
-    g = torch.Generator(device="cuda"); g.manual_seed(11 + ci)
-    dout = torch.randn(rows, D, device="cuda", generator=g).to(torch.bfloat16)
-    res = []
-    for bd in (None, dense):
-        kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=idx, rel_index_t=idx_t, keep0=c["keep0"], mode=mode,
-                  bias_dense=bd)
-        out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
-        lse = torch.empty(H, rows, device="cuda")
-        ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
-        dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
-        dbias_t = torch.zeros_like(bias_t)
-        ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
-        res.append((out.float(), lse, dqkv.float(), dbias_t))
-    (o0, l0, d0, b0), (o1, l1, d1, b1) = res
-    assert float((o0 - o1).abs().max()) <= 2e-2 * float(o0.abs().max()) + 1e-3
-    assert torch.allclose(l0, l1, rtol=1e-3, atol=5e-3)
-    assert float((d0 - d1).abs().max()) <= 2e-2 * float(d0.abs().max()) + 1e-3
-    assert float((b0 - b1).abs().max()) <= 2e-2 * float(b0.abs().max()) + 1e-3
+    d = ops.bias_dense(bias_t, idx, seq, mode)
+    if sep:
+        parts = [(0, n0, (n0 + 127) // 128 * 4, (n0 + 63) // 64), (pos1, NP, (n1 + 127) // 128 * 4, (n1 + 63) // 64)]
+    else:
+        parts = [(0, NP, (NP + 127) // 128 * 4, (NP + 63) // 64)]
+    assert d.tiles == sum(nsb * nst for _, _, nsb, nst in parts)
+    full = bias_t[:, (idx[:NP, :NP].long() >> 2)] * 1.4426950408889634   # [cols, q, k]
+    lane = torch.arange(64, device="cuda")
+    for got, k_major in ((d.q_major, False), (d.k_major, True)):
+        t = got.view(bias_t.shape[0], d.tiles, 2, 2, 64, 8).float()
+        first = 0
+        for org, lim, nsb, nst in parts:
+            for sb in range(nsb):
+                for st in range(nst):
+                    tile = t[:, first + sb * nst + st]                                  # [cols, blk, j, lane, e]
+                    s_pos = org + 32 * sb + (lane & 31)                                   # [64]
+                    blk, j, e = torch.meshgrid(torch.arange(2), torch.arange(2), torch.arange(8), indexing="ij")
+                    t_pos = (org + 64 * st + 32 * blk[..., None] + 16 * (lane >> 5).cpu()[None, None, None, :]
+                             + 8 * j[..., None] + e[..., None]).permute(0, 1, 3, 2).cuda()  # [blk, j, lane, e]
+                    sp = s_pos[None, None, :, None].expand_as(t_pos)
+
+                    def member(p_):
+                        return (p_ >= org) & (p_ < lim) & ((p_ < n0) | (p_ >= pos1)) & (p_ < NP)
+                    ok = member(sp) & member(t_pos)
+                    q, k = (t_pos, sp) if k_major else (sp, t_pos)
+                    want = torch.where(ok[None], full[:, q.clamp(0, NP - 1), k.clamp(0, NP - 1)], torch.full((), -30000.0, device="cuda"))
+                    assert torch.allclose(tile, want, rtol=1e-3, atol=1e-3), (k_major, sb, st)
+            first += nsb * nst

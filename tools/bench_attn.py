@@ -26,7 +26,7 @@ def timeit(fn, n=10):
 
 
 def main():
-    B, T, I, H = 22, 40, 577, 12
+    B, T, I, H = int(sys.argv[1]) if len(sys.argv) > 1 else 22, 40, 577, 12
     D = H * 64
     idx, nrel, _, allrel = vm.build_relative_position_indices((24, 24), 40, 196, 40)
     for name, n0, n1, index in (("joint", T, I, idx["text_imag_relative_position_index"]),
@@ -47,8 +47,8 @@ def main():
         for mode, mname in ((L.ATTN_JOINT, "joint"), (L.ATTN_SEPARATE, "sep")):
             if n0 == 0 and mode == L.ATTN_SEPARATE:
                 continue
-            dense = (ops.bias_dense(bias_t, m), ops.bias_dense(bias_t, mt))
-            for wb in (True, "dense", False):
+            dense = ops.bias_dense(bias_t, m, seq, mode)
+            for wb in ("dense", False):
                 kw = dict(bias_t=bias_t if wb else None, head_row0=12, rel_index=m if wb else None,
                           rel_index_t=mt if wb else None, mode=mode, bias_dense=dense if wb == "dense" else None)
                 f = timeit(lambda: ops.attention_fwd(qkv, out, lse, seq, H, **kw))

@@ -59,7 +59,7 @@ class AttnDesc(ctypes.Structure):
         ("keep0", c_void_p), ("keep1", c_void_p),
         ("B", ctypes.c_int32), ("n0", ctypes.c_int32), ("n1", ctypes.c_int32), ("base0", ctypes.c_int32),
         ("base1", ctypes.c_int32), ("pos1", ctypes.c_int32), ("scale", c_float), ("reserved", ctypes.c_int32),
-        ("bias_dense", c_void_p), ("bias_dense_t", c_void_p),
+        ("bias_dense", c_void_p), ("bias_dense_t", c_void_p), ("dense_tiles", ctypes.c_int32), ("reserved2", ctypes.c_int32),
     ]
 
 
@@ -94,7 +94,9 @@ SIGNATURES = {
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "vlm_accumulate_f32_f64": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
-    "vlm_bias_dense": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_bias_dense_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vlm_bias_dense": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                               c_void_p]),
     "vlm_transpose_bf16_tiles": (c_int, [c_void_p, c_int, c_void_p]),
     "vlm_droppath_sites": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p]),

@@ -622,7 +622,7 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   const size_t smem_db = 4 * ATT_TILE_BYTES + 2 * 4096 + 256 + Rp * 4;  // histogram aliases the K/V tiles (R*4 <= 32 KiB)
   if (smem_dq > 160 * 1024 || smem_dkv > 160 * 1024) return VLM_ERR_UNSUPPORTED;
   if (p.bias_t) {
-    const bool dense = p.dense && p.dense_t;
+    const bool dense = false;  // the round-1 backward kernels gather through the index (dense tables changed format)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<1>),

@@ -12,6 +12,12 @@
 // raw v_exp_f32 (2^x): libm's exp2f adds a denormal-range select/scale (5 instructions per call); scores that far
 // below the row maximum contribute 0 either way
 #define att_exp2(x) __builtin_amdgcn_exp2f(x)
+// one v_max3_f32 (fmaxf(fmaxf(a, b), c) on MFMA outputs makes hipcc insert canonicalising v_max in front)
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 // bias-table gather: the relative-position index is stored PRE-MULTIPLIED by 4 (byte offset into the LDS column)
 __device__ __forceinline__ float att_tab(const float* tab, uint32_t byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(tab) + byte_off);
@@ -53,8 +59,9 @@ struct attn_params_t {
   int ld_idx, idx_rows;
   const int16_t* idx_t;  // [k][q]
   int ld_idx_t, idx_t_rows;
-  const _Float16* dense;    // [n_cols][idx_rows][ld_idx] log2e * bias, or NULL
-  const _Float16* dense_t;  // [n_cols][idx_t_rows][ld_idx_t]
+  const _Float16* dense;    // tiled bias / scale (fp16, att_dense_layout), stationary = query; or NULL
+  const _Float16* dense_t;  // stationary = key
+  int dense_tiles;          // 4-KiB tiles per (layer, head) column
   const uint8_t* keep0;
   const uint8_t* keep1;
   attn_seq_t seq;
@@ -65,8 +72,9 @@ struct attn_params_t {
 static inline int att_fill_params(const vlm_attn_desc_t* d, attn_params_t& p) {
   if (!d || !d->qkv || d->H <= 0 || d->B < 0 || d->n0 < 0 || d->n1 < 0) return VLM_ERR_ARG;
   if ((d->ld_qkv & 7) || ((uintptr_t)d->qkv & 15)) return VLM_ERR_ARG;
-  if (d->bias_t && (!d->rel_index || d->R <= 0 || (d->ld_index & 3) || (d->pos1 & 3) || ((uintptr_t)d->rel_index & 7)))
+  if (d->bias_t && (!d->rel_index || d->R <= 0 || (d->ld_index & 3) || ((uintptr_t)d->rel_index & 7)))
     return VLM_ERR_ARG;
+  if ((d->pos1 & 7) || d->pos1 < d->n0) return VLM_ERR_ARG;  // image positions start at a multiple of 8 (16-B bias rows)
   if (d->mode != VLM_ATTN_JOINT && d->mode != VLM_ATTN_SEPARATE) return VLM_ERR_ARG;
   if (d->R > 8191) return VLM_ERR_UNSUPPORTED;  // int16 byte offsets (4*index), LDS-resident bias column
   p.qkv = reinterpret_cast<const bf16_t*>(d->qkv);
@@ -87,7 +95,8 @@ static inline int att_fill_params(const vlm_attn_desc_t* d, attn_params_t& p) {
   p.idx_t_rows = d->index_t_rows;
   p.dense = d->bias_t ? reinterpret_cast<const _Float16*>(d->bias_dense) : nullptr;
   p.dense_t = d->bias_t ? reinterpret_cast<const _Float16*>(d->bias_dense_t) : nullptr;
-  if ((p.dense && ((uintptr_t)p.dense & 7)) || (p.dense_t && ((uintptr_t)p.dense_t & 7))) return VLM_ERR_ARG;
+  p.dense_tiles = d->dense_tiles;
+  if ((p.dense && ((uintptr_t)p.dense & 15)) || (p.dense_t && ((uintptr_t)p.dense_t & 15))) return VLM_ERR_ARG;
   p.keep0 = d->keep0;
   p.keep1 = d->keep1;
   p.seq = (attn_seq_t){d->B, d->n0, d->n1, d->base0, d->base1, d->pos1};
@@ -229,4 +238,197 @@ __device__ __forceinline__ void att_stage_store(const att_stage_t& st, unsigned 
   att_tile_store_rows(st.k, ldsK, tid);
   att_tile_store_tr(st.v, ldsV, tid);
   if (tid < 64) kmask[tid] = st.mask;
+}
+
+
+// =====================================================================================================================
+// Round-2 kernels: everything below works in POSITION space (the coordinates of the relative-position index): text
+// token t sits at position t, image token i at pos1 + i (pos1 = roundup(n0, 8)), NP = pos1 + n1 positions in all.
+// The additive bias enters the score accumulators through the MATRIX pipe (v_mfma_f32_32x32x16_f16: fp16 keeps 11
+// significant bits of the bias, and the selection operand's 1.0 is exact): the dense table holds bias * log2(e) in fp16
+// ([q][k] and [k][q] orientations, rows and columns padded with ATT_NEG_BIG so that ragged tiles mask themselves), a
+// lane loads 32 contiguous bytes of its own row per 32-position block and two MFMAs against constant selection
+// fragments add them to the 32x32 accumulator -- no unpack, no per-element add on the vector pipe, which is the
+// bottleneck of head-dim-64 attention (exp + max + sum already cost more issue cycles than the QK^T / PV MFMAs).
+#define ATT_NEG_BIG (-30000.0f)
+
+struct att_pos_t {
+  int n0, n1, pos1, NP, base0, base1, B;
+};
+
+__device__ __forceinline__ att_pos_t att_pos(const attn_seq_t& sq) {
+  att_pos_t ps;
+  ps.n0 = sq.n0; ps.n1 = sq.n1; ps.pos1 = sq.pos1; ps.NP = sq.pos1 + sq.n1; ps.base0 = sq.base0; ps.base1 = sq.base1;
+  ps.B = sq.B;
+  return ps;
+}
+// activation row of position p of sample b, or -1 for a gap / out-of-range position
+__device__ __forceinline__ int att_row_of(const att_pos_t& ps, int b, int p) {
+  if (p < ps.n0) return ps.base0 + b * ps.n0 + p;
+  if (p >= ps.pos1 && p < ps.NP) return ps.base1 + b * ps.n1 + (p - ps.pos1);
+  return -1;
+}
+// The stationary tile of a workgroup (queries in forward / dQ, keys in dK-dV) and the position range it interacts with
+struct att_span_t {
+  int p0;      // first position of the workgroup's 128 stationary positions
+  int s_lo, s_hi;  // streamed positions [s_lo, s_hi): all of them (JOINT) or the stationary segment's own (SEPARATE)
+  int part, tile_in_part;  // dense-table part (att_dense_layout) and the 128-position tile's index inside it
+};
+__device__ __forceinline__ att_span_t att_span(const att_pos_t& ps, int mode, int tile) {
+  att_span_t sp;
+  if (mode == VLM_ATTN_SEPARATE) {
+    const int nt0 = (ps.n0 + ATT_BQ - 1) / ATT_BQ;
+    if (tile < nt0) { sp.p0 = tile * ATT_BQ; sp.s_lo = 0; sp.s_hi = ps.n0; sp.part = 0; sp.tile_in_part = tile; }
+    else { sp.p0 = ps.pos1 + (tile - nt0) * ATT_BQ; sp.s_lo = ps.pos1; sp.s_hi = ps.NP; sp.part = 1; sp.tile_in_part = tile - nt0; }
+  } else {
+    sp.p0 = tile * ATT_BQ; sp.s_lo = 0; sp.s_hi = ps.NP; sp.part = 0; sp.tile_in_part = tile;
+  }
+  return sp;
+}
+// ---- tiled dense bias ------------------------------------------------------------------------------------------------
+// One 4-KiB tile per (stationary block of 32 positions, streamed tile of 64 positions), stored in MFMA operand order
+// [blk 0..1][j 0..1][lane 0..63][8 x fp16]: lane (c = lane & 31, hh = lane >> 5) of operand (blk, j) holds the bias of
+// stationary position s0 + c against streamed positions t0 + 32*blk + 16*hh + 8*j + 0..7.  A wave's four bias loads
+// of a tile are therefore four fully coalesced 1-KiB reads (per-lane row reads of a row-major table cost the CU's
+// address path 32 cache lines per instruction and bound the round-1 kernels).  Entries whose stationary or streamed
+// position is not a valid member of the tile's segment hold ATT_NEG_BIG: ragged tiles, the gap between text and image
+// positions and (SEPARATE) the foreign segment mask themselves.
+// Tile order inside a (layer, head) column: JOINT: [sb][st] over all positions from 0; SEPARATE: the text segment's
+// [sb][st] (origin 0) followed by the image segment's (origin pos1).
+struct att_dense_layout_t {
+  int nsb[2], nst[2];  // stationary blocks / streamed tiles of part 0 (JOINT: everything; SEPARATE: text) and part 1
+  int org[2];          // first position of each part
+  int lim[2];          // one past the last valid position of each part
+  int tiles;           // per column
+};
+static inline __host__ __device__ att_dense_layout_t att_dense_layout(int n0, int n1, int pos1, int mode) {
+  att_dense_layout_t L;
+  const int NP = pos1 + n1;
+  if (mode == VLM_ATTN_SEPARATE) {
+    L.org[0] = 0; L.lim[0] = n0; L.nsb[0] = (n0 + ATT_BQ - 1) / ATT_BQ * 4; L.nst[0] = (n0 + ATT_BK - 1) / ATT_BK;
+    L.org[1] = pos1; L.lim[1] = NP; L.nsb[1] = (n1 + ATT_BQ - 1) / ATT_BQ * 4; L.nst[1] = (n1 + ATT_BK - 1) / ATT_BK;
+  } else {
+    L.org[0] = 0; L.lim[0] = NP; L.nsb[0] = (NP + ATT_BQ - 1) / ATT_BQ * 4; L.nst[0] = (NP + ATT_BK - 1) / ATT_BK;
+    L.org[1] = 0; L.lim[1] = 0; L.nsb[1] = 0; L.nst[1] = 0;
+  }
+  L.tiles = L.nsb[0] * L.nst[0] + L.nsb[1] * L.nst[1];
+  return L;
+}
+static inline __host__ __device__ int att_num_tiles(int n0, int n1, int pos1, int mode) {
+  if (mode == VLM_ATTN_SEPARATE) return (n0 + ATT_BQ - 1) / ATT_BQ + (n1 + ATT_BQ - 1) / ATT_BQ;
+  return (pos1 + n1 + ATT_BQ - 1) / ATT_BQ;
+}
+
+// XCD-aware work order.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own 4 MiB
+// L2): id -> (xcd = id % 8, slot = id / 8) is remapped so that every XCD walks ONE contiguous range of the logical
+// order (tile fastest, then sample, then head).  The 4-5 stationary tiles of a (sample, head) then share their streamed
+// K/V (or Q/dO) through one L2, and an XCD needs one head's bias slice (0.8 MB) at a time instead of all twelve.
+// Returns false for the few padding ids past the end.
+__device__ __forceinline__ bool att_work_item(int n_tiles, int B, int H, int& tile, int& b, int& h) {
+  const int total = n_tiles * B * H;
+  const int per = (total + 7) >> 3;
+  const int id = blockIdx.x, logical = (id & 7) * per + (id >> 3);
+  if ((id >> 3) >= per || logical >= total) return false;
+  tile = logical % n_tiles;
+  const int rest = logical / n_tiles;
+  b = rest % B;
+  h = rest / B;
+  return true;
+}
+static inline int att_grid_size(int n_tiles, int B, int H) { return ((n_tiles * B * H + 7) / 8) * 8; }
+
+// Constant A/B fragments of the two selection MFMAs: k-slot (hh, e) of MFMA #0 stands for position 16*hh + e of the
+// 32-position block, of MFMA #1 for 16*hh + 8 + e; lane (i = lane & 31) selects itself.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ void att_select_frags(int lane, f16x8& s0, f16x8& s1) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s0[e] = (_Float16)((r == 16 * hh + e) ? 1.0f : 0.0f);
+    s1[e] = (_Float16)((r == 16 * hh + 8 + e) ? 1.0f : 0.0f);
+  }
+}
+// acc[i][c] += bias(stationary position of lane c, streamed position i) for one 32-position block
+__device__ __forceinline__ f32x16 att_bias_mfma(const f16x8& s0, const f16x8& s1, const u32x4 (&w)[2], f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(s0, __builtin_bit_cast(f16x8, w[0]), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(s1, __builtin_bit_cast(f16x8, w[1]), acc, 0, 0, 0);
+}
+
+// One wave's bias operands for a 64-position streamed tile: four coalesced 1-KiB reads of the tiled table.
+// voff = byte offset of (this wave's stationary block, streamed tile 0) + lane * 16; the tile index rides in the scalar offset.
+struct att_bias_t {
+  u32x4 w[2][2];
+};
+__device__ __forceinline__ void att_bias_load(att_bias_t& bw, __amdgpu_buffer_rsrc_t mat, uint32_t voff, int st) {
+  const uint32_t soff = (uint32_t)st * 4096u;
+  bw.w[0][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff, soff, 0));
+  bw.w[0][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 1024, soff, 0));
+  bw.w[1][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 2048, soff, 0));
+  bw.w[1][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 3072, soff, 0));
+}
+// byte offset (inside a column) of stationary block `sb_in_part` of the part the workgroup's stationary tile lies in
+__device__ __forceinline__ uint32_t att_bias_voff(const att_dense_layout_t& L, int part, int sb_in_part, int lane) {
+  const uint32_t first = part ? (uint32_t)(L.nsb[0] * L.nst[0]) : 0u;
+  return (first + (uint32_t)sb_in_part * L.nst[part]) * 4096u + lane * 16;
+}
+
+// ---- LDS-DMA staging of [64 positions][64 bf16] tiles (8 pieces of 1 KiB, 2 per wave): the swizzles of the row image
+// (16-B chunk ^ (row & 7)) and of the transposed-read image (32-B chunk ^ ((row >> 1) & 1) << 1) live on the SOURCE
+// side; rows of invalid positions point past the buffer, so the hardware zero-fills them.
+// Per-lane byte offsets inside a tile are computed ONCE (att_dma_t); a tile made of 64 valid image positions -- all but
+// the first and the last tile of a pass -- then costs one LDS-DMA instruction per piece with the tile's first row in
+// the scalar offset, no vector arithmetic at all.
+typedef __attribute__((address_space(3))) void att_lds_void;
+struct att_dma_t {
+  uint32_t row[2];  // tile row of this lane's piece u
+  uint32_t off[2];  // (row * ld + swizzled chunk * 8) * 2, without the operand's column
+};
+template <bool TR>
+__device__ __forceinline__ att_dma_t att_dma_init(uint32_t ld, int wave, int lane) {
+  att_dma_t d;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t row = (wave * 2 + u) * 8 + (lane >> 3), c16 = lane & 7;
+    uint32_t chunk;
+    if (!TR) chunk = c16 ^ (row & 7);
+    else chunk = (((c16 >> 1) ^ (((row >> 1) & 1) << 1)) << 1) | (c16 & 1);
+    d.row[u] = row;
+    d.off[u] = (row * ld + chunk * 8) * 2;
+  }
+  return d;
+}
+// all 64 positions p0 .. p0+63 are image positions of sample b below p_hi: rows are consecutive
+__device__ __forceinline__ bool att_tile_plain(const att_pos_t& ps, int p0, int p_hi) {
+  return p0 >= ps.pos1 && p0 + ATT_BK <= p_hi && p_hi <= ps.NP;
+}
+__device__ __forceinline__ void att_dma_plain(__amdgpu_buffer_rsrc_t rsrc, unsigned char* tile, const att_dma_t& d,
+                                              const att_pos_t& ps, int b, int p0, uint32_t ld, uint32_t col, int wave) {
+  const uint32_t soff = ((uint32_t)(ps.base1 + b * ps.n1 + (p0 - ps.pos1)) * ld + col) * 2;  // wave-uniform
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (att_lds_void*)(tile + (wave * 2 + u) * 1024), 16, d.off[u], soff, 0, 0);
+}
+// any tile: per-row position -> row mapping through selects (text rows, gap, image rows, past the end)
+__device__ __forceinline__ void att_dma_any(__amdgpu_buffer_rsrc_t rsrc, unsigned char* tile, const att_dma_t& d,
+                                            const att_pos_t& ps, int b, int p0, int p_hi, uint32_t ld, uint32_t col, int wave) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int p = p0 + (int)d.row[u];
+    const bool txt = p < ps.n0, img = p >= ps.pos1 && p < ps.NP;
+    const bool ok = (txt || img) && p < p_hi;
+    const int first = txt ? ps.base0 + b * ps.n0 + p0 : ps.base1 + b * ps.n1 + (p0 - ps.pos1);  // row of the tile's row 0
+    const uint32_t off = ok ? ((uint32_t)first * ld + col) * 2 + d.off[u] : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (att_lds_void*)(tile + (wave * 2 + u) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// additive mask of streamed position p (key side): 0 keep, -inf drop
+__device__ __forceinline__ float att_key_mask(const att_pos_t& ps, int b, int p, int p_hi, const uint8_t* keep0,
+                                              const uint8_t* keep1) {
+  const bool txt = p < ps.n0, img = p >= ps.pos1 && p < ps.NP;
+  bool ok = (txt || img) && p < p_hi;
+  const uint8_t* kp = txt ? keep0 : keep1;
+  const size_t at = txt ? (size_t)b * ps.n0 + p : (size_t)b * ps.n1 + (p - ps.pos1);
+  if (ok && kp) ok = kp[at] != 0;
+  return ok ? 0.f : -INFINITY;
 }

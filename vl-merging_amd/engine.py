@@ -191,7 +191,17 @@ class RelPos:
         self.index = index16          # int16 [NP, ld]
         self.index_t = index16_t
         self.holder = holder          # _TableT ctx holder: accumulates d(bias_t)
-        self.dense = None             # (fp16 [H*L, NP, ld], same for the transposed index) or None: ops.bias_dense
+        self._dense = {}              # (n0, n1, pos1, mode) -> ops.DenseBias, built on first use inside the pass
+
+    def dense_for(self, seq, mode):
+        """Tiled fp16 bias of all layers and heads for this pass geometry and attention mode (2 launches, once per pass
+        and step): the attention kernels add their (layer, head) slice to the score accumulators on the matrix pipe."""
+        key = (seq.n0, seq.n1, seq.pos1, mode)
+        d = self._dense.get(key)
+        if d is None:
+            with torch.no_grad():
+                d = self._dense[key] = ops.bias_dense(self.bias_t.detach(), self.index, seq, mode)
+        return d
 
     @property
     def dbias_t(self):
@@ -219,14 +229,7 @@ def make_relpos(table, index16, index16_t):
     bias_t = _TableT.apply(table, holder)
     if torch.is_grad_enabled() and table.requires_grad:
         holder["dbias_t"] = torch.zeros_like(bias_t)
-    rp = RelPos(bias_t, index16, index16_t, holder)
-    if _DENSE_BIAS and bias_t.is_cuda:
-        # dense fp16 bias of all layers and heads for this index (2 launches per pass and step): the attention kernels
-        # then read their (layer, head) slice instead of gathering the LDS table through the index for every sample
-        with torch.no_grad():
-            b = bias_t.detach()
-            rp.dense = (ops.bias_dense(b, index16), ops.bias_dense(b, index16_t))
-    return rp
+    return RelPos(bias_t, index16, index16_t, holder)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -341,7 +344,7 @@ class GramCapture:
 # A/B switch for measurements: 0 = separate colsum launches, 1/2 = q/v bias inside the attention backward and fc1 bias
 # through the GELU-backward GEMM epilogue + fold workspace
 _DEFER_FOLD = os.environ.get("VLM_DEFER_FOLD", "1") != "0"
-_DENSE_BIAS = os.environ.get("VLM_DENSE_BIAS", "1") != "0"
+_DENSE_BIAS = True  # the attention kernels always read the dense table (round 2: bias enters through the matrix pipe)
 _FUSE_MODE = int(os.environ.get("VLM_FUSE_BIAS_GRADS", "2"))
 _FUSE_BIAS_GRADS = _FUSE_MODE != 0
 _FUSE_FC1_BIAS = _FUSE_MODE in (1, 2)  # through the fold workspace (mode 0: separate colsum launch)
@@ -410,7 +413,7 @@ class _BlockFn(torch.autograd.Function):
         ops.attention_fwd(qkv, o, lse, pc.seq, H, bias_t=bias_t, head_row0=plan.layer * H,
                           rel_index=rp.index if rp is not None else None,
                           rel_index_t=rp.index_t if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
-                          mode=plan.mode, bias_dense=rp.dense if rp is not None else None)
+                          mode=plan.mode, bias_dense=rp.dense_for(pc.seq, plan.mode) if rp is not None else None)
         x1 = torch.empty(M, D, device=dev, dtype=F32)
         y1 = torch.empty(M, D, device=dev, dtype=BF16)
         for r0, r1, e in plan.ranges:
@@ -499,7 +502,8 @@ class _BlockFn(torch.autograd.Function):
                           rel_index=rp.index if rp is not None else None,
                           rel_index_t=rp.index_t if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
                           mode=plan.mode, dbias_t=rp.holder.get("dbias_t") if rp is not None else None,
-                          dq_colsum=qb_grads, dv_colsum=vb_grads, bias_dense=rp.dense if rp is not None else None)
+                          dq_colsum=qb_grads, dv_colsum=vb_grads,
+                          bias_dense=rp.dense_for(pc.seq, plan.mode) if rp is not None else None)
         dx = torch.empty(M, D, device=dev, dtype=F32)
         for r0, r1, e in plan.ranges:
             rr = slice(r0, r1)

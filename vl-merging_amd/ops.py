@@ -265,7 +265,7 @@ class Seq:
         self.B, self.n0, self.n1 = B, n0, n1
         self.base0 = base0
         self.base1 = base0 + B * n0 if base1 is None else base1
-        self.pos1 = (n0 + 3) // 4 * 4 if pos1 is None else pos1
+        self.pos1 = (n0 + 7) // 8 * 8 if pos1 is None else pos1  # image positions start at a multiple of 8
 
     @property
     def rows(self):
@@ -306,30 +306,48 @@ def _attn_desc(qkv, seq, H, bias_t, head_row0, rel_index, rel_index_t, keep0, ke
     d.keep1 = keep1.data_ptr() if keep1 is not None else 0
     d.B, d.n0, d.n1, d.base0, d.base1, d.pos1 = seq.B, seq.n0, seq.n1, seq.base0, seq.base1, seq.pos1
     d.scale = scale
-    if bias_dense is not None and bias_t is not None:
-        dn, dt = bias_dense
-        L.require_cuda(dn, dt)
-        if dn.dtype != torch.float16 or dt.dtype != torch.float16 or rel_index is None \
-                or tuple(dn.shape[1:]) != tuple(rel_index.shape) or tuple(dt.shape[1:]) != tuple(rel_index_t.shape) \
-                or not dn.is_contiguous() or not dt.is_contiguous() or not rel_index.is_contiguous() \
-                or not rel_index_t.is_contiguous():
-            raise L.VlmError("bias_dense: (fp16 [n_cols, *rel_index.shape], fp16 [n_cols, *rel_index_t.shape]) from bias_dense()")
-        d.bias_dense, d.bias_dense_t = dn.data_ptr(), dt.data_ptr()
+    if bias_t is not None:
+        if bias_dense is None:
+            if rel_index is None:
+                raise L.VlmError("attention with a bias needs bias_dense (ops.bias_dense) or the int16 index")
+            bias_dense = globals()["bias_dense"](bias_t, rel_index, seq, mode)  # one-off callers (tests)
+        if not isinstance(bias_dense, DenseBias) or bias_dense.key != (seq.n0, seq.n1, seq.pos1, mode):
+            raise L.VlmError("bias_dense must come from ops.bias_dense() for the same geometry and mode")
+        d.bias_dense, d.bias_dense_t = bias_dense.q_major.data_ptr(), bias_dense.k_major.data_ptr()
+        d.dense_tiles = bias_dense.tiles
+        d._keep = bias_dense  # keep the tables alive until the launch is enqueued
     return d
 
 
-def bias_dense(bias_t, index16):
-    """fp16 [n_cols, rows, ld] = log2(e) * bias_t[c][index/4]: the dense relative-position bias of every (layer, head)
-    for one int16 index matrix (include/vlm_hip.h vlm_bias_dense; the reference's get_rel_pos_bias, vilt_module.py:1061)."""
+class DenseBias:
+    """fp16 relative-position bias of every (layer, head) in exponent units (bias * log2 e), tiled in MFMA operand order
+    for ONE attention mode of one pass geometry, in both orientations (include/vlm_hip.h vlm_bias_dense; the
+    reference's get_rel_pos_bias, vilt_module.py:1061-1064)."""
+
+    __slots__ = ("q_major", "k_major", "tiles", "key")
+
+    def __init__(self, q_major, k_major, tiles, key):
+        self.q_major, self.k_major, self.tiles, self.key = q_major, k_major, tiles, key
+
+
+def bias_dense(bias_t, index16, seq, mode):
+    """Dense bias tables of a pass geometry `seq` (n0, n1, pos1) and attention mode, from the int16 index [NP, ld]."""
     L.require_cuda(bias_t, index16)
-    if bias_t.dtype != F32 or not bias_t.is_contiguous() or index16.dtype != torch.int16 or not index16.is_contiguous():
-        raise L.VlmError("bias_dense: contiguous f32 bias_t [n_cols, R] and contiguous int16 index")
+    if index16.dtype != torch.int16 or not index16.is_contiguous() or index16.shape[0] < seq.pos1 + seq.n1:
+        raise L.VlmError("bias_dense: contiguous int16 index with pos1 + n1 rows")
+    if bias_t.dtype != F32 or not bias_t.is_contiguous():
+        raise L.VlmError("bias_dense: contiguous f32 bias_t [n_cols, R]")
     n_cols, R = bias_t.shape
-    rows, ld = index16.shape
-    out = torch.empty(n_cols, rows, ld, device=bias_t.device, dtype=torch.float16)
-    L.check(L.get_lib().vlm_bias_dense(L.ptr(bias_t), n_cols, R, L.ptr(index16), ld, rows, L.ptr(out), L.stream_ptr()),
-            "vlm_bias_dense")
-    return out
+    nbytes = L.get_lib().vlm_bias_dense_bytes(seq.n0, seq.n1, seq.pos1, mode)
+    if nbytes == 0:
+        raise L.VlmError("bias_dense: bad geometry (pos1 %% 8 == 0, pos1 >= n0)")
+    outs = []
+    for k_major in (0, 1):
+        out = torch.empty(n_cols, nbytes // 2, device=bias_t.device, dtype=torch.float16)
+        L.check(L.get_lib().vlm_bias_dense(L.ptr(bias_t), n_cols, R, L.ptr(index16), _ld(index16), seq.n0, seq.n1, seq.pos1,
+                                           mode, k_major, L.ptr(out), L.stream_ptr()), "vlm_bias_dense")
+        outs.append(out)
+    return DenseBias(outs[0], outs[1], nbytes // 4096, (seq.n0, seq.n1, seq.pos1, mode))
 
 
 def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None, keep0=None,

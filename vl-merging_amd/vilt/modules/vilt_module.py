@@ -82,7 +82,7 @@ def build_relative_position_indices(window, max_text_len, max_text_len_of_initck
 
 
 def _index16(index, n0):
-    """int16 index in kernel coordinates: text positions [0,n0), image positions start at pos1 = roundup(n0,4);
+    """int16 index in kernel coordinates: text positions [0,n0), image positions start at pos1 = roundup(n0,8);
     leading dimension padded to a multiple of 4; values are 4 x index (byte offsets into the fp32 table column, see
     include/vlm_hip.h).  Returns (index, transpose)."""
     index = index.long() * 4
@@ -90,7 +90,7 @@ def _index16(index, n0):
         raise L.VlmError("relative-position table too large for int16 byte offsets (R <= 8191)")
     n = index.shape[0]
     n1 = n - n0
-    pos1 = (n0 + 3) // 4 * 4
+    pos1 = (n0 + 7) // 8 * 8
     NP = pos1 + n1
     ld = (NP + 3) // 4 * 4
     pos = torch.cat([torch.arange(n0), pos1 + torch.arange(n1)]).to(index.device)
