@@ -67,5 +67,16 @@ int main(int argc, char** argv) {
   const double nn = mode ? (double)n0 * n0 + (double)n1 * n1 : (double)(n0 + n1) * (n0 + n1);
   const double fl = 4.0 * B * H * 64 * nn * (what ? 2.5 : 1.0);
   printf("%s B=%d mode=%d bias=%d: %.1f us  %.0f TFLOP/s\n", what ? "bwd" : "fwd", B, mode, with_bias, us, fl / us / 1e6);
+#ifdef ATT_DIAG_STAMPS
+  {
+    unsigned long long st[8 * 64];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(att_stamps), sizeof(st)));
+    for (int w = 0; w < 8; w += 4) {
+      printf("wave %d deltas:", w);
+      for (int i = 1; i < 64 && st[w * 64 + i]; ++i) printf(" %llu", st[w * 64 + i] - st[w * 64 + i - 1]);
+      printf("\n");
+    }
+  }
+#endif
   return 0;
 }

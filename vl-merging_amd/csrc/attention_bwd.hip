@@ -48,113 +48,135 @@ struct attn_bwd_params_t {
 };
 
 // ----------------------------------------------------------------------------------------------------- dQ kernel
-template <int BIAS>
+// Query-stationary: workgroup = 128 query positions of one (sample, head), lane <-> query, streams 64-key tiles.
+// Per 32-key block (exponent units, see attention_fwd.hip):
+//   E^T  = -lse + Bias^T*log2e + K (c1 Q)^T        C operand = a register tuple holding -lse (constant per lane)
+//   dP^T = -delta + V dO^T                         C operand = a register tuple holding -delta
+//   dS^T = exp2(E^T) * dP^T                        (one v_exp + one v_mul per score; natural-score units)
+//   dQ^T[d][q] += K^T . dS^T                       (A = K^T by ds_read_b64_tr_b16, B = dS^T accumulators as bf16)
+// and dQ leaves scaled by `scale` once at the end.
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_bwd_params_t bp) {
-  constexpr bool HAS_BIAS = BIAS != 0;
   const attn_params_t& p = bp.f;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * ATT_TILE_BYTES + 512];
   unsigned char* ldsK = smem;                          // [2] row image
-  unsigned char* ldsKt = smem + 2 * ATT_TILE_BYTES;    // [2] tr image
+  unsigned char* ldsKt = smem + 2 * ATT_TILE_BYTES;    // [2] transposed-read image
   unsigned char* ldsV = smem + 4 * ATT_TILE_BYTES;     // [2] row image
-  float* kmask = reinterpret_cast<float*>(smem + 6 * ATT_TILE_BYTES);
-  float* tab = reinterpret_cast<float*>(smem + 6 * ATT_TILE_BYTES + 512);
+  float* kmask = reinterpret_cast<float*>(smem + 6 * ATT_TILE_BYTES);  // [2][64]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
   const int r = lane & 31, hh = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const attn_seq_t sq = p.seq;
+  const att_pos_t ps = att_pos(p.seq);
+  int wtile, b, h;
+  if (!att_work_item(att_num_tiles(ps.n0, ps.n1, ps.pos1, p.mode), ps.B, p.H, wtile, b, h)) return;
+  const att_span_t sp = att_span(ps, p.mode, wtile);
   const int D = p.H * 64;
-  const int nt0 = (sq.n0 + ATT_BQ - 1) / ATT_BQ;
-  int qt = blockIdx.x;
-  const int seg = qt >= nt0 ? 1 : 0;
-  if (seg) qt -= nt0;
-  const int nq = seg ? sq.n1 : sq.n0;
-  const int q = qt * ATT_BQ + wave * 32 + r;
-  const bool qvalid = q < nq;
-  const int qc = qvalid ? q : nq - 1;
-  const size_t qrow = (size_t)(seg ? sq.base1 + b * sq.n1 : sq.base0 + b * sq.n0) + qc;
-  const int qpos = (seg ? sq.pos1 : 0) + qc;
-  att_ranges_t kr = att_key_ranges(sq, p.mode, seg, b, p.keep0, p.keep1);
-  const int ntiles = kr.nt[0] + kr.nt[1];
+  const int qp = sp.p0 + wave * 32 + r;
+  const int qrow_raw = qp < sp.s_hi ? att_row_of(ps, b, qp) : -1;
+  const bool qvalid = qrow_raw >= 0;
+  const size_t qrow = qvalid ? (size_t)qrow_raw : (size_t)att_row_of(ps, b, sp.s_lo);
+  const int ntiles = (sp.s_hi - sp.s_lo + ATT_BK - 1) / ATT_BK;
+  const float c1 = p.scale * ATT_LOG2E;
 
   bf16x8 qf[4], dof[4];
   {
-    const bf16_t* qp = p.qkv + qrow * p.ld_qkv + h * 64 + 8 * hh;
-    const bf16_t* dp = bp.d_o + qrow * bp.ld_do + h * 64 + 8 * hh;
+    const bf16_t* qptr = p.qkv + qrow * p.ld_qkv + h * 64 + 8 * hh;
+    const bf16_t* dptr = bp.d_o + qrow * bp.ld_do + h * 64 + 8 * hh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-      dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(qptr + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16_t)((float)raw[j] * c1);
+      dof[s] = *reinterpret_cast<const bf16x8*>(dptr + 16 * s);
     }
   }
-  const float lse2 = bp.lse[(size_t)h * p.total_rows + qrow];
-  const float dl = bp.delta[(size_t)h * p.total_rows + qrow];
-  if (BIAS == 1) {
-    const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
-    for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
+  f32x16 neglse, negdel;
+  {
+    const float l2 = qvalid ? -bp.lse[(size_t)h * p.total_rows + qrow] : -INFINITY;  // invalid rows: P = 0
+    const float dl = qvalid ? -bp.delta[(size_t)h * p.total_rows + qrow] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { neglse[i] = l2; negdel[i] = dl; }
   }
-  const void* mat16 = BIAS == 2 ? (const void*)(p.dense + (size_t)(p.head_row0 + h) * p.idx_rows * p.ld_idx) : (const void*)p.idx;
-  const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(mat16), 0, HAS_BIAS ? p.idx_rows * p.ld_idx * 2 : 0, 0x00020000);
-  const uint32_t irow = (uint32_t)qpos * p.ld_idx;
-  u32x2 iw[8];
-  if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)kr.pos[kr.nt[0] > 0 ? 0 : 1], hh, iw);
+  f16x8 sel0, sel1;
+  att_select_frags(lane, sel0, sel1);
+  const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv), 0, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000);
+  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(HAS_BIAS ? p.dense + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048 : nullptr), 0,
+      HAS_BIAS ? (uint32_t)p.dense_tiles * 4096u : 0, 0x00020000);
+  const uint32_t bvoff = att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + wave, lane);
+  const att_rows2_t ro = att_rows2_init(p.ld_qkv, tid);
 
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
 
-  att_stage_t st;
-  att_stage_load(st, p.qkv, p.ld_qkv, D, h, kr, 0, tid);
-  att_tile_store_rows(st.k, ldsK, tid);
-  att_tile_store_tr(st.k, ldsKt, tid);
-  att_tile_store_rows(st.v, ldsV, tid);
-  if (tid < 64) kmask[tid] = st.mask;
+  auto tile_masked = [&](int kp0) {
+    return (p.keep0 != nullptr && kp0 < ps.n0) || (p.keep1 != nullptr && kp0 + ATT_BK > ps.pos1) ||
+           (!HAS_BIAS && (kp0 < ps.pos1 || kp0 + ATT_BK > sp.s_hi));
+  };
+  u32x4 rk[2], rv[2];
+  float rmask = 0.f;
+  auto load = [&](int t) {
+    const int kp0 = sp.s_lo + t * ATT_BK;
+    att_rows2_load(rk, rkv, ro, ps, b, kp0, sp.s_hi, p.ld_qkv, D + h * 64, tid);
+    att_rows2_load(rv, rkv, ro, ps, b, kp0, sp.s_hi, p.ld_qkv, 2 * D + h * 64, tid);
+    if (tile_masked(kp0) && tid < 64) rmask = att_key_mask(ps, b, kp0 + tid, sp.s_hi, p.keep0, p.keep1);
+  };
+  auto store = [&](int t, int buf) {
+    att_tile_store_rows(rk, ldsK + buf * ATT_TILE_BYTES, tid);
+    att_tile_store_tr(rk, ldsKt + buf * ATT_TILE_BYTES, tid);
+    att_tile_store_rows(rv, ldsV + buf * ATT_TILE_BYTES, tid);
+    if (tile_masked(sp.s_lo + t * ATT_BK) && tid < 64) kmask[buf * 64 + tid] = rmask;
+  };
+  att_bias_t bw;
+  if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);
+  load(0);
+  store(0, 0);
   __syncthreads();
 
-  const float c1 = p.scale * ATT_LOG2E;
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) att_stage_load(st, p.qkv, p.ld_qkv, D, h, kr, t + 1, tid);
+    const int kp0 = sp.s_lo + t * ATT_BK;
+    if (t + 1 < ntiles) load(t + 1);
     const unsigned char* lk = ldsK + cur * ATT_TILE_BYTES;
     const unsigned char* lkt = ldsKt + cur * ATT_TILE_BYTES;
     const unsigned char* lv = ldsV + cur * ATT_TILE_BYTES;
     const float* km = kmask + cur * 64;
-    int rng, k0;
-    att_tile_origin(kr, t, rng, k0);
-    const bool need_mask = (k0 + ATT_BK > kr.n[rng]) || (kr.keep[rng] != nullptr);
-
+    const bool masked = tile_masked(kp0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+      bf16x8 kfr[4], vfr[4];
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
-        const bf16x8 a = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ss], s, 0, 0, 0);
-        const bf16x8 va = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ss], dp, 0, 0, 0);
+        kfr[ss] = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh);
+        vfr[ss] = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 e = neglse, dp = negdel;
+      if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[kb], e);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int kl = kb * 32 + 8 * g4 + 4 * hh;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS) att_bias4<BIAS>(tab, iw[kb * 4 + g4], bv);
-        f32x4 mk = {0.f, 0.f, 0.f, 0.f};
-        if (need_mask) mk = *reinterpret_cast<const f32x4*>(km + kl);  // wave-uniform branch
+      for (int ss = 0; ss < 4; ++ss) {
+        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ss], qf[ss], e, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ss], dof[ss], dp, 0, 0, 0);
+      }
+      if (masked) {  // workgroup-uniform
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + mk[e];
-          const float pr = att_exp2(v - lse2);
-          s[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl) * p.scale;  // dS^T, pre-scaled
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(km + kb * 32 + 8 * g4 + 4 * hh);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) e[4 * g4 + i] += mk[i];
         }
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) e[i] = att_exp2(e[i]) * dp[i];  // dS^T (natural units, unscaled)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 df;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) df[j] = (bf16_t)s[8 * s2 + j];
+        for (int j = 0; j < 8; ++j) df[j] = (bf16_t)e[8 * s2 + j];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16x8 kf = att_tr_frag(lkt, kb * 32 + 16 * s2, db, lane);
@@ -162,18 +184,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         }
       }
     }
-    if (HAS_BIAS && t + 1 < ntiles) {  // next tile's indices (same registers), in flight across the barrier
-      int rng1, k1;
-      att_tile_origin(kr, t + 1, rng1, k1);
-      att_idx_tile(ridx, irow, (uint32_t)(kr.pos[rng1] + k1), hh, iw);
-    }
-    if (t + 1 < ntiles) {
-      att_tile_store_rows(st.k, ldsK + (cur ^ 1) * ATT_TILE_BYTES, tid);
-      att_tile_store_tr(st.k, ldsKt + (cur ^ 1) * ATT_TILE_BYTES, tid);
-      att_tile_store_rows(st.v, ldsV + (cur ^ 1) * ATT_TILE_BYTES, tid);
-      if (tid < 64) kmask[(cur ^ 1) * 64 + tid] = st.mask;
-    }
+    if (HAS_BIAS && t + 1 < ntiles) att_bias_load(bw, rbias, bvoff, t + 1);  // same registers, consumed next trip
+    if (t + 1 < ntiles) store(t + 1, cur ^ 1);
     __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    o[0][i] *= p.scale;
+    o[1][i] *= p.scale;
   }
   if (qvalid) {
     bf16_t* op = bp.dqkv + qrow * bp.ld_dqkv + h * 64 + 4 * hh;
@@ -183,13 +201,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
       for (int g4 = 0; g4 < 4; ++g4) {
         bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)o[db][4 * g4 + e];
+        for (int i = 0; i < 4; ++i) v[i] = (bf16_t)o[db][4 * g4 + i];
         *reinterpret_cast<bf16x4*>(op + db * 32 + 8 * g4) = v;
       }
   }
-  if (bp.dq_colsum[seg]) {
-    // q_bias gradient = column sums of dQ: the 128x64 tile goes through LDS (row stride 68 floats: conflict-free
-    // 16-B writes), every thread sums 32 rows of one column, 256 atomics per workgroup -- no second pass over dqkv
+  if (bp.dq_colsum[0] || bp.dq_colsum[1]) {
+    // q_bias gradient = column sums of dQ per token segment: the 128x64 tile goes through LDS (row stride 68 floats:
+    // conflict-free 16-B writes), every thread sums 32 rows of one column, split by the row's segment (a JOINT tile
+    // can hold text and image positions) -- no second pass over dqkv
     float* red = reinterpret_cast<float*>(smem);
     const int lr = wave * 32 + r;
 #pragma unroll
@@ -202,195 +221,215 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
       }
     __syncthreads();
     const int col = tid & 63, part = tid >> 6;
-    float sum = 0.f;
+    float sum_t = 0.f, sum_i = 0.f;
 #pragma unroll 8
-    for (int i = 0; i < 32; ++i) sum += red[(part * 32 + i) * 68 + col];
-    atomicAdd(bp.dq_colsum[seg] + h * 64 + col, sum);
+    for (int i = 0; i < 32; ++i) {
+      const float v = red[(part * 32 + i) * 68 + col];
+      if (sp.p0 + part * 32 + i < ps.n0) sum_t += v;
+      else sum_i += v;
+    }
+    if (bp.dq_colsum[0] && sp.p0 + part * 32 < ps.n0) atomicAdd(bp.dq_colsum[0] + h * 64 + col, sum_t);
+    if (bp.dq_colsum[1] && sp.p0 + part * 32 + 32 > ps.pos1) atomicAdd(bp.dq_colsum[1] + h * 64 + col, sum_i);
   }
 }
 
-// ------------------------------------------------------------------------------------------- dK / dV / dBias kernel
-template <int BIAS>
+// ------------------------------------------------------------------------------------------- dK / dV kernel
+// Key-stationary: workgroup = 128 key positions of one (sample, head), lane <-> key, streams 64-query tiles of Q and dO.
+// Per 32-query block:
+//   E[q][key]  = -lse[q] + Bias*log2e + Q (c1 K)^T     C operand = -lse of the block's 16 query rows, read from LDS
+//   dP[q][key] = -delta[q] + dO V^T                    C operand = -delta, read from LDS
+//   P = exp2(E) ; dS = P * dP
+//   dV[key][d] += P^T dO ,  dK[key][d] += dS^T Q       (A = the accumulator registers as bf16, B = transposed reads)
+// dK leaves scaled by `scale` at the end.  Dropped keys (padding tokens) add -inf to their lanes' C operands.
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn_bwd_params_t bp) {
-  constexpr bool HAS_BIAS = BIAS != 0;
   const attn_params_t& p = bp.f;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsQ = smem;                           // row image  [64 q][64 d]
-  unsigned char* ldsQt = smem + ATT_TILE_BYTES;         // tr image
-  unsigned char* ldsO = smem + 2 * ATT_TILE_BYTES;      // dO row image
-  unsigned char* ldsOt = smem + 3 * ATT_TILE_BYTES;     // dO tr image
-  float* qstat = reinterpret_cast<float*>(smem + 4 * ATT_TILE_BYTES);  // [64] lse2 then [64] delta
-  float* tab = qstat + 128;                                             // [R] bias column * log2e
+  __shared__ __attribute__((aligned(16))) unsigned char smem[8 * ATT_TILE_BYTES + 1024];
+  unsigned char* ldsQ = smem;                           // [2] row image  [64 q][64 d]
+  unsigned char* ldsQt = smem + 2 * ATT_TILE_BYTES;     // [2] transposed-read image
+  unsigned char* ldsO = smem + 4 * ATT_TILE_BYTES;      // [2] dO row image
+  unsigned char* ldsOt = smem + 6 * ATT_TILE_BYTES;     // [2] dO transposed-read image
+  float* qstat = reinterpret_cast<float*>(smem + 8 * ATT_TILE_BYTES);  // [2][-lse 64 | -delta 64]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
   const int r = lane & 31, hh = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const attn_seq_t sq = p.seq;
+  const att_pos_t ps = att_pos(p.seq);
+  int wtile, b, h;
+  if (!att_work_item(att_num_tiles(ps.n0, ps.n1, ps.pos1, p.mode), ps.B, p.H, wtile, b, h)) return;
+  const att_span_t sp = att_span(ps, p.mode, wtile);  // stationary = keys, streamed = the queries that see them
   const int D = p.H * 64;
-  const int nt0 = (sq.n0 + ATT_BQ - 1) / ATT_BQ;
-  int kt = blockIdx.x;
-  const int seg = kt >= nt0 ? 1 : 0;  // segment of this workgroup's keys
-  if (seg) kt -= nt0;
-  const int nk = seg ? sq.n1 : sq.n0;
-  const int key = kt * ATT_BQ + wave * 32 + r;
-  const bool kvalid = key < nk;
-  const int kc = kvalid ? key : nk - 1;
-  const size_t krow = (size_t)(seg ? sq.base1 + b * sq.n1 : sq.base0 + b * sq.n0) + kc;
-  const int kpos = (seg ? sq.pos1 : 0) + kc;
-  const uint8_t* keep = seg ? p.keep1 : p.keep0;
-  const bool kkeep = kvalid && (!keep || keep[(size_t)b * nk + kc] != 0);
-  const float kmaskv = kkeep ? 0.f : -INFINITY;
-  // query ranges that see this key segment (same rule as the forward, by symmetry of the block structure)
-  att_ranges_t qr = att_key_ranges(sq, p.mode, seg, b, nullptr, nullptr);
-  const int ntiles = qr.nt[0] + qr.nt[1];
+  const int kp = sp.p0 + wave * 32 + r;
+  const int krow_raw = kp < sp.s_hi ? att_row_of(ps, b, kp) : -1;
+  const bool kvalid = krow_raw >= 0;
+  const size_t krow = kvalid ? (size_t)krow_raw : (size_t)att_row_of(ps, b, sp.s_lo);
+  const float kmaskv = kvalid ? att_key_mask(ps, b, kp, sp.s_hi, p.keep0, p.keep1) : -INFINITY;
+  // does this WAVE hold a dropped key whose scores the table does not already mask?  (padding tokens; without a bias
+  // table also the gap / past-the-end positions)
+  const bool wave_masked = __any(kmaskv != 0.f && (kvalid || !HAS_BIAS));
+  const int ntiles = (sp.s_hi - sp.s_lo + ATT_BK - 1) / ATT_BK;
+  const float c1 = p.scale * ATT_LOG2E;
 
   bf16x8 kf[4], vf[4];
   {
-    const bf16_t* kp = p.qkv + krow * p.ld_qkv + D + h * 64 + 8 * hh;
+    const bf16_t* kptr = p.qkv + krow * p.ld_qkv + D + h * 64 + 8 * hh;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-      vf[s] = *reinterpret_cast<const bf16x8*>(kp + D + 16 * s);
+      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(kptr + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[s][j] = (bf16_t)(kvalid ? (float)raw[j] * c1 : 0.f);
+      vf[s] = *reinterpret_cast<const bf16x8*>(kptr + D + 16 * s);
     }
   }
-  if (BIAS == 1) {
-    const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
-    for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
-  }
-  const void* mat16 = BIAS == 2 ? (const void*)(p.dense_t + (size_t)(p.head_row0 + h) * p.idx_t_rows * p.ld_idx_t) : (const void*)p.idx_t;
-  const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(mat16), 0, HAS_BIAS ? p.idx_t_rows * p.ld_idx_t * 2 : 0, 0x00020000);
-  const uint32_t irow = (uint32_t)kpos * p.ld_idx_t;
-  u32x2 iw[8];
-  if (HAS_BIAS) att_idx_tile(ridx, irow, (uint32_t)qr.pos[qr.nt[0] > 0 ? 0 : 1], hh, iw);
+  f16x8 sel0, sel1;
+  att_select_frags(lane, sel0, sel1);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv), 0, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(bp.d_o), 0, (uint32_t)((size_t)p.total_rows * bp.ld_do * 2), 0x00020000);
+  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(HAS_BIAS ? p.dense_t + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048 : nullptr), 0,
+      HAS_BIAS ? (uint32_t)p.dense_tiles * 4096u : 0, 0x00020000);
+  const uint32_t bvoff = att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + wave, lane);
+  const att_rows2_t roq = att_rows2_init(p.ld_qkv, tid), roo = att_rows2_init(bp.ld_do, tid);
 
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
 
-  u32x4 sq_[2], so_[2];
-  float s_lse = 0.f, s_dl = 0.f;
-  auto stage_load = [&](int t) {
-    int rng, q0;
-    att_tile_origin(qr, t, rng, q0);
-    att_tile_load(sq_, p.qkv, p.ld_qkv, h * 64, qr.rowbase[rng], q0, qr.n[rng], tid);
-    att_tile_load(so_, bp.d_o, bp.ld_do, h * 64, qr.rowbase[rng], q0, qr.n[rng], tid);
-    if (tid < 64) {
-      const int qq = q0 + tid;
-      const bool ok = qq < qr.n[rng];
-      const size_t row = (size_t)qr.rowbase[rng] + (ok ? qq : 0);
-      s_lse = ok ? bp.lse[(size_t)h * p.total_rows + row] : INFINITY;  // exp2(x - inf) = 0 for padded queries
-      s_dl = ok ? bp.delta[(size_t)h * p.total_rows + row] : 0.f;
+  u32x4 rq_[2], ro_[2];
+  float rstat = 0.f;
+  auto load = [&](int t) {
+    const int qp0 = sp.s_lo + t * ATT_BK;
+    att_rows2_load(rq_, rq, roq, ps, b, qp0, sp.s_hi, p.ld_qkv, h * 64, tid);
+    att_rows2_load(ro_, rdo, roo, ps, b, qp0, sp.s_hi, bp.ld_do, h * 64, tid);
+    if (tid < 128) {  // threads 0..63: -lse, 64..127: -delta of the tile's 64 query positions
+      const int qq = qp0 + (tid & 63);
+      const int row = qq < sp.s_hi ? att_row_of(ps, b, qq) : -1;
+      const float* src = tid < 64 ? bp.lse : bp.delta;
+      const float v = row >= 0 ? -src[(size_t)h * p.total_rows + row] : 0.f;
+      rstat = row >= 0 ? v : (tid < 64 ? -INFINITY : 0.f);  // absent queries: P = exp2(-inf) = 0
     }
   };
-  auto stage_store = [&]() {
-    att_tile_store_rows(sq_, ldsQ, tid);
-    att_tile_store_tr(sq_, ldsQt, tid);
-    att_tile_store_rows(so_, ldsO, tid);
-    att_tile_store_tr(so_, ldsOt, tid);
-    if (tid < 64) {
-      qstat[tid] = s_lse;
-      qstat[64 + tid] = s_dl;
-    }
+  auto store = [&](int buf) {
+    att_tile_store_rows(rq_, ldsQ + buf * ATT_TILE_BYTES, tid);
+    att_tile_store_tr(rq_, ldsQt + buf * ATT_TILE_BYTES, tid);
+    att_tile_store_rows(ro_, ldsO + buf * ATT_TILE_BYTES, tid);
+    att_tile_store_tr(ro_, ldsOt + buf * ATT_TILE_BYTES, tid);
+    if (tid < 128) qstat[buf * 128 + tid] = rstat;
   };
-  stage_load(0);
-  stage_store();
+  att_bias_t bw;
+  if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);
+  load(0);
+  store(0);
   __syncthreads();
 
-  const float c1 = p.scale * ATT_LOG2E;
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) stage_load(t + 1);
-    int rng, q0;
-    att_tile_origin(qr, t, rng, q0);
+    const int cur = t & 1;
+    if (t + 1 < ntiles) load(t + 1);
+    const unsigned char* lq = ldsQ + cur * ATT_TILE_BYTES;
+    const unsigned char* lqt = ldsQt + cur * ATT_TILE_BYTES;
+    const unsigned char* lo = ldsO + cur * ATT_TILE_BYTES;
+    const unsigned char* lot = ldsOt + cur * ATT_TILE_BYTES;
+    const float* st = qstat + cur * 128;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+      bf16x8 qfr[4], ofr[4];
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
-        const bf16x8 a = att_k_rowfrag(ldsQ, qb * 32 + r, 2 * ss + hh);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ss], s, 0, 0, 0);     // S[q][key]
-        const bf16x8 oa = att_k_rowfrag(ldsO, qb * 32 + r, 2 * ss + hh);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);  // dP[q][key]
+        qfr[ss] = att_k_rowfrag(lq, qb * 32 + r, 2 * ss + hh);
+        ofr[ss] = att_k_rowfrag(lo, qb * 32 + r, 2 * ss + hh);
       }
+      f32x16 e, dp;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int ql = qb * 32 + 8 * g4 + 4 * hh;  // local query row of element 0 of this group
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (HAS_BIAS) att_bias4<BIAS>(tab, iw[qb * 4 + g4], bv);
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(qstat + ql);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(qstat + 64 + ql);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st + qb * 32 + 8 * g4 + 4 * hh);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(st + 64 + qb * 32 + 8 * g4 + 4 * hh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + kmaskv;
-          const float pr = att_exp2(v - ls[e]);
-          s[4 * g4 + e] = pr;                               // P
-          dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - dl[e]);   // dS (natural units, w.r.t. the biased score)
-        }
+        for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
       }
-      // dV += P^T dO ; dK += scale * dS^T Q   (A = accumulator regs as bf16, B = tr-read tiles)
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave_masked) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] += kmaskv;
+      }
+      if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[qb], e);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ss], kf[ss], e, 0, 0, 0);     // E[q][key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ss], vf[ss], dp, 0, 0, 0);   // dP[q][key]
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        e[i] = att_exp2(e[i]);  // P
+        dp[i] *= e[i];          // dS (natural units)
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pf, df;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pf[j] = (bf16_t)s[8 * s2 + j];
-          df[j] = (bf16_t)(dp[8 * s2 + j] * p.scale);
+          pf[j] = (bf16_t)e[8 * s2 + j];
+          df[j] = (bf16_t)dp[8 * s2 + j];
         }
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const bf16x8 ob = att_tr_frag(ldsOt, qb * 32 + 16 * s2, db, lane);
+          const bf16x8 ob = att_tr_frag(lot, qb * 32 + 16 * s2, db, lane);
           dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ob, dv[db], 0, 0, 0);
-          const bf16x8 qb_ = att_tr_frag(ldsQt, qb * 32 + 16 * s2, db, lane);
+          const bf16x8 qb_ = att_tr_frag(lqt, qb * 32 + 16 * s2, db, lane);
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb_, dk[db], 0, 0, 0);
         }
       }
     }
-    if (HAS_BIAS && t + 1 < ntiles) {  // next query tile's indices (same registers), in flight across the barriers
-      int rng1, q1;
-      att_tile_origin(qr, t + 1, rng1, q1);
-      att_idx_tile(ridx, irow, (uint32_t)(qr.pos[rng1] + q1), hh, iw);
-    }
+    if (HAS_BIAS && t + 1 < ntiles) att_bias_load(bw, rbias, bvoff, t + 1);
+    if (t + 1 < ntiles) store(cur ^ 1);
     __syncthreads();
-    if (t + 1 < ntiles) {
-      stage_store();
-      __syncthreads();
-    }
   }
 
-  // ---- store dK, dV: accumulator rows = keys (regs), column = d (lane & 31) ----------------------------------------
+  // ---- store dK, dV: accumulator rows = keys (registers), column = d (lane & 31) ---------------------------------------
   {
-    const int kbase = kt * ATT_BQ + wave * 32;
-    const size_t row0 = (size_t)(seg ? sq.base1 + b * sq.n1 : sq.base0 + b * sq.n0);
+    const int kp0w = sp.p0 + wave * 32;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int kl = (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (kbase + kl < nk) {
-        bf16_t* dst = bp.dqkv + (row0 + kbase + kl) * bp.ld_dqkv + D + h * 64 + r;
+      const int kpi = kp0w + kl;
+      const int row = kpi < sp.s_hi ? att_row_of(ps, b, kpi) : -1;
+      if (row >= 0) {
+        bf16_t* dst = bp.dqkv + (size_t)row * bp.ld_dqkv + D + h * 64 + r;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          dst[db * 32] = (bf16_t)dk[db][i];
+          dst[db * 32] = (bf16_t)(dk[db][i] * p.scale);
           dst[D + db * 32] = (bf16_t)dv[db][i];
         }
       }
     }
-    if (bp.dv_colsum[seg]) {  // v_bias gradient = column sums of dV over this workgroup's 128 keys: 64 atomics
-      float* red = reinterpret_cast<float*>(smem);
+    if (bp.dv_colsum[0] || bp.dv_colsum[1]) {  // v_bias gradient = column sums of dV over this workgroup's keys, per segment
+      float* red = reinterpret_cast<float*>(smem);  // [segment][wave][64]
       __syncthreads();
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        float sum = 0.f;
+        float sum_t = 0.f, sum_i = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int kl = (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kbase + kl < nk) sum += dv[db][i];
+          const int kpi = kp0w + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const bool ok = kpi < sp.s_hi && (kpi < ps.n0 || kpi >= ps.pos1);
+          if (ok && kpi < ps.n0) sum_t += dv[db][i];
+          if (ok && kpi >= ps.pos1) sum_i += dv[db][i];
         }
-        sum += __shfl_xor(sum, 32, 64);
-        if (hh == 0) red[wave * 64 + db * 32 + r] = sum;
+        sum_t += __shfl_xor(sum_t, 32, 64);
+        sum_i += __shfl_xor(sum_i, 32, 64);
+        if (hh == 0) {
+          red[wave * 64 + db * 32 + r] = sum_t;
+          red[256 + wave * 64 + db * 32 + r] = sum_i;
+        }
       }
       __syncthreads();
-      if (tid < 64) atomicAdd(bp.dv_colsum[seg] + h * 64 + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
+      if (tid < 128) {
+        const int sg = tid >> 6, c = tid & 63;
+        const float v = red[sg * 256 + c] + red[sg * 256 + 64 + c] + red[sg * 256 + 128 + c] + red[sg * 256 + 192 + c];
+        if (bp.dv_colsum[sg] && v != 0.f) atomicAdd(bp.dv_colsum[sg] + h * 64 + c, v);
+      }
     }
   }
 }
@@ -417,7 +456,8 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const at
   float* tab = qstat + 64;
   float* hist = reinterpret_cast<float*>(smem);  // aliases the K/V tiles: only used after the sample loop
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
   const int r = lane & 31, hh = lane >> 5;
   const int h = blockIdx.y;
   const attn_seq_t sq = p.seq;
@@ -615,30 +655,19 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
                      ld_dout, p.total_rows, p.H, delta_ws);
   VLM_CHECK_LAUNCH();
 
-  dim3 grid(nt0 + nt1, p.H, p.seq.B), block(ATT_THREADS);
-  const size_t Rp = (size_t)((p.R + 3) & ~3);
-  const size_t smem_dq = 6 * ATT_TILE_BYTES + 512 + Rp * 4;
-  const size_t smem_dkv = 4 * ATT_TILE_BYTES + 512 + Rp * 4;
-  const size_t smem_db = 4 * ATT_TILE_BYTES + 2 * 4096 + 256 + Rp * 4;  // histogram aliases the K/V tiles (R*4 <= 32 KiB)
-  if (smem_dq > 160 * 1024 || smem_dkv > 160 * 1024) return VLM_ERR_UNSUPPORTED;
+  if ((size_t)p.total_rows * p.ld_qkv * 2 >= (1ull << 32) || (size_t)p.total_rows * ld_dout * 2 >= (1ull << 32)) return VLM_ERR_UNSUPPORTED;
+  if (p.bias_t && (!p.dense || !p.dense_t)) return VLM_ERR_ARG;  // biased attention runs on the dense tables (vlm_bias_dense)
+  if (p.dense && p.dense_tiles != att_dense_layout(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode).tiles) return VLM_ERR_ARG;
+  const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
+  dim3 grid(att_grid_size(nt, p.seq.B, p.H)), block(ATT_THREADS);
   if (p.bias_t) {
-    const bool dense = false;  // the round-1 backward kernels gather through the index (dense tables changed format)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dq) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_dkv) != hipSuccess)
-      return VLM_ERR_LAUNCH;
-    if (dense) hipLaunchKernelGGL((attn_bwd_dq_kernel<2>), grid, block, smem_dq, s, bp);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<1>), grid, block, smem_dq, s, bp);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
     VLM_CHECK_LAUNCH();
-    if (dense) hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), grid, block, smem_dkv, s, bp);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), grid, block, smem_dkv, s, bp);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, s, bp);
     if (dbias_t) {
       VLM_CHECK_LAUNCH();
+      const size_t Rp = (size_t)((p.R + 3) & ~3);
+      const size_t smem_db = 4 * ATT_TILE_BYTES + 2 * 4096 + 256 + Rp * 4;  // histogram aliases the K/V tiles (R*4 <= 32 KiB)
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dbias_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_db) != hipSuccess)
         return VLM_ERR_LAUNCH;
@@ -646,9 +675,9 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
       hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(nt0 + nt1, p.H, ntq), block, smem_db, s, bp);
     }
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<0>), grid, block, smem_dq, s, bp);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, 0, s, bp);
     VLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<0>), grid, block, smem_dkv, s, bp);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), grid, block, 0, s, bp);
   }
   VLM_CHECK_LAUNCH();
   return VLM_OK;

@@ -369,7 +369,8 @@ __device__ __forceinline__ void att_bias_load(att_bias_t& bw, __amdgpu_buffer_rs
 // byte offset (inside a column) of stationary block `sb_in_part` of the part the workgroup's stationary tile lies in
 __device__ __forceinline__ uint32_t att_bias_voff(const att_dense_layout_t& L, int part, int sb_in_part, int lane) {
   const uint32_t first = part ? (uint32_t)(L.nsb[0] * L.nst[0]) : 0u;
-  return (first + (uint32_t)sb_in_part * L.nst[part]) * 4096u + lane * 16;
+  const uint32_t nst = part ? (uint32_t)L.nst[1] : (uint32_t)L.nst[0];  // (no dynamic array index: that went to scratch)
+  return (first + (uint32_t)sb_in_part * nst) * 4096u + lane * 16;
 }
 
 // ---- LDS-DMA staging of [64 positions][64 bf16] tiles (8 pieces of 1 KiB, 2 per wave): the swizzles of the row image
@@ -431,4 +432,40 @@ __device__ __forceinline__ float att_key_mask(const att_pos_t& ps, int b, int p,
   const size_t at = txt ? (size_t)b * ps.n0 + p : (size_t)b * ps.n1 + (p - ps.pos1);
   if (ok && kp) ok = kp[at] != 0;
   return ok ? 0.f : -INFINITY;
+}
+
+// ---- register-staged [64 positions][64 bf16] tiles for the backward kernels ----------------------------------------
+// Each thread moves two 16-B pieces (piece = tid + 256u: row = piece >> 3, chunk = piece & 7) global -> VGPR -> LDS;
+// the loads of tile t+1 are issued before tile t's arithmetic and written to the other stage after it.  (LDS-DMA costs
+// the issuing wave ~100 cycles per 1-KiB piece next to MFMAs; the backward kernels stage up to 24 pieces per tile.)
+struct att_rows2_t {
+  uint32_t off[2];  // byte offset of this thread's pieces inside a plain tile (row * ld + chunk * 8) * 2
+};
+__device__ __forceinline__ att_rows2_t att_rows2_init(uint32_t ld, int tid) {
+  att_rows2_t d;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint32_t piece = tid + 256 * u;
+    d.off[u] = ((piece >> 3) * ld + (piece & 7) * 8) * 2;
+  }
+  return d;
+}
+// rows p0 .. p0+63 of operand column `col` (bf16 elements) of sample b; invalid positions read as zero
+__device__ __forceinline__ void att_rows2_load(u32x4 (&reg)[2], __amdgpu_buffer_rsrc_t rsrc, const att_rows2_t& d,
+                                               const att_pos_t& ps, int b, int p0, int p_hi, uint32_t ld, uint32_t col, int tid) {
+  if (att_tile_plain(ps, p0, p_hi)) {  // workgroup-uniform: consecutive image rows
+    const uint32_t soff = ((uint32_t)(ps.base1 + b * ps.n1 + (p0 - ps.pos1)) * ld + col) * 2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) reg[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, d.off[u], soff, 0));
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = p0 + ((tid + 256 * u) >> 3);
+      const bool txt = p < ps.n0, img = p >= ps.pos1 && p < ps.NP;
+      const bool ok = (txt || img) && p < p_hi;
+      const int first = txt ? ps.base0 + b * ps.n0 + p0 : ps.base1 + b * ps.n1 + (p0 - ps.pos1);
+      const uint32_t off = ok ? ((uint32_t)first * ld + col) * 2 + d.off[u] : 0xFFFFFFF0u;
+      reg[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  }
 }

@@ -25,6 +25,12 @@
 #ifndef ATT_FWD_WAVES
 #define ATT_FWD_WAVES 2
 #endif
+#ifdef ATT_DIAG_STAMPS  // diagnostic builds only (tools/scratch/attn_bench.hip): s_memtime inside the tile loop
+__device__ unsigned long long att_stamps[8 * 64];
+#define ATT_STAMP(slot) do { const int s_ = (slot); if (blockIdx.x == 8 * 100 && lane == 0 && s_ < 64) att_stamps[wave * 64 + s_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATT_STAMP(slot) do { } while (0)
+#endif
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(const attn_params_t p) {
 #ifdef ATT_DIAG_LDSPAD
@@ -39,7 +45,8 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   __shared__ __attribute__((aligned(16))) unsigned char ldsV0[ATT_TILE_BYTES], ldsV1[ATT_TILE_BYTES];  // transposed-read image
   __shared__ float kmask0[64], kmask1[64];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
   const int r = lane & 31, hh = lane >> 5;
   const att_pos_t ps = att_pos(p.seq);
   int wtile, b, h;
@@ -121,9 +128,11 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   ATT_PUBLISH();
 
   // one streamed tile; `bw` = this tile's bias rows (complete since the last publish), `bn` receives the next tile's
+  int slot = 0;
   auto tile = [&](int t, const att_bias_t& bw, att_bias_t& bn, const unsigned char* lk, const unsigned char* lv,
                   const float* km, unsigned char* nk, unsigned char* nv, float* nm_) {
     const int kp0 = sp.s_lo + t * ATT_BK;
+    ATT_STAMP(slot++);
     if (t + 1 < ntiles) {
 #ifndef ATT_DIAG_NOBIASLOAD
       if (HAS_BIAS) att_bias_load(bn, rbias, bvoff, t + 1);
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
     }
 
     // ---- E^T = -m + Bias^T*log2e + K (c1 Q)^T : two 32-key chains of exponents ------------------------------------
+    ATT_STAMP(slot++);  // after issuing the next tile's loads
     // all eight K row fragments are requested up front (hipcc otherwise issues each ds_read right in front of its
     // MFMA and waits out the full LDS latency eight times per tile); the bias MFMAs need no LDS data and cover it
     bf16x8 kfr[2][4];
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ss], qf[ss], s[kb], 0, 0, 0);
+    ATT_STAMP(slot++);  // S chain issued
     if (tile_masked(kp0)) {  // workgroup-uniform
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
     mx = fmaxf(mx, s[1][15]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 #endif
+    ATT_STAMP(slot++);  // max known
     if (__any(mx > 6.0f)) {  // some row's exponents exceed 2^6: move those rows' reference points (rare after tile 0)
       const float m_new = mx > 0.f ? (float)(_Float16)(m + mx) : m;
       const float delta = m_new - m;  // exact: both are fp16 values
@@ -197,6 +209,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
         s[kb][i] = att_exp2(s[kb][i]);
 #endif
       }
+    ATT_STAMP(slot++);  // exps issued
     // ---- O^T += V^T P^T ;  row sums += 1^T P^T -------------------------------------------------------------------
 #ifdef ATT_DIAG_NOPV
     o[0][0] += s[0][0];
@@ -217,6 +230,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
         }
       }
     }
+    ATT_STAMP(slot++);  // PV issued
     ATT_PUBLISH();
   };
   for (int t = 0; t < ntiles; t += 2) {  // two tiles per trip: the bias registers alternate without copies
