@@ -246,7 +246,8 @@ def main():
     model.train()
     model.setup_engine()
     (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"])
-    reducer = ddp.FlatGradReducer(model, force_collectives=force_dist)
+    reducer = ddp.FlatGradReducer(model, force_collectives=force_dist,
+                                  sharded=os.environ.get("VLM_SHARDED", "0") != "0")  # ddp_sharded (run.py:231-232)
     # the embeddings' all-reduce overlaps the AdamW update of everything else (same wiring as run.py)
     reducer.attach(opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
     batch = synthetic_batch(args.batch, args.image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)

@@ -60,6 +60,35 @@ def _worker(rank, world, port, q):
             for n, p in m.named_parameters():
                 assert torch.all(p.grad == want), (step, n, p.grad.flatten()[:3], want)
             assert red.expected == {0: 1, 1: 1, 2: 2}
+        # ---- sharded mode (ddp_sharded): reduce-scatter semantics, the own chunks partition every bucket, parameter
+        # all-gather from the owners
+        m2 = Tiny()
+        m2._flat = engine.FlatParams(m2, order_key=vu.flat_order_key)
+        red2 = ddp.FlatGradReducer(m2, sharded=True)
+        own = red2.own_ranges()
+        assert sum(hi - lo for lo, hi in own) * world == sum(hi - lo for lo, hi in red2.buckets())
+        for step in range(2):
+            red2.begin_step()
+            for p in m2.parameters():
+                p.grad.fill_(float(rank + 1 + step))
+            for layer in (2, 2, 1, 0):
+                m2._grad_hook(layer)
+            red2.finish_backward()
+            want = sum(r + 1 + step for r in range(world))
+            real = torch.zeros(m2._flat.numel, dtype=torch.bool)   # elements that belong to a parameter (not padding)
+            for n in m2._flat.names:
+                o, k = m2._flat.offsets[n]
+                real[o:o + k] = True
+            for lo, hi in own:
+                assert torch.all(m2._flat.flat_g[lo:hi][real[lo:hi]] == want)
+        for (lo, hi), (clo, chi) in zip(red2.buckets(), own):
+            m2._flat.flat_p[lo:hi] = -1.0
+            m2._flat.flat_p[clo:chi] = float(rank + 1)   # "the optimizer updated the own chunk"
+        red2.gather_params()
+        for lo, hi in red2.buckets():
+            c = (hi - lo) // world
+            for r in range(world):
+                assert torch.all(m2._flat.flat_p[lo + r * c: lo + (r + 1) * c] == float(r + 1))
         # a changed use count must be loud
         red.begin_step()
         m._grad_hook(2)

@@ -20,13 +20,20 @@ _BLOCK = re.compile(r"transformer\.blocks\.(\d+)\.")
 
 
 class FlatGradReducer:
-    def __init__(self, model, process_group=None, force_collectives=False):
-        """force_collectives: issue the all-reduces even at world size 1 (a single-GPU smoke test of the RCCL path)."""
+    def __init__(self, model, process_group=None, force_collectives=False, sharded=False):
+        """force_collectives: issue the all-reduces even at world size 1 (a single-GPU smoke test of the RCCL path).
+        sharded: the reference's `ddp_sharded` plugin (run.py:231-232, fairscale OSS + ShardedDDP) on the flat buffers:
+        every bucket is REDUCE-SCATTERED instead of all-reduced (rank r receives the sum of its 1/W chunk of the
+        bucket), FusedAdamW keeps m / v only for those chunks and updates only them, and the updated fp32 parameters are
+        ALL-GATHERED bucket by bucket after the step.  Same bytes on the wire as one all-reduce (reduce-scatter +
+        all-gather is how RCCL's ring all-reduce is built), 1/W of the optimizer state and of the AdamW traffic."""
         self.force = force_collectives
+        self.sharded = bool(sharded)
         self.model = model
         self.flat = model._flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         names_by_block = {}
         early, late = [], []
         for n in self.flat.names:
@@ -70,6 +77,8 @@ class FlatGradReducer:
         self.defer_tail = bool(defer_tail) and (self.world > 1 or self.force)
         tr = self.tail_range()
         optimizer.tail_sync = (tr[0], tr[1], self.wait_tail) if tr is not None else None
+        if self.sharded and self.world > 1:
+            optimizer.set_shard(self.own_ranges(), self.gather_params)
         self._attached = optimizer
         return self
 
@@ -86,19 +95,63 @@ class FlatGradReducer:
         """Called by the first (counting) step for every block evaluation to learn the static use counts."""
         self.expected[layer] += 1
 
+    # ---- sharded mode: chunk r of bucket [lo, hi) belongs to rank r ---------------------------------------------------
+    def buckets(self):
+        """All buckets (flat ranges) in flat-buffer order: tail (embeddings), blocks, late (heads)."""
+        return sorted(list(self.tail_slices) + list(self.block_slices.values()) + list(self.late_slices))
+
+    def own_chunk(self, lo, hi, rank=None):
+        n = hi - lo
+        if n % self.world:
+            raise RuntimeError("sharded mode: bucket of %d elements does not split over %d ranks (buckets are multiples "
+                               "of 64 elements: use a world size that divides 64)" % (n, self.world))
+        c = n // self.world
+        r = self.rank if rank is None else rank
+        return lo + r * c, lo + (r + 1) * c
+
+    def own_ranges(self):
+        return [self.own_chunk(lo, hi) for lo, hi in self.buckets()]
+
+    def _reduce(self, lo, hi):
+        """The gradient collective of one bucket (async): all-reduce, or reduce-scatter into the rank's own chunk."""
+        buf = self.flat.flat_g[lo:hi]
+        if self.sharded and self.world > 1:
+            clo, chi = self.own_chunk(lo, hi)
+            if dist.get_backend(self.group) == "nccl":
+                return dist.reduce_scatter_tensor(self.flat.flat_g[clo:chi], buf, group=self.group, async_op=True)
+            # gloo (CPU tests, several ranks on one device) has no reduce-scatter: the all-reduce leaves the same sum
+            # in the own chunk (the other chunks are ignored by the sharded optimizer)
+        return dist.all_reduce(buf, group=self.group, async_op=True)
+
+    def gather_params(self):
+        """Sharded mode, after the optimizer step: every bucket's fp32 parameters from their owners (in place)."""
+        if not self.sharded or self.world == 1:
+            return
+        works = []
+        for lo, hi in self.buckets():
+            clo, chi = self.own_chunk(lo, hi)
+            full, mine = self.flat.flat_p[lo:hi], self.flat.flat_p[clo:chi]
+            if dist.get_backend(self.group) == "nccl":
+                works.append(dist.all_gather_into_tensor(full, mine, group=self.group, async_op=True))
+            else:
+                c = chi - clo
+                works.append(dist.all_gather([full[r * c:(r + 1) * c] for r in range(self.world)], mine.clone(),
+                                             group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
     def _launch(self, lo, hi):
         if self.world == 1 and not self.force:
             return
-        buf = self.flat.flat_g[lo:hi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             ws = engine.wgrad_stream()
             if ws is not None:
                 self.comm_stream.wait_stream(ws)  # the slice's weight gradients are produced on the side stream
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(dist.all_reduce(buf, group=self.group, async_op=True))
+                self.handles.append(self._reduce(lo, hi))
         else:
-            self.handles.append(dist.all_reduce(buf, group=self.group, async_op=True))
+            self.handles.append(self._reduce(lo, hi))
 
     def on_block_backward(self, layer):
         self.seen[layer] += 1

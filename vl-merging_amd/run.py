@@ -45,7 +45,8 @@ def main(argv):
     model.train()
     model.setup_engine()
     (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"] or 100000)
-    red = ddp.FlatGradReducer(model).attach(opt)  # same reducer set-up as bench.py
+    # use_sharded_training=True: the reference's `ddp_sharded` plugin (run.py:231-232) -> reduce-scatter + sharded AdamW
+    red = ddp.FlatGradReducer(model, sharded=bool(cfg.get("use_sharded_training"))).attach(opt)  # same set-up as bench.py
     B = cfg["per_gpu_batchsize"] or 2
     # run.py:155-158 of the reference: accumulate_grad_batches = batch_size // (per_gpu_batchsize * gpus * nodes)
     grad_steps = max(1, int(cfg["batch_size"]) // (B * world * max(1, int(cfg["num_nodes"]))))

@@ -78,6 +78,8 @@ class FusedAdamW:
         self.step_count = 0
         self.m = torch.zeros_like(self.flat.flat_p)
         self.v = torch.zeros_like(self.flat.flat_p)
+        self._shard = None        # sharded mode: [(lo, hi, state offset)] of the flat ranges this rank owns
+        self._after_step = None   # sharded mode: all-gather of the updated parameters
         self.grad_scale = 1.0
         self.tail_sync = None
         # HF AdamW skips parameters whose .grad is None (`if p.grad is None: continue`): tensors no pass of the current
@@ -96,6 +98,25 @@ class FusedAdamW:
         self._all_ranges = [list(g["ranges"]) for g in groups]
         self._active = set()
         self._active_key = None
+
+    def set_shard(self, ranges, after_step):
+        """ddp_sharded (reference run.py:231-232): this rank updates only `ranges` (its chunk of every gradient bucket,
+        ddp.FlatGradReducer.own_ranges) and keeps Adam's m / v for those elements only, packed back to back;
+        `after_step` all-gathers the updated fp32 parameters."""
+        if self.step_count:
+            raise RuntimeError("set_shard() must come before the first optimizer step")
+        off, table = 0, []
+        for lo, hi in sorted(ranges):
+            table.append((lo, hi, off))
+            off += hi - lo
+        self._shard = table
+        self._after_step = after_step
+        dev = self.flat.flat_p.device
+        self.m = torch.zeros(off, device=dev, dtype=self.flat.flat_p.dtype)
+        self.v = torch.zeros(off, device=dev, dtype=self.flat.flat_p.dtype)
+
+    def state_elements(self):
+        return self.m.numel()
 
     def _discover_active(self):
         """Re-derive each group's ranges from the parameters that have received a gradient so far."""
@@ -130,10 +151,18 @@ class FusedAdamW:
             self._discover_active()
             self._active_key = key
 
+        def update_one(g, lo, hi, so):
+            ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[so:so + hi - lo], self.v[so:so + hi - lo],
+                           f.flat_b[lo:hi], g["lr"], self.betas[0], self.betas[1], self.eps, g["weight_decay"],
+                           self.step_count, grad_scale=self.grad_scale, zero_grad=True)
+
         def update(g, lo, hi):
-            ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], f.flat_b[lo:hi],
-                           g["lr"], self.betas[0], self.betas[1], self.eps, g["weight_decay"], self.step_count,
-                           grad_scale=self.grad_scale, zero_grad=True)
+            if self._shard is None:
+                return update_one(g, lo, hi, lo)
+            for slo, shi, soff in self._shard:  # the part of [lo, hi) this rank owns
+                a, b = max(lo, slo), min(hi, shi)
+                if a < b:
+                    update_one(g, a, b, soff + a - slo)
 
         # tail_sync = (lo, hi, wait): the gradient all-reduce of flat range [lo, hi) may still be in flight (DDP reducer
         # with defer_tail); everything outside it is updated first, then `wait()`, then the range itself
@@ -153,6 +182,12 @@ class FusedAdamW:
             tail[2]()
         for g, lo, hi in late:
             update(g, lo, hi)
+        if self._shard is not None:
+            # the other ranks' chunks: their gradients are dropped, their parameters arrive by all-gather, and the bf16
+            # shadows of the whole buffer are rebuilt by one cast launch
+            f.flat_g.zero_()
+            self._after_step()
+            ops.cast_bf16(f.flat_p[:f.numel], f.flat_b[:f.numel])
         f.refresh_transposed()  # W^T shadows of the block weights (one batched launch)
         f.dirty = False  # the kernel refreshed the bf16 shadows
 
