@@ -183,10 +183,26 @@ int vlm_droppath_rows(const float* u, float keep, int B, int n0, int n1, int bas
 int vlm_droppath_sites(const float* u0, const float* u1, const float* keep, int n_sites, int B, int n0, int n1, int base0,
                        int base1, int rows, float* out, void* stream);
 int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W, int P, int lead_rows, void* stream);
-/* Gram cache (K15, src/cache_gram_matrices.py:246-254: G += X^T X in float64 for the input X of every hooked linear):
- * the product runs on the MFMA GEMM (vlm_gemm_bf16 ta=1 tb=1 over the bf16 activations the linear consumed, fp32
- * accumulation, split-K), and this entry point adds the fp32 [D,D] result into the float64 accumulator on device. */
+/* ------------------------------------------------------------------------------------------------
+ * float64 kernels of the merge side (csrc/f64ops.hip), all products on v_mfma_f64_16x16x4_f64.
+ * Gram cache (K15, src/cache_gram_matrices.py:246-254: `G += X.to(float64)^T X` for the input X of every hooked
+ * linear): vlm_gram_f64 adds X^T X of a bf16 or fp32 [M, D] activation matrix into the fp64 [D, D] accumulator on the
+ * device (exact conversion, fp64 FMA chains, upper-triangular tiles mirrored on the way out).
+ * RegMean (K14, src/vilt/modules/vilt_module.py:388-392, 407-434): vlm_scale_gram_f64 forms a*G + (1-a)*diag(G)
+ * (optionally accumulating the sum over modalities); vlm_gemm_f64 is C = alpha*op(A) op(B) + beta*C in fp64 (A may be the
+ * fp32 checkpoint weight); the reference's torch.inverse of the SPD sum is replaced by a blocked Cholesky
+ * factorisation + two triangular solves built from vlm_potrf_block_f64 (in-place lower factor of one <= 64-wide
+ * diagonal block; *status gets 1 + the index of a non-positive pivot), vlm_trsm_block_f64 (X <- X op(L)^-1 for a
+ * row panel against one diagonal block; trans = 1: X L^T = B, trans = 0: X L = B) and vlm_gemm_f64 for the block
+ * updates; vl_merging_amd/regmean.py walks the block columns.  vlm_accumulate_f32_f64 (dst += src) is kept for callers
+ * that already hold an fp32 product. */
 int vlm_accumulate_f32_f64(const float* src, double* dst_f64, uint64_t n, void* stream);
+int vlm_gram_f64(const void* x, int ldx, int M, int D, int x_is_f32, double* gram, void* stream);
+int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32, const double* B,
+                 int ldb, double beta, double* C, int ldc, void* stream);
+int vlm_scale_gram_f64(const double* src, double* dst, int n, double alpha, int accumulate, void* stream);
+int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* status, void* stream);
+int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* B, int ldb, int rows, int c0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (K4 + K7 + K7b): softmax(scale*Q K^T + bias[h] + key mask) V, head_dim = 64.

@@ -279,6 +279,51 @@ def gold_irtr():
         np.savez_compressed(os.path.join(HERE, f"irtr_tiny_{arch}.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- RegMean at base size
+REGMEAN_BASE_LAYERS = (0, 11)  # the reference takes ~4 s per 3072^2 inverse on this box: two layers pin the arithmetic
+
+
+def regmean_base_inputs(layers=REGMEAN_BASE_LAYERS):
+    """Base-size (D = 768, F = 3072) all_moe block weights and SPD Gram matrices for the listed layers; every other
+    layer of the 12 the merge walks is passed through as an already-merged (ufo-shaped) tensor (the reference's
+    `else: later_weight = state_dict[later_name]` branch, vilt_module.py:425-427)."""
+    D, F = 768, 3072
+    moe = synth.block_shapes(D, F, "all_moe")
+    ufo = synth.block_shapes(D, F, "ufo")
+    sd = {}
+    for k, (shp, dt) in moe.items():
+        if int(k.split(".")[2]) in layers:
+            sd[k] = det_array(k, shp)
+    for k, (shp, dt) in ufo.items():
+        if int(k.split(".")[2]) not in layers and "gamma" not in k:
+            sd[k] = det_array(k, shp, 5)
+    for k, (shp, dt) in moe.items():
+        if "gamma" in k:
+            sd[k] = det_array(k, shp)
+    grams = {k: det_gram(k, s[0]) for k, s in synth.gram_shapes(D, F).items() if int(k.split(".")[2]) in layers}
+    return sd, grams
+
+
+def gold_regmean_base():
+    vm, _, _ = import_reference()
+    sd, grams = regmean_base_inputs()
+    tmp = "/tmp/vlm_golden"
+    os.makedirs(tmp, exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in grams.items()}, os.path.join(tmp, "grams_base.pth"))
+    me = fake_self(scaling_for_non_diag=0.9, loss_names={"irtr": 1}, gram_matrices=os.path.join(tmp, "grams_base.pth"))
+    res = vm.ViLTransformerSS.regmean(me, {k: torch.from_numpy(v) for k, v in sd.items()})
+    os.remove(os.path.join(tmp, "grams_base.pth"))
+    out = {}
+    for k, v in res.items():
+        if v.dtype == torch.float64 and int(k.split(".")[2]) in REGMEAN_BASE_LAYERS:
+            a = v.numpy()
+            out[k + "/norm"] = np.array(np.linalg.norm(a))
+            out[k + "/rows"] = a[[0, a.shape[0] // 2, a.shape[0] - 1]][:, :256]
+            out[k + "/colsum"] = a.sum(0)[:256]
+            print(k, a.shape, float(out[k + "/norm"]))
+    np.savez_compressed(os.path.join(HERE, "regmean_base.npz"), **out)
+
+
 # ----------------------------------------------------------------------------- base width (the benchmarked size)
 BASE = dict(vit="vit_base_patch16_384", image_size=384, hidden_size=768, num_heads=12, max_text_len=40,
             vocab_size=1024, drop_rate=0.1)
@@ -701,4 +746,4 @@ if __name__ == "__main__":
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
          "irtr": gold_irtr, "model_base": gold_model_base, "irtr_merged_base": gold_irtr_merged_base,
-         "train_tiny": gold_train_tiny, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()
+         "train_tiny": gold_train_tiny, "regmean_base": gold_regmean_base, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()

@@ -1,0 +1,83 @@
+"""float64 kernels (csrc/f64ops.hip, v_mfma_f64_16x16x4_f64) against torch's float64 arithmetic on the same inputs:
+Gram SYRK over bf16 / fp32 activations, GEMM in every transpose combination with ragged sizes, G' = aG + (1-a)diag(G),
+blocked Cholesky and the SPD right-hand solve RegMean uses in place of torch.inverse (vilt_module.py:432-434).
+Tolerances are fp64 rounding: 1e-12 relative on sums of ~1e3 products, 1e-9 on the solve of a condition-1e4 system."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    return importlib.import_module("vl_merging_amd.ops")
+
+
+@pytest.mark.parametrize("M,D,dtype", [(1000, 192, torch.bfloat16), (333, 768, torch.float32), (70, 100, torch.bfloat16),
+                                       (5000, 3072, torch.bfloat16)])
+def test_gram_f64_matches_torch(ops, M, D, dtype):
+    g = torch.Generator(device="cuda"); g.manual_seed(M + D)
+    x = torch.randn(M, D, device="cuda", generator=g).to(dtype)
+    acc = torch.zeros(D, D, device="cuda", dtype=torch.float64)
+    ops.gram_accumulate(x, acc)
+    ops.gram_accumulate(x, acc)
+    xd = x.double()
+    want = 2 * (xd.t() @ xd)
+    assert torch.allclose(acc, want, rtol=1e-12, atol=1e-9), float((acc - want).abs().max())
+    assert torch.allclose(acc, acc.t(), rtol=1e-13, atol=1e-10)  # mirrored tiles (the row slices meet through atomics in any order)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("a32", [False, True])
+def test_gemm_f64_matches_torch(ops, ta, tb, a32):
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    M, N, K = 150, 97, 333
+    a = torch.randn((K, M) if ta else (M, K), device="cuda", generator=g, dtype=torch.float32 if a32 else torch.float64)
+    b = torch.randn((N, K) if tb else (K, N), device="cuda", generator=g, dtype=torch.float64)
+    c0 = torch.randn(M, N, device="cuda", generator=g, dtype=torch.float64)
+    c = c0.clone()
+    ops.gemm_f64(a, b, c, ta=ta, tb=tb, alpha=-0.5, beta=2.0)
+    want = -0.5 * ((a.double().t() if ta else a.double()) @ (b.t() if tb else b)) + 2.0 * c0
+    assert torch.allclose(c, want, rtol=1e-12, atol=1e-11), float((c - want).abs().max())
+    # views with a leading dimension (the block updates of the factorisation)
+    big = torch.zeros(M + 5, N + 9, device="cuda", dtype=torch.float64)
+    ops.gemm_f64(a, b, big[2:2 + M, 3:3 + N], ta=ta, tb=tb)
+    assert torch.allclose(big[2:2 + M, 3:3 + N], (a.double().t() if ta else a.double()) @ (b.t() if tb else b), rtol=1e-12, atol=1e-11)
+    assert float(big[:2].abs().max()) == 0 and float(big[:, :3].abs().max()) == 0
+
+
+def test_scale_gram(ops):
+    g = torch.randn(130, 130, device="cuda", dtype=torch.float64)
+    g = g @ g.t()
+    out = torch.empty_like(g)
+    ops.scale_gram(g, out, 0.9)
+    want = 0.9 * g + (1 - 0.9) * torch.diag_embed(torch.diag(g))
+    assert torch.equal(out, want)  # same two products and one add per element as the reference's expression
+    ops.scale_gram(g, out, 0.9, accumulate=True)
+    assert torch.equal(out, want + want)
+
+
+@pytest.mark.parametrize("n,rows", [(64, 10), (200, 333), (768, 3072), (3072, 768)])
+def test_cholesky_solve_matches_inverse(ops, n, rows):
+    g = torch.Generator(device="cuda"); g.manual_seed(n)
+    x = torch.randn(n + 64, n, device="cuda", generator=g, dtype=torch.float64)
+    s = x.t() @ x                       # SPD, condition ~ 1e3..1e4 (the Gram matrices RegMean sums)
+    num = torch.randn(rows, n, device="cuda", generator=g, dtype=torch.float64)
+    chol = ops.cholesky_(s.clone())
+    low = torch.tril(chol)
+    assert torch.allclose(low @ low.t(), s, rtol=1e-12, atol=1e-9 * float(s.abs().max()))
+    got = ops.solve_spd_right_(num.clone(), chol)
+    want = num @ torch.inverse(s)       # what the reference computes
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-9 * scale
+    assert float((got @ s - num).abs().max()) <= 1e-9 * float(num.abs().max()) * (1 + n / 100)
+
+
+def test_cholesky_rejects_indefinite(ops, pkg):
+    L = importlib.import_module("vl_merging_amd._lib")
+    s = torch.eye(100, device="cuda", dtype=torch.float64)
+    s[70, 70] = -1.0
+    with pytest.raises(L.VlmError):
+        ops.cholesky_(s)

@@ -22,9 +22,9 @@ def mods(pkg):
 
 
 def test_gram_capture_matches_reference(mods, golden_dir):
-    """Same 96 keys as the reference's hook produces; values within the bf16-activation tolerance: the engine feeds
-    the linears bf16 activations (2^-9 relative rounding per element, uncorrelated), the reference fp32 ones ->
-    relative Frobenius error of a Gram matrix <= 5e-3."""
+    """Same 96 keys as the reference's hook produces.  The products and sums are float64 on the device (v_mfma_f64
+    SYRK); what differs from the reference is the ACTIVATIONS the engine computed upstream in bf16 (and, for the
+    attention output and the GELU output, the bf16 tensors themselves): relative Frobenius error of a Gram <= 5e-3."""
     gold = np.load(os.path.join(golden_dir, "irtr_tiny_all_moe.npz"))
     model = build(mods, "all_moe", "tiny_irtr_all_moe", golden_dir, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0}, max_vl=None)
     batch = gpu_batch(det_batch(3, 224, 40, 1024, seed=77))
@@ -78,3 +78,81 @@ def test_regmean_matches_reference_tiny(case, pkg, golden_dir):
                 np.testing.assert_allclose(o, g, rtol=1e-8, atol=1e-11)  # fp64 GEMM + inverse on device
         else:
             assert res[k] is sd[k]
+
+
+def test_regmean_base_size_matches_reference(pkg, golden_dir):
+    """configs[3], RegMean half, at base size (D = 768, F = 3072): layers 0 and 11 of an all_moe state through the
+    MFMA-f64 GEMMs + blocked Cholesky solve against the reference's `W.double() @ G` / torch.inverse results
+    (tests/golden/regmean_base.npz: norms, three rows and the column sums of every merged weight).  1e-8 relative."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    rm = importlib.import_module("vl_merging_amd.regmean")
+    gold = np.load(os.path.join(golden_dir, "regmean_base.npz"))
+    from oracle import synth
+    from oracle.detweights import det_array, det_gram
+    layers = (0, 11)
+    D, F = 768, 3072
+    sd = {}
+    for k, (shp, dt) in synth.block_shapes(D, F, "all_moe").items():
+        if int(k.split(".")[2]) in layers or "gamma" in k:
+            sd[k] = torch.from_numpy(det_array(k, shp)).cuda()
+    for k, (shp, dt) in synth.block_shapes(D, F, "ufo").items():
+        if int(k.split(".")[2]) not in layers and "gamma" not in k:
+            sd[k] = torch.from_numpy(det_array(k, shp, 5)).cuda()
+    grams = {k: torch.from_numpy(det_gram(k, s[0])) for k, s in synth.gram_shapes(D, F).items() if int(k.split(".")[2]) in layers}
+    cfg = merge_cfg(scaling_for_non_diag=0.9, loss_names={"irtr": 1})
+    res = rm.regmean(sd, cfg, gram_matrices=grams)
+    torch.cuda.synchronize()
+    checked = 0
+    for key in gold.files:
+        if key.endswith("/norm"):
+            k = key[:-5]
+            a = res[k]
+            assert a.dtype == torch.float64
+            want = float(gold[key])
+            assert abs(float(a.norm()) - want) <= 1e-9 * want, k
+            rows = a[[0, a.shape[0] // 2, a.shape[0] - 1]][:, :256].cpu().numpy()
+            np.testing.assert_allclose(rows, gold[k + "/rows"], rtol=1e-8, atol=1e-10 * want)
+            np.testing.assert_allclose(a.sum(0)[:256].cpu().numpy(), gold[k + "/colsum"], rtol=1e-8, atol=1e-9 * want)
+            checked += 1
+    assert checked == 8  # qkv, proj, fc1, fc2 of two layers
+
+
+def test_engine_grams_feed_regmean_like_reference_grams(mods, golden_dir):
+    """End to end (tiny width): Gram matrices CAPTURED BY THE ENGINE on an irtr batch -> regmean, against the oracle's
+    float64 Gram matrices of the same batch (pinned to the reference's hook outputs, tests/test_oracle_model.py) ->
+    the same regmean.  The merged weights differ only through the engine's bf16 activations: <= 2e-2 of the weight
+    scale (RegMean divides by the sum of Grams, so their relative error carries over once)."""
+    from oracle import vlmo_ref as R
+    rm = importlib.import_module("vl_merging_amd.regmean")
+    model = build(mods, "all_moe", "tiny_irtr_all_moe", golden_dir, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0}, max_vl=None)
+    nb = det_batch(3, 224, 40, 1024, seed=77)
+    batch = gpu_batch(nb)
+    mods[1].vilt_utils.set_task(model)
+    cap = model.start_gram_capture()
+    with torch.no_grad():
+        model(batch)
+    model.stop_gram_capture()
+    eng = cap.state_dict()
+    sd_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if v.is_floating_point()}
+    idx = {k: getattr(model, k).cpu() for k in ("relative_position_index", "text_relative_position_index",
+                                                 "text_imag_relative_position_index")}
+    with torch.no_grad():
+        ref = R.gram_inputs(sd_cpu, R.Arch("all_moe", hidden=192, heads=3), idx, {k: torch.from_numpy(v) for k, v in nb.items()})
+    assert sorted(ref) == sorted(eng)
+    # ridge the tiny-batch Grams (3 x 237 tokens < 768 fc2 inputs: singular without it) the same way on both sides
+    def ridged(gs):
+        return {k: v.double() + 1e-3 * float(v.diagonal().mean()) * torch.eye(v.shape[0], dtype=torch.float64) for k, v in gs.items()}
+    cfg = merge_cfg(scaling_for_non_diag=0.9, loss_names={"irtr": 1})
+    sd = {k: v for k, v in model.state_dict().items() if "transformer.blocks." in k}
+    a = rm.regmean(dict(sd), cfg, gram_matrices=ridged(eng))
+    b = rm.regmean(dict(sd), cfg, gram_matrices=ridged(ref))
+    torch.cuda.synchronize()
+    n = 0
+    for k, v in a.items():
+        if torch.is_tensor(v) and v.dtype == torch.float64:
+            err = float((v - b[k]).abs().max())
+            scale = float(b[k].abs().max())
+            assert err <= 2e-2 * scale, (k, err, scale)
+            n += 1
+    assert n == 48

@@ -93,6 +93,12 @@ SIGNATURES = {
     "vlm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_float, c_float, c_float,
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "vlm_accumulate_f32_f64": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
+    "vlm_gram_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_gemm_f64": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_int, c_int, c_void_p, c_int,
+                             ctypes.c_double, c_void_p, c_int, c_void_p]),
+    "vlm_scale_gram_f64": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_double, c_int, c_void_p]),
+    "vlm_potrf_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_trsm_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_bias_dense_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vlm_bias_dense": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -4,9 +4,10 @@
 
 The reference registers forward hooks that add X^T X (float64) of the input of every linear / attention module and
 drives them with `trainer.validate` over the retrieval validation set; here the fused block function feeds the same
-inputs to an on-device accumulator (MFMA product + float64 accumulation, ONE device->host copy at the end instead of
-one 4.7/75 MB copy per hook call) and the driver is a loop over synthetic COCO-shaped batches (the data modules are
-outside the hot path).  Output: `<log_dir>/<representation_name>.pth` = torch.save(dict name -> float64 [D,D]),
+inputs to an on-device float64 accumulator (v_mfma_f64 SYRK, ONE device->host copy at the end instead of one 4.7/75 MB
+copy per hook call).  Batches come from Arrow shards (`data_root=<dir>`: ArrowDataset over every *.arrow file in it,
+vocab.txt next to them) or, without a data_root, from synthetic COCO-shaped batches.  Multi-GPU: launch with
+torch.distributed.run; the batches are dealt round-robin over the ranks and the Gram sums are all-reduced.  Output: `<log_dir>/<representation_name>.pth` = torch.save(dict name -> float64 [D,D]),
 the file `regmean` loads at vilt_module.py:386.
 """
 import importlib
@@ -21,7 +22,37 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 
+def arrow_batches(cfg, B, dev):
+    """Validation batches of the retrieval task from Arrow shards under cfg["data_root"] (the reference drives its hooks
+    with trainer.validate over the same shards, cache_gram_matrices.py:339): ArrowDataset + its collate, a
+    non-masking collator (evaluation reads the plain ids)."""
+    ds = importlib.import_module("vl_merging_amd.vilt.datasets")
+    names = sorted(f[:-6] for f in os.listdir(cfg["data_root"]) if f.endswith(".arrow"))
+    vocab = os.path.join(cfg["data_root"], "vocab.txt")
+    if not os.path.isfile(vocab):
+        raise FileNotFoundError("cache_gram_matrices: %s (tokenizer vocabulary next to the shards)" % vocab)
+    tok = ds.build_synthetic_tokenizer(vocab) if os.path.getsize(vocab) < 4096 else None
+    if tok is None:
+        from transformers import BertTokenizer
+        tok = BertTokenizer(vocab, do_lower_case=True)
+    data = ds.ArrowDataset(cfg["data_root"], ["square_transform"], cfg["image_size"], names, text_column_name="caption",
+                           max_text_len=cfg["max_text_len"], tokenizer=tok)
+
+    def no_mask(encodings):
+        ids = torch.zeros(len(encodings), cfg["max_text_len"], dtype=torch.long)
+        for r, e in enumerate(encodings):
+            ids[r, : len(e["input_ids"])] = torch.tensor(e["input_ids"])
+        return {"input_ids": ids.clone(), "labels": torch.full_like(ids, -100)}
+
+    for lo in range(0, len(data) - B + 1, B):
+        b = data.collate([data[i] for i in range(lo, lo + B)], no_mask)
+        yield {"image": [b["image"][0].to(dev)], "text_ids": b["text_ids"].to(dev), "text_masks": b["text_masks"].to(dev),
+               "text_labels": b["text_labels"].to(dev), "text_ids_mlm": b["text_ids_mlm"].to(dev),
+               "text_labels_mlm": b["text_labels_mlm"].to(dev)}
+
+
 def main(argv):
+    import torch.distributed as dist
     ge.import_package()
     cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
     vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
@@ -35,25 +66,45 @@ def main(argv):
         else:
             rest.append(a)
     cfg = cfgmod.parse_cli(rest)
-    torch.cuda.set_device(0)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0)) if os.environ.get("VLM_BENCH_ONE_DEVICE", "0") == "0" else 0
+    torch.cuda.set_device(local)
+    if world > 1:  # one process per GPU; every rank hooks its shard of the batches, the float64 sums meet over RCCL
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29578")
+        dist.init_process_group(os.environ.get("VLM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     torch.manual_seed(cfg["seed"])
     model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).cuda().eval()
     model.setup_engine()
     vu.set_task(model)
     cap = model.start_gram_capture()
     B = cfg["per_gpu_batchsize"] or 2
+    if cfg["data_root"]:
+        source = arrow_batches(cfg, B, "cuda")
+    else:
+        source = (synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 4321 + i, "cuda")["vl"]
+                  for i in range(batches))
+    n_seen = 0
     with torch.no_grad():
-        for i in range(batches):
-            batch = synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 4321 + i, "cuda")["vl"]
-            model(batch)
+        for i, batch in enumerate(source):
+            if i >= batches and not cfg["data_root"]:
+                break
+            if i % world == rank:  # DistributedSampler-style round robin over the batches
+                model(batch)
+                n_seen += 1
     model.stop_gram_capture()
-    os.makedirs(cfg["log_dir"], exist_ok=True)
-    path = os.path.join(cfg["log_dir"], cfg["representation_name"] + ".pth")
+    cap.all_reduce()
     grams = cap.state_dict()
-    torch.save(grams, path)
-    for k, v in list(grams.items())[:4]:
-        print(k, tuple(v.shape), float(v.min()), float(v.max()))
-    print("saved %d gram matrices to %s" % (len(grams), path))
+    if rank == 0:
+        os.makedirs(cfg["log_dir"], exist_ok=True)
+        path = os.path.join(cfg["log_dir"], cfg["representation_name"] + ".pth")
+        torch.save(grams, path)
+        for k, v in list(grams.items())[:4]:
+            print(k, tuple(v.shape), float(v.min()), float(v.max()))
+        print("saved %d gram matrices (%d batches on rank 0, %d ranks) to %s" % (len(grams), n_seen, world, path))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,270 @@
+// float64 kernels of the merge side: the Gram cache's X^T X (reference
+// src/cache_gram_matrices.py:246-254: `to(float64)` then matmul) and RegMean's W* = (sum_m W_m G'_m)(sum_m G'_m)^-1
+// (src/vilt/modules/vilt_module.py:407-434, 459-484: `W.double() @ G`, `torch.inverse`).  All products run on
+// v_mfma_f64_16x16x4_f64 (exact fp64 FMA chains); the inverse is replaced by a blocked Cholesky factorisation of the
+// SPD sum of Gram matrices and two triangular solves (the driver, vl_merging_amd/regmean.py, walks the 64-wide block
+// columns and launches the kernels below).
+//
+// MFMA f64 16x16x4 operand layout: A[16][4]: lane l holds A[l & 15][l >> 4]; B[4][16]: lane l holds B[l >> 4][l & 15];
+// C/D[16][16]: register r of lane l holds row 4*r + (l >> 4) of column l & 15.
+#include "vlm_common.h"
+
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
+#define F64_TILE 64   // output tile per workgroup (4 waves, each 32 x 32 = 2 x 2 MFMA blocks)
+#define F64_KC 16     // reduction rows staged per step
+
+template <typename T>
+__device__ __forceinline__ double f64_load(const T* p) { return (double)*p; }
+template <>
+__device__ __forceinline__ double f64_load<bf16_t>(const bf16_t* p) { return (double)(float)*p; }
+
+// One 64x64 output tile's accumulation over reduction rows [k0, k1): A-side and B-side panels are staged as
+// [F64_KC][64 + 1] doubles.  a(k, i) / b(k, j) are fetched through the functors (any layout / element type).
+template <typename FA, typename FB>
+__device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1, FA a_at, FB b_at, double (*sa)[F64_TILE + 1],
+                                             double (*sb)[F64_TILE + 1]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  for (int k = k0; k < k1; k += F64_KC) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (F64_KC * F64_TILE) / 256; ++u) {
+      const int e = tid + 256 * u, kk = e >> 6, c = e & 63;
+      const bool ok = k + kk < k1;
+      sa[kk][c] = ok ? a_at(k + kk, c) : 0.0;
+      sb[kk][c] = ok ? b_at(k + kk, c) : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k4 = 0; k4 < F64_KC; k4 += 4) {
+      const int kk = k4 + (lane >> 4), c = lane & 15;
+      const double a0 = sa[kk][wi + c], a1 = sa[kk][wi + 16 + c];
+      const double b0 = sb[kk][wj + c], b1 = sb[kk][wj + 16 + c];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- Gram (SYRK)
+// G[D][D] += X^T X for X [M][D] (bf16 or fp32 activations, converted exactly), upper-triangular tiles only, mirrored on
+// the way out; the M rows are cut into gridDim.z slices that meet in G through fp64 atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void gram_f64_kernel(const T* __restrict__ x, int ldx, int M, int D, double* __restrict__ g) {
+  __shared__ double sa[F64_KC][F64_TILE + 1], sb[F64_KC][F64_TILE + 1];
+  // blockIdx.x enumerates tile pairs (ti <= tj)
+  const int nt = (D + F64_TILE - 1) / F64_TILE;
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= nt - ti) { rem -= nt - ti; ++ti; }
+  const int tj = ti + rem;
+  const int i0 = ti * F64_TILE, j0 = tj * F64_TILE;
+  const int per = ((M + gridDim.z - 1) / gridDim.z + F64_KC - 1) / F64_KC * F64_KC;
+  const int k0 = blockIdx.z * per, k1 = k0 + per < M ? k0 + per : M;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  if (k0 < k1)
+    f64_tile_mac(acc, k0, k1,
+                 [&](int k, int c) { return i0 + c < D ? f64_load(x + (size_t)k * ldx + i0 + c) : 0.0; },
+                 [&](int k, int c) { return j0 + c < D ? f64_load(x + (size_t)k * ldx + j0 + c) : 0.0; }, sa, sb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi + 16 * a + 4 * r + (lane >> 4), j = j0 + wj + 16 * b + (lane & 15);
+        if (i < D && j < D) {
+          const double v = acc[a][b][r];
+          if (ti != tj) {
+            atomicAdd(g + (size_t)i * D + j, v);
+            atomicAdd(g + (size_t)j * D + i, v);
+          } else {
+            atomicAdd(g + (size_t)i * D + j, v);  // diagonal tile: computed in full
+          }
+        }
+      }
+}
+
+extern "C" int vlm_gram_f64(const void* x, int ldx, int M, int D, int x_is_f32, double* gram, void* stream) {
+  if (M == 0 || D == 0) return VLM_OK;
+  if (!x || !gram || M < 0 || D < 0 || ldx < D) return VLM_ERR_ARG;
+  const int nt = (D + F64_TILE - 1) / F64_TILE, pairs = nt * (nt + 1) / 2;
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  int slices = (4 * cus + pairs - 1) / pairs;  // ~4 workgroups per CU
+  const int max_slices = (M + 4 * F64_KC - 1) / (4 * F64_KC);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  dim3 grid(pairs, 1, slices);
+  if (x_is_f32)
+    hipLaunchKernelGGL((gram_f64_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(x), ldx, M, D, gram);
+  else
+    hipLaunchKernelGGL((gram_f64_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(x), ldx, M, D, gram);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- GEMM
+// C[M][N] = alpha * op(A) op(B) + beta * C, fp64, row-major; op(A)[i][k] = ta ? A[k][i] : A[i][k], op(B)[k][j] = tb ?
+// B[j][k] : B[k][j].  A may be fp32 (a_is_f32: the fp32 checkpoint weights of RegMean enter without a host-side cast).
+template <typename TA_>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
+                                                       int lda, const double* __restrict__ B, int ldb, double beta,
+                                                       double* __restrict__ C, int ldc) {
+  __shared__ double sa[F64_KC][F64_TILE + 1], sb[F64_KC][F64_TILE + 1];
+  const int i0 = blockIdx.y * F64_TILE, j0 = blockIdx.x * F64_TILE;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  f64_tile_mac(acc, 0, K,
+               [&](int k, int c) { return i0 + c < M ? (double)(ta ? A[(size_t)k * lda + i0 + c] : A[(size_t)(i0 + c) * lda + k]) : 0.0; },
+               [&](int k, int c) { return j0 + c < N ? (tb ? B[(size_t)(j0 + c) * ldb + k] : B[(size_t)k * ldb + j0 + c]) : 0.0; }, sa, sb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi + 16 * a + 4 * r + (lane >> 4), j = j0 + wj + 16 * b + (lane & 15);
+        if (i < M && j < N) {
+          double* c = C + (size_t)i * ldc + j;
+          *c = alpha * acc[a][b][r] + (beta != 0.0 ? beta * *c : 0.0);
+        }
+      }
+}
+
+extern "C" int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32,
+                            const double* B, int ldb, double beta, double* C, int ldc, void* stream) {
+  if (M == 0 || N == 0) return VLM_OK;
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || ldc < N) return VLM_ERR_ARG;
+  dim3 grid((N + F64_TILE - 1) / F64_TILE, (M + F64_TILE - 1) / F64_TILE);
+  if (a_is_f32)
+    hipLaunchKernelGGL((gemm_f64_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, ta, tb, M, N, K, alpha,
+                       reinterpret_cast<const float*>(A), lda, B, ldb, beta, C, ldc);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, ta, tb, M, N, K, alpha,
+                       reinterpret_cast<const double*>(A), lda, B, ldb, beta, C, ldc);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- G' = a G + (1-a) diag(G), summed
+// dst (+)= alpha * src + (1 - alpha) * diag(src)   (vilt_module.py:388-392 `scaling_for_non_diag`), accumulate flag
+__global__ __launch_bounds__(256) void scale_gram_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, double alpha,
+                                                         int accumulate) {
+  const size_t total = (size_t)n * n;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+    const double g = src[e];
+    // the reference forms alpha * G + (1 - alpha) * diag(G) in this order (two products, one add)
+    const double v = __dadd_rn(__dmul_rn(alpha, g), i == j ? __dmul_rn(1.0 - alpha, g) : 0.0);
+    dst[e] = accumulate ? __dadd_rn(dst[e], v) : v;
+  }
+}
+
+extern "C" int vlm_scale_gram_f64(const double* src, double* dst, int n, double alpha, int accumulate, void* stream) {
+  if (n == 0) return VLM_OK;
+  if (!src || !dst || n < 0) return VLM_ERR_ARG;
+  size_t blocks = ((size_t)n * n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, alpha, accumulate);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- Cholesky block
+// In-place lower Cholesky factor of the nb x nb (nb <= 64) diagonal block at A[j0][j0] (row-major, leading dimension
+// lda): one wave, the block lives in LDS.  status[0] is set to j0 + k + 1 if pivot k is not positive (not SPD).
+__global__ __launch_bounds__(64) void potrf_block_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ status) {
+  __shared__ double s[64][65];
+  const int t = threadIdx.x;
+  for (int r = 0; r < nb; ++r)
+    if (t < nb) s[r][t] = A[(size_t)(j0 + r) * lda + j0 + t];
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    const double d = s[k][k];
+    if (!(d > 0.0)) {
+      if (t == 0 && status) atomicCAS(status, 0, j0 + k + 1);
+      return;
+    }
+    const double rd = sqrt(d);
+    __syncthreads();
+    if (t == k) s[k][k] = rd;
+    if (t > k && t < nb) s[t][k] = s[t][k] / rd;
+    __syncthreads();
+    // trailing update: thread t owns column t (t > k): s[i][t] -= s[i][k] * s[t][k] for i >= t
+    if (t > k && t < nb) {
+      const double ltk = s[t][k];
+      for (int i = t; i < nb; ++i) s[i][t] -= s[i][k] * ltk;
+    }
+    __syncthreads();
+  }
+  for (int r = 0; r < nb; ++r)
+    if (t < nb) A[(size_t)(j0 + r) * lda + j0 + t] = t <= r ? s[r][t] : 0.0;
+}
+
+extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* status, void* stream) {
+  if (nb == 0) return VLM_OK;
+  if (!A || nb < 0 || nb > 64 || j0 < 0 || lda < j0 + nb) return VLM_ERR_ARG;
+  hipLaunchKernelGGL(potrf_block_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, lda, j0, nb, status);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- triangular block solves
+// X (rows x nb, in place in Bm at column c0) <- X * op(L)^-1 with L the nb x nb lower-triangular block at L[l0][l0]:
+//   trans = 1:  X L^T = B  (forward over the block's columns: Cholesky panel, first RegMean solve)
+//   trans = 0:  X L   = B  (backward over the block's columns: second RegMean solve)
+// One thread per row, the triangle in LDS (broadcast reads).
+__global__ __launch_bounds__(64) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
+                                                        double* __restrict__ Bm, int ldb, int rows, int c0) {
+  __shared__ double s[64][65];
+  const int t = threadIdx.x;
+  for (int r = 0; r < nb; ++r)
+    if (t < nb) s[r][t] = L[(size_t)(l0 + r) * ldl + l0 + t];
+  __syncthreads();
+  const int row = blockIdx.x * 64 + t;
+  if (row >= rows) return;
+  double* x = Bm + (size_t)row * ldb + c0;
+  double v[64];
+#pragma unroll 8
+  for (int j = 0; j < nb; ++j) v[j] = x[j];
+  if (trans) {  // x_j = (b_j - sum_{k<j} x_k L[j][k]) / L[j][j]
+    for (int j = 0; j < nb; ++j) {
+      double acc = v[j];
+      for (int k = 0; k < j; ++k) acc -= v[k] * s[j][k];
+      v[j] = acc / s[j][j];
+    }
+  } else {      // x_j = (b_j - sum_{k>j} x_k L[k][j]) / L[j][j]
+    for (int j = nb - 1; j >= 0; --j) {
+      double acc = v[j];
+      for (int k = j + 1; k < nb; ++k) acc -= v[k] * s[k][j];
+      v[j] = acc / s[j][j];
+    }
+  }
+#pragma unroll 8
+  for (int j = 0; j < nb; ++j) x[j] = v[j];
+}
+
+extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* Bm, int ldb, int rows, int c0,
+                                  void* stream) {
+  if (nb == 0 || rows == 0) return VLM_OK;
+  if (!L || !Bm || nb < 0 || nb > 64 || rows < 0 || l0 < 0 || c0 < 0) return VLM_ERR_ARG;
+  hipLaunchKernelGGL(trsm_block_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, L, ldl, l0, nb, trans, Bm, ldb,
+                     rows, c0);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}

@@ -322,19 +322,27 @@ class GramCapture:
 
     def __init__(self):
         self.grams = {}
-        self._tmp = {}
 
     def add(self, name, x):
+        """G[name] += x^T x in float64 on the device (v_mfma_f64 SYRK, ops.gram_accumulate); x: bf16 or fp32 [rows, D]."""
         if name is None or x.shape[0] == 0:
             return
         D = x.shape[1]
         g = self.grams.get(name)
         if g is None:
             g = self.grams[name] = torch.zeros(D, D, device=x.device, dtype=torch.float64)
-        tmp = self._tmp.get(D)
-        if tmp is None:
-            tmp = self._tmp[D] = torch.empty(D, D, device=x.device, dtype=F32)
-        ops.gram_accumulate(x.contiguous(), g, tmp)
+        ops.gram_accumulate(x if x.stride(1) == 1 else x.contiguous(), g)
+
+    def all_reduce(self, group=None):
+        """Sum every accumulator over the ranks of a data-parallel evaluation (the reference's hooks run
+        under the Trainer on every rank and only rank-local sums reach its torch.save; here the float64 matrices are
+        all-reduced on the device -- one collective per matrix, same key set on every rank)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        for k in sorted(self.grams):
+            dist.all_reduce(self.grams[k], group=group)
+        return self
 
     def state_dict(self):
         """What the reference torch.save()s: name -> float64 CPU tensor (cache_gram_matrices.py:349)."""
@@ -431,11 +439,21 @@ class _BlockFn(torch.autograd.Function):
             ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
                      row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
         if pc.gram is not None:
+            # Gram cache: the LayerNorm outputs enter in fp32 (re-computed here, capture runs are not timed), like the
+            # fp32 activations the reference's hooks see; the attention output and the GELU output exist only as the bf16
+            # tensors the next GEMM consumes
             for r0, r1, e in plan.ranges:
                 gn = e.gram_names
-                pc.gram.add(gn.get("qkv"), ln1[r0:r1])
+                if gn.get("qkv") or gn.get("fc1"):
+                    t32 = torch.empty(r1 - r0, D, device=dev, dtype=F32)
+                    st = torch.empty(r1 - r0, 2, device=dev, dtype=F32)
+                    if gn.get("qkv"):
+                        ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, t32, st)
+                        pc.gram.add(gn.get("qkv"), t32)
+                    if gn.get("fc1"):
+                        ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, t32, st)
+                        pc.gram.add(gn.get("fc1"), t32)
                 pc.gram.add(gn.get("proj"), o[r0:r1])
-                pc.gram.add(gn.get("fc1"), ln2[r0:r1])
                 pc.gram.add(gn.get("fc2"), a[r0:r1])
         ctx.plan, ctx.pc, ctx.hook = plan, pc, hook
         ctx.has_bias = bias_t is not None

@@ -233,17 +233,94 @@ def droppath_rows(u, keep, seq, out):
 
 
 def gram_accumulate(x, gram64, tmp32=None):
-    """gram64 (float64 [D,D]) += x^T x for bf16 activations x [M,D] (the input of a hooked linear)."""
-    L.require_cuda(x, gram64, tmp32)
+    """gram64 (float64 [D,D]) += x^T x for bf16 or fp32 activations x [M,D] (the input of a hooked linear), in float64
+    on the device (include/vlm_hip.h vlm_gram_f64; cache_gram_matrices.py:246-254)."""
+    L.require_cuda(x, gram64)
     M, D = x.shape
     if gram64.dtype != torch.float64 or tuple(gram64.shape) != (D, D) or not gram64.is_contiguous():
         raise L.VlmError("gram accumulator must be a contiguous float64 [D,D] tensor")
-    if tmp32 is None:
-        tmp32 = torch.empty(D, D, device=x.device, dtype=F32)
-    gemm(x, x, tmp32, ta=True, tb=True)
-    L.check(L.get_lib().vlm_accumulate_f32_f64(L.ptr(tmp32), L.ptr(gram64), D * D, L.stream_ptr()),
-            "vlm_accumulate_f32_f64")
+    if x.dtype not in (BF16, F32):
+        raise L.VlmError("gram_accumulate: bf16 or fp32 activations")
+    L.check(L.get_lib().vlm_gram_f64(L.ptr(x), _ld(x), M, D, int(x.dtype == F32), L.ptr(gram64), L.stream_ptr()), "vlm_gram_f64")
     return gram64
+
+
+F64 = torch.float64
+
+
+def gemm_f64(a, b, c, ta=False, tb=False, alpha=1.0, beta=0.0):
+    """c[M,N] = alpha * op(a) op(b) + beta * c in float64 on v_mfma_f64 (a: float64 or float32, b / c: float64)."""
+    L.require_cuda(a, b, c)
+    if b.dtype != F64 or c.dtype != F64 or a.dtype not in (F64, F32):
+        raise L.VlmError("gemm_f64: a float64/float32, b and c float64")
+    M, N = c.shape
+    K = a.shape[0] if ta else a.shape[1]
+    if (a.shape[1] if ta else a.shape[0]) != M or (b.shape[1] if tb else b.shape[0]) != K or (b.shape[0] if tb else b.shape[1]) != N:
+        raise L.VlmError("gemm_f64: shapes %s %s -> %s" % (tuple(a.shape), tuple(b.shape), tuple(c.shape)))
+    if K == 0:
+        if beta == 0.0:
+            c.zero_()
+        return c
+    L.check(L.get_lib().vlm_gemm_f64(int(ta), int(tb), M, N, K, float(alpha), L.ptr(a), _ld(a), int(a.dtype == F32), L.ptr(b),
+                                     _ld(b), float(beta), L.ptr(c), _ld(c), L.stream_ptr()), "vlm_gemm_f64")
+    return c
+
+
+def scale_gram(src, dst, alpha, accumulate=False):
+    """dst (+)= alpha * src + (1 - alpha) * diag(src), float64 [n,n] (vilt_module.py:388-392)."""
+    L.require_cuda(src, dst)
+    n = src.shape[0]
+    if src.dtype != F64 or dst.dtype != F64 or tuple(src.shape) != (n, n) or tuple(dst.shape) != (n, n) \
+            or not src.is_contiguous() or not dst.is_contiguous():
+        raise L.VlmError("scale_gram: contiguous float64 [n,n] matrices")
+    L.check(L.get_lib().vlm_scale_gram_f64(L.ptr(src), L.ptr(dst), n, float(alpha), int(accumulate), L.stream_ptr()),
+            "vlm_scale_gram_f64")
+    return dst
+
+
+def cholesky_(s):
+    """In-place lower Cholesky factor of the SPD float64 matrix s [n,n] (upper triangle left undefined): blocked
+    right-looking factorisation, 64-wide block columns (potrf block, panel solve, MFMA-f64 trailing update)."""
+    L.require_cuda(s)
+    n = s.shape[0]
+    if s.dtype != F64 or tuple(s.shape) != (n, n) or not s.is_contiguous():
+        raise L.VlmError("cholesky_: contiguous float64 [n,n]")
+    lib, st = L.get_lib(), L.stream_ptr()
+    status = torch.zeros(1, device=s.device, dtype=torch.int32)
+    for j0 in range(0, n, 64):
+        nb = min(64, n - j0)
+        L.check(lib.vlm_potrf_block_f64(L.ptr(s), n, j0, nb, L.ptr(status), st), "vlm_potrf_block_f64")
+        r = n - j0 - nb
+        if r > 0:
+            below = s[j0 + nb:]
+            L.check(lib.vlm_trsm_block_f64(L.ptr(s), n, j0, nb, 1, L.ptr(below), n, r, j0, st), "vlm_trsm_block_f64")
+            panel = below[:, j0:j0 + nb]
+            gemm_f64(panel, panel, below[:, j0 + nb:], tb=True, alpha=-1.0, beta=1.0)
+    bad = int(status.item())
+    if bad:
+        raise L.VlmError("cholesky_: matrix is not positive definite (pivot %d)" % (bad - 1))
+    return s
+
+
+def solve_spd_right_(rhs, chol):
+    """rhs [rows, n] <- rhs (L L^T)^-1 in place, `chol` from cholesky_: Y L^T = rhs forward over the block columns, then
+    X L = Y backward (vlm_trsm_block_f64 on the diagonal blocks, MFMA-f64 GEMMs for the off-diagonal updates)."""
+    L.require_cuda(rhs, chol)
+    rows, n = rhs.shape
+    if rhs.dtype != F64 or chol.dtype != F64 or tuple(chol.shape) != (n, n) or not chol.is_contiguous() or rhs.stride(1) != 1:
+        raise L.VlmError("solve_spd_right_: float64 rhs [rows, n], contiguous float64 factor [n, n]")
+    lib, st = L.get_lib(), L.stream_ptr()
+    blocks = [(j0, min(64, n - j0)) for j0 in range(0, n, 64)]
+    for j0, nb in blocks:  # Y[:, jb] = (rhs[:, jb] - Y[:, :j0] L[jb, :j0]^T) L[jb, jb]^-T
+        if j0:
+            gemm_f64(rhs[:, :j0], chol[j0:j0 + nb, :j0], rhs[:, j0:j0 + nb], tb=True, alpha=-1.0, beta=1.0)
+        L.check(lib.vlm_trsm_block_f64(L.ptr(chol), n, j0, nb, 1, L.ptr(rhs), _ld(rhs), rows, j0, st), "vlm_trsm_block_f64")
+    for j0, nb in reversed(blocks):  # X[:, jb] = (Y[:, jb] - X[:, j1:] L[j1:, jb]) L[jb, jb]^-1
+        j1 = j0 + nb
+        if j1 < n:
+            gemm_f64(rhs[:, j1:], chol[j1:, j0:j1], rhs[:, j0:j1], alpha=-1.0, beta=1.0)
+        L.check(lib.vlm_trsm_block_f64(L.ptr(chol), n, j0, nb, 0, L.ptr(rhs), _ld(rhs), rows, j0, st), "vlm_trsm_block_f64")
+    return rhs
 
 
 def patch_im2col(image, patches, patch, lead_rows):

@@ -3,13 +3,16 @@
 Biases / q_bias / v_bias / LayerNorm tensors: plain averages through the HIP merge kernel (VLM_MERGE_MEAN,
 bit-exact with the reference: add in order, then divide by the count).  Linear weights:
 W* = (sum_m W_m G'_m)(sum_m G'_m)^-1 with G' = a*G + (1-a)*diag(G), kept in float64 like the reference.
-Round 1: the fp64 products and the inverse run through torch's ROCm libraries on the device (rocBLAS / rocSOLVER);
-a hand-written v_mfma_f64 SYRK/GEMM + Cholesky path is the next step for this row (DESIGN.md "RegMean").
+The fp64 products run on v_mfma_f64_16x16x4_f64 (csrc/f64ops.hip: vlm_gemm_f64 takes the fp32 weight directly); the
+reference's torch.inverse of the sum of Gram matrices is replaced by a blocked Cholesky factorisation (the sum of
+a*G + (1-a)*diag(G) of SPD Gram matrices is SPD for 0 <= a <= 1) and two triangular solves, ops.cholesky_ /
+ops.solve_spd_right_.  Same W* up to fp64 rounding (tests: 1e-8 relative against the reference's outputs).
 """
 import torch
 
 from . import _lib as L
 from . import merge as M
+from . import ops
 
 
 def scale_gram(G, alpha):
@@ -33,25 +36,34 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
                 srcs, through = M._collect(state_dict, src, dst, mods)
                 out[dst] = through if srcs is None else plan.add(L.MERGE_MEAN, [t for _, t in srcs], None)
                 continue
-            num, den, through = 0, 0, None
+            num, den, through = None, None, None
             for m in mods:
                 name = src(m)
                 gname = name.replace(".qkv.weight", "") if "qkv" in name else name.replace(".weight", "")
                 if name in state_dict:
                     if gname not in gram_matrices:
                         continue  # :419-420 (vl experts never get a gram)
-                    G = scale_gram(gram_matrices[gname].to(dev, torch.float64), alpha)
-                    den = den + G
-                    num = num + state_dict[name].to(dev, torch.float64) @ G
+                    G = gram_matrices[gname].to(dev, torch.float64).contiguous()
+                    Gs = torch.empty_like(G)
+                    ops.scale_gram(G, Gs, alpha)                         # G' = a G + (1 - a) diag(G)   (:388-392)
+                    W = state_dict[name].to(dev)
+                    W = W.contiguous() if W.dtype in (torch.float32, torch.float64) else W.double().contiguous()
+                    if num is None:
+                        den = Gs
+                        num = ops.gemm_f64(W, Gs, torch.empty(W.shape[0], G.shape[0], device=dev, dtype=torch.float64))
+                    else:
+                        ops.gemm_f64(W, Gs, num, beta=1.0)               # num += W_m.double() @ G'_m   (:421-423)
+                        den = den + Gs
                 else:
                     through = state_dict[dst]
                     break
             if through is not None:
                 out[dst] = through
-            elif isinstance(den, int):
-                out[dst] = num
+            elif num is None:
+                out[dst] = 0  # the reference's untouched accumulator (no modality had a gram; does not occur in practice)
             else:
-                out[dst] = num @ torch.inverse(den)  # stays float64 in the returned dict (:432-434)
+                # W* = num @ inverse(den) (:432-434), as a Cholesky solve; stays float64 in the returned dict
+                out[dst] = ops.solve_spd_right_(num, ops.cholesky_(den))
     if plan.jobs:
         plan.run()
     if plan_out is not None:
