@@ -128,9 +128,70 @@ def calibrate(dev):
             "d2d_copy_GBps": 2.0 * src.numel() * 4 / t_cp / 1e9}
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle (parity-pinned CPU restatement of the reference) on this host: base_vl ufo, 224x224, B=2,
-    mlm+itm+ifm fwd+bwd (BASELINE configs[0]); bounded sample."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_merge_baseline():
+    """The merge oracle (oracle/merge_oracle.py: C restatement of the reference's arithmetic, numpy float64 for RegMean)
+    on this host, base-size all_moe blocks: interpolation and task-vector over all 12 layers (median of 5 after 1
+    warm-up, GB/s over the same algorithmic bytes as the GPU figure), RegMean on a bounded 2-layer sample."""
+    import numpy as np
+    from oracle import merge_oracle as mo
+    from oracle import synth
+    from oracle.detweights import det_array, det_gram
+    D, Fd = 768, 3072
+    shapes = synth.block_shapes(D, Fd, "all_moe")
+    sd = {k: det_array(k, s) for k, (s, dt) in shapes.items()}
+    cfg = dict(vlffn_start_layer_index=10, only_activate_used_experts=False, merge_ratio=0.5, sum_lambda=0.75,
+               scaling_for_non_diag=0.9, loss_names={"irtr": 1})
+    central = {k: det_array(k, s, 7) for k, (s, dt) in synth.block_shapes(D, Fd, "ufo").items()}
+
+    def med(fn, n=5):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[n // 2], min(ts), max(ts)
+
+    out = {}
+    t, lo, hi = med(lambda: mo.merge_weights(sd, cfg))
+    moved = 0
+    res = mo.merge_weights(sd, cfg)
+    for k, v in res.items():  # algorithmic bytes: 4 B written + 4 B per source read, for every merged output
+        srcs = [kk for kk in sd if kk != k and kk.replace(".v.", ".").replace(".l.", ".").replace(".vl.", ".") == k]
+        if srcs:
+            moved += np.asarray(v).nbytes * (1 + len(srcs))
+    out["interpolation"] = {"seconds_median": t, "seconds_min_max": [lo, hi], "GBps": moved / t / 1e9, "bytes": moved}
+    t, lo, hi = med(lambda: mo.sum_task_vectors(sd, cfg, central))
+    out["task_vector"] = {"seconds_median": t, "seconds_min_max": [lo, hi]}
+    layers = (0, 11)
+    sub = {k: v for k, v in sd.items() if int(k.split(".")[2]) in layers}
+    for k, (shp, dt) in synth.block_shapes(D, Fd, "ufo").items():
+        if int(k.split(".")[2]) not in layers and "gamma" not in k:
+            sub[k] = central[k]
+    grams = {k: det_gram(k, shp[0]) for k, shp in synth.gram_shapes(D, Fd).items() if int(k.split(".")[2]) in layers}
+    t0 = time.perf_counter()
+    mo.regmean(sub, cfg, grams)
+    t = time.perf_counter() - t0
+    out["regmean"] = {"seconds": t, "sample": "2 of 12 layers (8 weight matrices: 6 inverses of 768^2, 2 of 3072^2), numpy float64",
+                      "seconds_scaled_to_12_layers": 6 * t}
+    return out
+
+
+def cpu_baseline():
+    """The oracle (parity-pinned CPU restatement of the reference) on this host's cores: base_vl ufo, 224x224, B=2,
+    mlm+itm+ifm fwd+bwd (BASELINE configs[0]): 2 warm-up + 5 timed iterations, median and
+    spread; CPU model and thread count stated; plus the merge oracle (cpu_merge_baseline)."""
     from oracle import vlmo_ref as R
     pkg_vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
     torch.manual_seed(0)
@@ -179,19 +240,25 @@ def cpu_baseline(seconds_budget=30.0):
     batch = dict(b)
     batch["image"] = b["image"][0]
     times = []
-    t_all = time.time()
-    for it in range(4):
-        t0 = time.time()
+    for it in range(7):
+        t0 = time.perf_counter()
         out = R.pretrain_step(sd, a, idx, batch)
         out["total_loss"].backward()
-        times.append(time.time() - t0)
-        if time.time() - t_all > seconds_budget:
-            break
-    use = times[1:] if len(times) > 1 else times
-    per_iter = sorted(use)[len(use) // 2]
-    return {"value": 2.0 / per_iter, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/vlmo_ref.py pretrain_step fwd+bwd, base_vl ufo 224^2 T=40 B=2 (BASELINE configs[0]), "
-                      "%d iteration(s) after 1 warm-up, fp32" % len(use)}
+        for v in sd.values():
+            v.grad = None
+        if it >= 2:
+            times.append(time.perf_counter() - t0)
+    per_iter = sorted(times)[len(times) // 2]
+    res = {"value": 2.0 / per_iter, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(),
+           "seconds_per_iteration": {"median": per_iter, "min": min(times), "max": max(times)},
+           "sample": "oracle/vlmo_ref.py pretrain_step fwd+bwd, base_vl ufo 224^2 T=40 B=2 (BASELINE configs[0]), "
+                     "5 timed iterations after 2 warm-ups, fp32, torch CPU threads = cores"}
+    try:
+        res["merge"] = cpu_merge_baseline()
+    except Exception as e:  # the baseline must never take the GPU number down with it
+        res["merge"] = {"error": repr(e)}
+    return res
 
 
 def main():

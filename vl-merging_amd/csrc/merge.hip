@@ -8,6 +8,8 @@
 // the first use.  Compiled with -ffp-contract=off and written with __fmul_rn/__fadd_rn so that no FMA is
 // formed: the reference's CPU path rounds after the multiply and after every add (SURVEY.md 7 "hard parts").
 #include "vlm_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -43,7 +45,16 @@ __device__ __forceinline__ float merge_scalar(const vlm_merge_job_t& j, float ba
   return acc;
 }
 
-template <int MODE, int NSRC>
+// cache policy of the streams (measured per box by tools/bench_merge_variants.py, see vlm_merge_run)
+template <bool NT>
+__device__ __forceinline__ f32x4 merge_ld(const f32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void merge_st(f32x4 v, f32x4* p) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <int MODE, int NSRC, bool NTL, bool NTS>
 __device__ __forceinline__ void merge_chunk_vec(const vlm_merge_job_t& j, uint64_t start4, uint64_t n4) {
   // 4 float4 per thread per chunk, strided by the block so every wave instruction is 1 KiB contiguous
   f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(j.dst);
@@ -63,8 +74,8 @@ __device__ __forceinline__ void merge_chunk_vec(const vlm_merge_job_t& j, uint64
     idx[u] = start4 + threadIdx.x + u * MERGE_THREADS;
     if (idx[u] < n4) {
 #pragma unroll
-      for (int m = 0; m < NSRC; ++m) v[u][m] = __builtin_nontemporal_load(&s[m][idx[u]]);
-      if (MODE == VLM_MERGE_TASKVEC) b[u] = __builtin_nontemporal_load(&base[idx[u]]);
+      for (int m = 0; m < NSRC; ++m) v[u][m] = merge_ld<NTL>(&s[m][idx[u]]);
+      if (MODE == VLM_MERGE_TASKVEC) b[u] = merge_ld<NTL>(&base[idx[u]]);
     }
   }
 #pragma unroll
@@ -92,21 +103,22 @@ __device__ __forceinline__ void merge_chunk_vec(const vlm_merge_job_t& j, uint64
         }
         o[c] = acc;
       }
-      __builtin_nontemporal_store(o, &dst[idx[u]]);
+      merge_st<NTS>(o, &dst[idx[u]]);
     }
   }
 }
 
-template <int MODE>
+template <int MODE, bool NTL, bool NTS>
 __device__ __forceinline__ void merge_chunk_mode(const vlm_merge_job_t& j, uint64_t start4, uint64_t n4) {
   switch (j.n_src) {
-    case 1: merge_chunk_vec<MODE, 1>(j, start4, n4); break;
-    case 2: merge_chunk_vec<MODE, 2>(j, start4, n4); break;
-    case 3: merge_chunk_vec<MODE, 3>(j, start4, n4); break;
-    default: merge_chunk_vec<MODE, 4>(j, start4, n4); break;
+    case 1: merge_chunk_vec<MODE, 1, NTL, NTS>(j, start4, n4); break;
+    case 2: merge_chunk_vec<MODE, 2, NTL, NTS>(j, start4, n4); break;
+    case 3: merge_chunk_vec<MODE, 3, NTL, NTS>(j, start4, n4); break;
+    default: merge_chunk_vec<MODE, 4, NTL, NTS>(j, start4, n4); break;
   }
 }
 
+template <bool NTL, bool NTS>
 __global__ __launch_bounds__(MERGE_THREADS) void vlm_merge_kernel(const unsigned char* __restrict__ ws) {
   const merge_header_t* hdr = reinterpret_cast<const merge_header_t*>(ws);
   const vlm_merge_job_t* jobs = reinterpret_cast<const vlm_merge_job_t*>(ws + hdr->jobs_off);
@@ -117,9 +129,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void vlm_merge_kernel(const unsigned
     const vlm_merge_job_t& j = jobs[ck.job];  // block-uniform => scalar loads
     const uint64_t n4 = j.n_elem >> 2;
     const uint64_t start4 = ck.start4;
-    if (j.mode == VLM_MERGE_LERP) merge_chunk_mode<VLM_MERGE_LERP>(j, start4, n4);
-    else if (j.mode == VLM_MERGE_TASKVEC) merge_chunk_mode<VLM_MERGE_TASKVEC>(j, start4, n4);
-    else merge_chunk_mode<VLM_MERGE_MEAN>(j, start4, n4);
+    if (j.mode == VLM_MERGE_LERP) merge_chunk_mode<VLM_MERGE_LERP, NTL, NTS>(j, start4, n4);
+    else if (j.mode == VLM_MERGE_TASKVEC) merge_chunk_mode<VLM_MERGE_TASKVEC, NTL, NTS>(j, start4, n4);
+    else merge_chunk_mode<VLM_MERGE_MEAN, NTL, NTS>(j, start4, n4);
     // ragged tail (n_elem % 4) belongs to the chunk that holds the last float4 (or chunk 0 of a tiny job)
     const uint64_t tail0 = n4 << 2;
     const bool last = (start4 + (MERGE_CHUNK / 4) >= n4);
@@ -198,11 +210,26 @@ extern "C" int vlm_merge_plan_upload(const vlm_merge_job_t* jobs, int n_jobs, vo
 
 extern "C" int vlm_merge_run(const void* workspace, void* stream) {
   if (!workspace) return VLM_ERR_ARG;
-  // grid: 8 blocks per CU keeps >= 2 KiB x n_src of loads in flight per SIMD; chunk loop strides the grid
+  // grid: G blocks per CU keep >= 2 KiB x n_src of loads in flight per SIMD; the chunk loop strides the grid.
+  // VLM_MERGE_VARIANT="<blocks per CU>,<nt loads 0/1>,<nt stores 0/1>" overrides the default (measurement switch).
+  static int blocks_per_cu = 96, ntl = 1, nts = 1, parsed = 0;
+  if (!parsed) {
+    parsed = 1;
+    const char* v = getenv("VLM_MERGE_VARIANT");
+    if (v) sscanf(v, "%d,%d,%d", &blocks_per_cu, &ntl, &nts);
+    if (blocks_per_cu < 1 || blocks_per_cu > 256) blocks_per_cu = 96;
+  }
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;
-  dim3 grid(cus * 8), block(MERGE_THREADS);
-  hipLaunchKernelGGL(vlm_merge_kernel, grid, block, 0, (hipStream_t)stream, (const unsigned char*)workspace);
+  // 96 blocks per CU (8 resident at a time): 5.74 TB/s against 5.53 at 24 and 5.50 at 8 on one box, 5.89 against 5.50 on another:
+  // late-finishing blocks no longer hold a whole stride of chunks back (tools/bench_merge_variants.py; nt loads + nt stores win)
+  dim3 grid(cus * blocks_per_cu), block(MERGE_THREADS);
+  const unsigned char* ws = (const unsigned char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  if (ntl && nts) hipLaunchKernelGGL((vlm_merge_kernel<true, true>), grid, block, 0, s, ws);
+  else if (ntl) hipLaunchKernelGGL((vlm_merge_kernel<true, false>), grid, block, 0, s, ws);
+  else if (nts) hipLaunchKernelGGL((vlm_merge_kernel<false, true>), grid, block, 0, s, ws);
+  else hipLaunchKernelGGL((vlm_merge_kernel<false, false>), grid, block, 0, s, ws);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
