@@ -279,6 +279,79 @@ def gold_irtr():
         np.savez_compressed(os.path.join(HERE, f"irtr_tiny_{arch}.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- vlmo checkpoint adaptation + schedule
+def vlmo_ckpt_inputs(hidden=768, heads=12, layers=12, src_window=14, text_len=60):
+    """A 224^2-pretrained VLMo checkpoint's size-dependent tensors (vilt_module.py:749-806 reads only these): the
+    relative-position table of a 14x14 window with max_text_len_of_initckpt = 196, a longer text position table and the
+    index buffers the reference pops."""
+    n_rel = (2 * src_window - 1) ** 2 + 3
+    R_src = n_rel + 2 * 196 + 2
+    return {"relative_position_bias_table": det_array("ckpt224.relative_position_bias_table", (R_src, heads * layers)),
+            "text_embeddings.position_embeddings.weight": det_array("ckpt224.pos", (text_len, hidden)),
+            "text_embeddings.position_ids": np.arange(text_len, dtype=np.int64)[None],
+            "relative_position_index": np.zeros((4, 4), dtype=np.int64),
+            "text_relative_position_index": np.zeros((4, 4), dtype=np.int64),
+            "text_imag_relative_position_index": np.zeros((4, 4), dtype=np.int64),
+            "transformer.cls_token": det_array("ckpt224.cls", (1, 1, hidden))}
+
+
+def gold_vlmo_resize():
+    """modify_checkpoint_vlmo of the REFERENCE on a 224^2 checkpoint loaded into a 384^2 model: the bicubic 27x27 ->
+    47x47 resize of the table body, the untouched tail rows, the truncated text positions, the popped buffers."""
+    cfg = base_config(vit="vit_base_patch16_384", image_size=384, hidden_size=768, num_heads=12, max_text_len=40,
+                      vocab_size=64, loss_names={"irtr": 1})
+    model, cfg = build_reference_model(cfg, "ufo")
+    sd = {k: torch.from_numpy(v) for k, v in vlmo_ckpt_inputs().items()}
+    res = model.modify_checkpoint_vlmo({"state_dict": sd})
+    out = {"__keys__": np.array(json.dumps(sorted(res.keys())))}
+    for k, v in res.items():
+        a = v.contiguous().numpy()
+        out[k + "/sha256"] = np.array(sha(a))
+        out[k + "/shape"] = np.array(a.shape)
+        if k == "relative_position_bias_table":
+            out[k + "/rows"] = a[::97]   # every 97th row of the resized table (the digest pins the rest)
+        elif a.size <= 4096:
+            out[k] = a
+    print("vlmo resize:", {k: tuple(v.shape) for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, "vlmo_resize.npz"), **out)
+
+
+def gold_schedule():
+    """The reference's set_schedule (vilt_utils.py:225-359) on tiny models: which parameter lands in which of the four
+    groups (weight decay, lr multiplier) and the learning-rate factor of the polynomial-decay-with-warm-up schedule
+    at chosen steps.  AdamW = the torch.optim stub of ref_harness (only the param_groups are read)."""
+    vm, vit, obj = import_reference()
+    from vilt.modules import vilt_utils
+    out = {}
+    for tag, arch, over in (("pretrain_all_moe", "all_moe", dict(loss_names={"itm": 1, "mlm": 1, "ifm": 1}, warmup_steps=2500,
+                                                                  max_steps=200000)),
+                            ("vqa_ufo_mult", "ufo", dict(loss_names={"vqa": 1}, vqav2_label_size=37, lr_mult=10, warmup_steps=0.1,
+                                                         max_steps=1000, all_mlp_mult=True, weight_decay_custom_modules=0.05,
+                                                         learning_rate=3e-5, end_lr=1e-7, decay_power=2)),
+                            ("irtr_all_moe_vlmult", "all_moe", dict(loss_names={"irtr": 1}, all_vl_mult=True, lr_mult=5,
+                                                                     warmup_steps=0.1, max_steps=500))):
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_text_len=40, vocab_size=64, **over)
+        model, cfg = build_reference_model(cfg, arch)
+        model.trainer = types.SimpleNamespace(max_steps=cfg["max_steps"])
+        (opt,), (sch,) = vilt_utils.set_schedule(model)
+        ids = {id(p): n for n, p in model.named_parameters()}
+        groups = []
+        for g in opt.param_groups:
+            groups.append({"weight_decay": g["weight_decay"], "initial_lr": g.get("initial_lr", g["lr"]),
+                           "names": sorted(ids[id(p)] for p in g["params"])})
+        steps = [0, 1, 10, cfg["max_steps"] // 20, cfg["max_steps"] // 10, cfg["max_steps"] // 2, cfg["max_steps"] - 1,
+                 cfg["max_steps"], cfg["max_steps"] + 5]
+        lam = sch["scheduler"].lr_lambdas[0]
+        out[tag] = {"config": {k: cfg[k] for k in ("learning_rate", "weight_decay", "weight_decay_custom_modules", "lr_mult",
+                                                   "end_lr", "decay_power", "warmup_steps", "max_steps", "all_mlp_mult",
+                                                   "all_vl_mult", "all_v_mult", "all_l_mult", "beta_2")},
+                    "arch": arch, "loss_names": {k: v for k, v in cfg["loss_names"].items() if v},
+                    "groups": groups, "steps": steps, "lr_factor": [float(lam(s)) for s in steps]}
+        print(tag, [len(g["names"]) for g in groups], out[tag]["lr_factor"][:4])
+    with open(os.path.join(HERE, "schedule_groups.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 # ----------------------------------------------------------------------------- RegMean at base size
 REGMEAN_BASE_LAYERS = (0, 11)  # the reference takes ~4 s per 3072^2 inverse on this box: two layers pin the arithmetic
 
@@ -746,4 +819,5 @@ if __name__ == "__main__":
     for w in what:
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
          "irtr": gold_irtr, "model_base": gold_model_base, "irtr_merged_base": gold_irtr_merged_base,
-         "train_tiny": gold_train_tiny, "regmean_base": gold_regmean_base, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()
+         "train_tiny": gold_train_tiny, "regmean_base": gold_regmean_base, "vlmo_resize": gold_vlmo_resize, "schedule": gold_schedule,
+         "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()

@@ -139,3 +139,78 @@ def test_flat_params_qkv_bias_view():
     assert view.data_ptr() == m.q_bias.data_ptr() and view.numel() == 3 * kq
     assert torch.equal(view, torch.cat([q0, torch.zeros(128), v0]))
     assert flat.slice_of(["attn.q_bias"]) == (oq, oq + 2 * kq)
+
+
+def test_param_groups_and_schedule_match_reference_set_schedule(pkg, cfgmod, vm, golden_dir):
+    """The reference's own set_schedule (vilt_utils.py:225-359) on tiny models (tests/golden/schedule_groups.json, made by
+    make_golden.py schedule): which parameter name lands in which of the four groups, each group's weight decay and
+    learning rate, and the lr factor of the polynomial schedule at chosen steps (int and fractional warm-up, lr_mult,
+    all_mlp_mult / all_vl_mult, decay_power 1 and 2, end_lr)."""
+    import json
+    vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
+    gold = json.load(open(os.path.join(golden_dir, "schedule_groups.json")))
+    assert set(gold) == {"pretrain_all_moe", "vqa_ufo_mult", "irtr_all_moe_vlmult"}
+    for tag, g in gold.items():
+        over = dict(g["config"])
+        cfg = cfgmod.make_config(g["arch"], vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, vocab_size=64,
+                                 max_text_len=40, patch_size=16, vlffn_start_layer_index=10, image_size=224,
+                                 vqav2_label_size=37, loss_names=cfgmod._loss_names(g["loss_names"]), **over)
+        model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+        heads = vu.head_names(cfg)
+        mine = [[], [], [], []]
+        for n, _ in model.named_parameters():
+            mine[vu.param_group_of(n, heads)].append(n)
+        spec = vu.group_spec(cfg)
+        for gi, ref in enumerate(g["groups"]):
+            assert sorted(mine[gi]) == ref["names"], (tag, gi, sorted(set(mine[gi]) ^ set(ref["names"]))[:6])
+            assert spec[gi][0] == ref["weight_decay"] and abs(spec[gi][1] - ref["initial_lr"]) <= 1e-18, (tag, gi)
+        lam = vu.schedule_lambda(cfg, cfg["max_steps"])
+        for s_, want in zip(g["steps"], g["lr_factor"]):
+            assert abs(lam(s_) - want) <= 1e-15, (tag, s_, lam(s_), want)
+
+
+def test_modify_checkpoint_vlmo_matches_reference(cfgmod, vm, golden_dir):
+    """A 224^2 checkpoint into a 384^2 model (vilt_module.py:749-806): bicubic 27x27 -> 47x47 resize of the table body,
+    tail rows carried over, text positions truncated, index buffers dropped -- bit for bit what the reference's
+    modify_checkpoint_vlmo returns on the same input (tests/golden/vlmo_resize.npz: sha256 of every tensor, sampled rows)."""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden import vlmo_ckpt_inputs  # inputs only (seed-derived), no reference import at module scope
+    gold = np.load(os.path.join(golden_dir, "vlmo_resize.npz"))
+    cfg = cfgmod.make_config("ufo", vit="vit_base_patch16_384", hidden_size=768, num_heads=12, vocab_size=64,
+                             max_text_len=40, patch_size=16, vlffn_start_layer_index=10, image_size=384,
+                             loss_names=cfgmod._loss_names({"irtr": 1}))
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    sd = {k: torch.from_numpy(v) for k, v in vlmo_ckpt_inputs().items()}
+    res = model.modify_checkpoint_vlmo({"state_dict": sd})
+    assert sorted(res.keys()) == json.loads(str(gold["__keys__"]))
+    for k, v in res.items():
+        a = np.ascontiguousarray(v.contiguous().numpy())
+        assert list(a.shape) == list(gold[k + "/shape"]), k
+        if k == "relative_position_bias_table":
+            np.testing.assert_array_equal(a[::97], gold[k + "/rows"])
+        assert hashlib.sha256(a.tobytes()).hexdigest() == str(gold[k + "/sha256"]), k
+
+
+def test_reference_artefacts_load(tmp_path, cfgmod, vm):
+    """The reference's own files are pickles of non-tensor objects: cache_gram_matrices.py saves a defaultdict(float)
+    (:349), Lightning checkpoints carry hyper-parameter objects.  torch >= 2.6 refuses those under its weights_only
+    default; the loaders here (checkpoint.load_file) read them."""
+    import collections
+    import types
+    ck = importlib.import_module("vl_merging_amd.checkpoint")
+    grams = collections.defaultdict(float)
+    grams["transformer.blocks.0.attn.v"] += torch.eye(4, dtype=torch.float64)
+    gp = os.path.join(tmp_path, "grams.pth")
+    torch.save(grams, gp)
+    with pytest.raises(Exception):
+        torch.load(gp, map_location="cpu", weights_only=True)
+    back = ck.load_file(gp)
+    assert isinstance(back, collections.defaultdict) and torch.equal(back["transformer.blocks.0.attn.v"], torch.eye(4, dtype=torch.float64))
+    cp = os.path.join(tmp_path, "model.ckpt")
+    torch.save({"state_dict": {"w": torch.ones(3)}, "hyper_parameters": types.SimpleNamespace(config={"a": 1}),
+                "callbacks": {collections.OrderedDict: 1}}, cp)
+    assert torch.equal(ck.load_ckpt(cp)["w"], torch.ones(3))
+    assert torch.equal(ck.load_file(cp)["state_dict"]["w"], torch.ones(3))

@@ -215,12 +215,29 @@ def _merge_ranges(ranges):
     return out
 
 
+def group_spec(cfg):
+    """(weight_decay, lr) of the four parameter groups, vilt_utils.py:272-312."""
+    lr, wd = cfg["learning_rate"], cfg["weight_decay"]
+    return [(wd, lr), (0.0, lr), (cfg["weight_decay_custom_modules"], lr * cfg["lr_mult"]), (0.0, lr * cfg["lr_mult"])]
+
+
+def schedule_lambda(cfg, max_steps):
+    """lr factor as a function of the step, vilt_utils.py:330-352 (float warm-up = fraction of max_steps)."""
+    warmup = cfg["warmup_steps"]
+    if isinstance(warmup, float):
+        warmup = int(max_steps * warmup)
+    if cfg["decay_power"] == "cosine":
+        raise NotImplementedError("cosine schedule is not used by the hot-path configs")
+    lr = cfg["learning_rate"]
+    return lambda s: polynomial_decay_lambda(s, warmup, max_steps, lr, cfg["end_lr"], cfg["decay_power"])
+
+
 def set_schedule(pl_module, max_steps=None):
     cfg = pl_module.hparams.config
     pl_module._ensure_engine()
-    lr, wd = cfg["learning_rate"], cfg["weight_decay"]
+    lr = cfg["learning_rate"]
     heads = head_names(cfg)
-    spec = [(wd, lr), (0.0, lr), (cfg["weight_decay_custom_modules"], lr * cfg["lr_mult"]), (0.0, lr * cfg["lr_mult"])]
+    spec = group_spec(cfg)
     flat = pl_module._flat
     buckets = [[] for _ in range(4)]
     for n in flat.names:
@@ -237,11 +254,5 @@ def set_schedule(pl_module, max_steps=None):
             max_steps = cfg["max_steps"]
         if max_steps is None:
             raise ValueError("max_steps must be given when the config leaves it to the dataloader length")
-    warmup = cfg["warmup_steps"]
-    if isinstance(warmup, float):
-        warmup = int(max_steps * warmup)
-    if cfg["decay_power"] == "cosine":
-        raise NotImplementedError("cosine schedule is not used by the hot-path configs")
-    sched = LambdaSchedule(optimizer, lambda s: polynomial_decay_lambda(s, warmup, max_steps, lr, cfg["end_lr"],
-                                                                        cfg["decay_power"]))
+    sched = LambdaSchedule(optimizer, schedule_lambda(cfg, max_steps))
     return [optimizer], [{"scheduler": sched, "interval": "step"}]
