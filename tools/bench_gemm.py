@@ -1,4 +1,5 @@
-"""GEMM micro-benchmark at the training shapes (M = 22*617 tokens)."""
+"""GEMM micro-benchmark at the training shapes (M = 22*617 tokens, or argv[1]): vlm_gemm_bf16 next to the vendor library
+(hipBLASLt through torch.matmul, same operand layouts, bf16 output) on the same box, shape by shape."""
 import importlib
 import sys
 
@@ -32,17 +33,22 @@ def main():
               ("fc1 wgrad", True, True, 3072, 768, M), ("fc2 wgrad", True, True, 768, 3072, M),
               ("qkv wgrad", True, True, 2304, 768, M), ("square 4096", False, False, 4096, 4096, 4096),
               ("text qkv", False, False, 880, 2304, 768)]
-    tot_t = tot_f = 0
+    tot_t = tot_f = tot_v = 0
     for name, ta, tb, m, n, k in shapes:
         a = torch.randn((k, m) if ta else (m, k), device="cuda").to(torch.bfloat16)
         b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.float32 if ta else torch.bfloat16)
         t = timeit(lambda: ops.gemm(a, b, out, ta, tb, accumulate=bool(ta)))
         fl = 2.0 * m * n * k
-        print("%-12s M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s" % (name, m, n, k, t, fl / t / 1e6))
+        am = a.t() if ta else a          # [m, k] view in the stored layout
+        bm = b if tb else b.t()          # [k, n] view
+        ref = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+        tv = timeit(lambda: torch.matmul(am, bm, out=ref))
+        print("%-12s M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s   | hipBLASLt %8.1f us  %7.1f TFLOP/s  (ours / vendor = %.2f)"
+              % (name, m, n, k, t, fl / t / 1e6, tv, fl / tv / 1e6, tv / t))
         if "square" not in name:
-            tot_t += t; tot_f += fl
-    print("weighted over training shapes: %.1f TFLOP/s" % (tot_f / tot_t / 1e6))
+            tot_t += t; tot_f += fl; tot_v += tv
+    print("weighted over training shapes: %.1f TFLOP/s (hipBLASLt: %.1f TFLOP/s)" % (tot_f / tot_t / 1e6, tot_f / tot_v / 1e6))
 
 
 if __name__ == "__main__":

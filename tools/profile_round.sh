@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel-trace stats + three separate PMC passes over the SAME bench command, condensed into
+# gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: tools/profile_round.sh r02
+TAG=${1:-r02}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- $CMD > $OUT/trace.log 2>&1
+PMC="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calibrate --no-gemm-timer"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o run -- $PMC > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o run -- $PMC > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- $PMC > $OUT/pmc_write.log 2>&1
+cd $ROOT
+python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate under rocprofv3 --kernel-trace --stats; 6 steps + merge bench"
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/traffic.txt
+python3 - <<PY
+import collections, csv, glob, json, re
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for f in glob.glob("$OUT/pmc_mfma/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"[<(].*", "", r["Kernel_Name"]).replace("void ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+res = {}
+for k, v in acc.items():
+    if ("attn" in k or "vlm_gemm" in k or "merge" in k) and v.get("GRBM_GUI_ACTIVE"):
+        # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+        res[k] = {"launches": n[(k, "GRBM_GUI_ACTIVE")], "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)}
+json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 2 --warmup 1: busy cycles summed over the 1024 SIMDs / (1024 x per-XCD active cycles), time-weighted over all launches of a kernel", "kernels": res}, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+tail -1 $OUT/trace.log | cut -c1-400 > $OUT/${TAG}_bench_line_under_trace.txt
+head -25 $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&qkv, hq.size() * 2)); CK(hipMemcpy(qkv, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
   CK(hipMalloc(&out, (size_t)rows * D * 2)); CK(hipMalloc(&dout, (size_t)rows * D * 2)); CK(hipMalloc(&dqkv, (size_t)rows * 3 * D * 2));
   CK(hipMemcpy(dout, hq.data(), (size_t)rows * D * 2, hipMemcpyHostToDevice));
-  CK(hipMalloc(&lse, (size_t)H * rows * 4)); CK(hipMalloc(&delta, (size_t)H * rows * 4));
+  CK(hipMalloc(&lse, (size_t)H * rows * 4)); CK(hipMalloc(&delta, (size_t)H * rows * 4 + ((size_t)64 << 20)));
   std::vector<float> hb((size_t)ncols * R);
   for (auto& v : hb) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
   CK(hipMalloc(&bias_t, hb.size() * 4)); CK(hipMemcpy(bias_t, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
   d.bias_dense = dense; d.bias_dense_t = dense_t; d.dense_tiles = (int)(cb / 4096);
   auto run = [&]() {
     int rc = what == 0 ? vlm_attention_fwd(&d, out, D, lse, 0)
-                       : vlm_attention_bwd(&d, out, D, dout, D, lse, delta, dqkv, 3 * D, with_bias ? dbias : nullptr, nullptr, 0);
+                       : vlm_attention_bwd(&d, out, D, dout, D, lse, delta, vlm_attention_bwd_ws_floats(&d, 1), dqkv, 3 * D, with_bias ? dbias : nullptr, nullptr, 0);
     if (rc) { printf("launch failed rc=%d\n", rc); exit(1); }
   };
   if (what == 1) { int rc = vlm_attention_fwd(&d, out, D, lse, 0); if (rc) { printf("fwd rc=%d\n", rc); return 1; } }

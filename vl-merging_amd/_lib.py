@@ -79,7 +79,8 @@ SIGNATURES = {
     "vlm_gemm_bf16": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                               c_int, ctypes.POINTER(Epilogue), c_void_p]),
     "vlm_attention_fwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_void_p]),
-    "vlm_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+    "vlm_attention_bwd_ws_floats": (c_size_t, [ctypes.POINTER(AttnDesc), c_int]),
+    "vlm_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vlm_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p]),

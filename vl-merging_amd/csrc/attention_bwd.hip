@@ -43,6 +43,7 @@ struct attn_bwd_params_t {
   bf16_t* dqkv;           // [rows, 3*H*64]
   int ld_dqkv;
   float* dbias_t;         // [n_cols, R] accumulate
+  float* dbias_part;      // [items][R] per-workgroup histograms (two-stage reduction) or NULL (global atomics)
   float* dq_colsum[2];    // per segment (0 text rows, 1 image rows): [H*64] += column sums of dQ (q_bias grad) or NULL
   float* dv_colsum[2];    // same for dV (v_bias gradient)
 };
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
     const bool masked = tile_masked(kp0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+#ifndef ATT_DQ_NOPREFETCH
       bf16x8 kfr[4], vfr[4];
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
@@ -155,12 +157,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         vfr[ss] = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
       }
       __builtin_amdgcn_sched_barrier(0);
+#endif
       f32x16 e = neglse, dp = negdel;
       if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[kb], e);
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
+#ifdef ATT_DQ_NOPREFETCH
+        const bf16x8 ka = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh), va = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
+        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ss], e, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ss], dp, 0, 0, 0);
+#else
         e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ss], qf[ss], e, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ss], dof[ss], dp, 0, 0, 0);
+#endif
       }
       if (masked) {  // workgroup-uniform
 #pragma unroll
@@ -335,12 +344,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
     const float* st = qstat + cur * 128;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+#ifdef ATT_DKV_PREFETCH  // (explicit fragment prefetch measured 11 % slower here: 256 VGPRs and spills)
       bf16x8 qfr[4], ofr[4];
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
         qfr[ss] = att_k_rowfrag(lq, qb * 32 + r, 2 * ss + hh);
         ofr[ss] = att_k_rowfrag(lo, qb * 32 + r, 2 * ss + hh);
       }
+#endif
       f32x16 e, dp;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -349,7 +360,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
 #pragma unroll
         for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
       }
+#ifdef ATT_DKV_PREFETCH
       __builtin_amdgcn_sched_barrier(0);
+#endif
       if (wave_masked) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] += kmaskv;
@@ -357,8 +370,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[qb], e);
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
+#ifndef ATT_DKV_PREFETCH
+        const bf16x8 qa = att_k_rowfrag(lq, qb * 32 + r, 2 * ss + hh), oa = att_k_rowfrag(lo, qb * 32 + r, 2 * ss + hh);
+        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ss], e, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
+#else
         e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ss], kf[ss], e, 0, 0, 0);     // E[q][key]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ss], vf[ss], dp, 0, 0, 0);   // dP[q][key]
+#endif
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -435,199 +454,271 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
 }
 
 // ---------------------------------------------------------------------------------------------- dBias kernel
-// d(bias table column)[idx[q][key]] += sum_b dS[b,h,q,key].  LDS float atomics cost ~300 cycles per wave instruction
-// on gfx950 (measured: the histogram inside the dK/dV kernel took 4x the rest of the backward), so the batch sum is
-// taken FIRST, in registers: one workgroup owns a (128-key, 64-query) tile pair of one head, loops over the B
-// samples recomputing S and dP (2 of the 7 MFMA products), and only then feeds the 8192 summed dS values through
-// the LDS histogram (B-fold fewer atomics), with the all-indices-equal tiles (text->image pairs share ONE table
-// row, vilt_module.py:180-181) reduced in registers instead.
-__global__ __launch_bounds__(ATT_THREADS, 3) void attn_bwd_dbias_kernel(const attn_bwd_params_t bp) {
-  // Every operand tile is fetched COOPERATIVELY (one wave instruction = 8 rows x 128 B = 8 cache lines) and the MFMA
-  // fragments are read from LDS: per-lane row-fragment loads straight from global memory put 64 different cache
-  // lines behind every wave instruction and left the kernel bound by the CU's address coalescer (measured 216 us;
-  // the MFMA work is ~30 us).
+// d(bias table column)[idx[q][key]] += sum_b dS[b,h,q,key] (autograd of F.embedding in get_rel_pos_bias,
+// vilt_module.py:1061-1064).  The sum over the samples is taken FIRST, in registers: a scatter of every sample's dS would
+// cost B times the atomics, so one workgroup owns a (128-key x 128-query) tile of one head, walks its share of the
+// samples recomputing E and dP (2 of the 5 MFMA products of the backward, with the same matrix-pipe formulation as
+// the dQ / dK-dV kernels: tiled fp16 bias through selection MFMAs, -lse / -delta as C operands) and only then feeds the
+// summed dS through an LDS histogram -> global atomics.
+// 8 waves: wave (kw = wave & 3, qh = wave >> 2) owns 32 keys x 64 queries; per sample the four operand tiles (K, V of
+// the 128 keys, Q, dO of the 128 queries: 64 KB) are staged global -> VGPR -> LDS by all 512 threads, the next sample's
+// loads in flight during this sample's MFMAs.  [Round 1: 32 x 128 tiles moved 40 KB per 8 MFMAs per wave and gathered
+// the bias from an LDS table per element; this tile moves 64 KB per 20.]
+#define ATT_DB_THREADS 512
+__global__ __launch_bounds__(ATT_DB_THREADS, 2) void attn_bwd_dbias_kernel(const attn_bwd_params_t bp, int n_groups) {
   const attn_params_t& p = bp.f;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsK = smem;                        // [128 keys][64 d] row image
-  unsigned char* ldsV = smem + 2 * ATT_TILE_BYTES;   // [128 keys][64 d] row image
-  unsigned char* ldsQ = smem + 4 * ATT_TILE_BYTES;   // [32 q][64 d] row image
-  unsigned char* ldsO = ldsQ + 4096;                 // [32 q][64 d] dO row image
-  float* qstat = reinterpret_cast<float*>(ldsO + 4096);  // lse2[32], delta[32]
-  float* tab = qstat + 64;
-  float* hist = reinterpret_cast<float*>(smem);  // aliases the K/V tiles: only used after the sample loop
+  // two stages of {K, V of the 128 keys, Q, dO of the 128 queries (row images, 16 KB each), -lse | -delta}: sample b + 1
+  // is written while sample b is read (one barrier per sample; the workgroup owns the CU's LDS anyway: 8 waves, 242 VGPRs)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (8 * ATT_TILE_BYTES + 1024)];
+  constexpr int STAGE = 8 * ATT_TILE_BYTES + 1024;
+  float* hist = reinterpret_cast<float*>(smem);        // aliases the tiles: only used after the sample loop
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kw = wave & 3, qh = wave >> 2;
   const int r = lane & 31, hh = lane >> 5;
-  const int h = blockIdx.y;
-  const attn_seq_t sq = p.seq;
+  const att_pos_t ps = att_pos(p.seq);
   const int D = p.H * 64;
-  const int nt0 = (sq.n0 + ATT_BQ - 1) / ATT_BQ;
-  int kt = blockIdx.x;
-  const int seg = kt >= nt0 ? 1 : 0;
-  if (seg) kt -= nt0;
-  const int nk = seg ? sq.n1 : sq.n0;
-  att_ranges_t qr = att_key_ranges(sq, p.mode, seg, 0, nullptr, nullptr);
-  const int ntq0 = (qr.n[0] + 31) >> 5, ntq1 = (qr.n[1] + 31) >> 5;  // 32-row query tiles of the interacting ranges
-  if ((int)blockIdx.z >= ntq0 + ntq1) return;  // block-uniform, before any barrier
-  const int rng = (int)blockIdx.z >= ntq0 ? 1 : 0;
-  const int q0 = (rng ? (int)blockIdx.z - ntq0 : (int)blockIdx.z) << 5;
-  const int qpos0 = qr.pos[rng] + q0;
-  const int qn = qr.n[rng];
-  const int qbase = qr.rowbase[rng];  // b = 0
-  const int k0 = kt * ATT_BQ;
-  const int key = k0 + wave * 32 + r;
-  const bool kvalid = key < nk;
-  const int kc = kvalid ? key : nk - 1;
-  const int kpos = (seg ? sq.pos1 : 0) + kc;
-  const uint8_t* keep = seg ? p.keep1 : p.keep0;
-  const int kbase = seg ? sq.base1 : sq.base0;
-
-  {
-    const float* col = p.bias_t + (size_t)(p.head_row0 + h) * p.R;
-    for (int i = tid; i < p.R; i += ATT_THREADS) tab[i] = col[i] * ATT_LOG2E;
+  // ---- work item: (key tile, query tile of its span, head, sample group) ------------------------------------------------
+  const int nkt = att_num_tiles(ps.n0, ps.n1, ps.pos1, p.mode);
+  int item = blockIdx.x;
+  const int grp = item % n_groups; item /= n_groups;
+  const int h = item % p.H; item /= p.H;
+  // item now enumerates (key tile, query tile) pairs: key tile kt has nq(kt) query tiles
+  int kt = 0;
+  att_span_t sp = att_span(ps, p.mode, 0);
+  for (;; ++kt) {
+    sp = att_span(ps, p.mode, kt);
+    const int nq = (sp.s_hi - sp.s_lo + ATT_BQ - 1) / ATT_BQ;
+    if (item < nq) break;
+    item -= nq;
+    if (kt + 1 >= nkt) return;
   }
-  const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int16_t*>(p.idx), 0, p.idx_rows * p.ld_idx * 2, 0x00020000);
-  const uint32_t ld2 = (uint32_t)p.ld_idx * 2, ivoff = (uint32_t)(kpos + 4 * hh * p.ld_idx) * 2;
-  // byte offsets (4 x relative-position index) of this lane's 16 (q, key) pairs: independent of the sample
-  uint32_t ids[8];
-#pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
-    uint32_t io[4];
-    att_idx4(ridx, ivoff, (uint32_t)(qpos0 + 8 * g4), ld2, io);
-    ids[2 * g4] = io[0] | (io[1] << 16);
-    ids[2 * g4 + 1] = io[2] | (io[3] << 16);
-  }
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int qp0 = sp.s_lo + item * ATT_BQ;       // first query position of the tile
+  const int b_lo = (int)((long)ps.B * grp / n_groups), b_hi = (int)((long)ps.B * (grp + 1) / n_groups);
+  if (b_lo >= b_hi) return;
 
-  u32x4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3, rq, ro;
-  float s_st = 0.f;
+  const int kp = sp.p0 + kw * 32 + r;            // this lane's key position
+  const bool kvalid = kp < sp.s_hi && (kp < ps.n0 || kp >= ps.pos1);
+  const uint8_t* keepk = kp < ps.n0 ? p.keep0 : p.keep1;
+  const int keep_at = kp < ps.n0 ? kp : kp - ps.pos1, keep_n = kp < ps.n0 ? ps.n0 : ps.n1;
+  const bool wave_keep = __any(kvalid && keepk != nullptr);
+
+  f16x8 sel0, sel1;
+  att_select_frags(lane, sel0, sel1);
+  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(p.dense_t + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048), 0, (uint32_t)p.dense_tiles * 4096u, 0x00020000);
+  att_bias_t bw;   // both 32-query blocks of this wave's 64 queries: the same for every sample
+  att_bias_load(bw, rbias, att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + kw, lane), (qp0 - sp.s_lo) / ATT_BK + qh);
+
+  // ---- staging: thread -> (row tid >> 3 [+64], chunk tid & 7) of each of the four 128-row tiles -------------------------
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv), 0, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(bp.d_o), 0, (uint32_t)((size_t)p.total_rows * bp.ld_do * 2), 0x00020000);
   const int srow = tid >> 3, schunk = tid & 7;
-  // (plain macros, not lambdas: by-reference captures of register arrays were placed in scratch memory)
-#define DB_LOAD_KV(U, RK, RV)                                                                              \
-  {                                                                                                        \
-    const int row_ = srow + 32 * (U);                                                                      \
-    if (k0 + row_ < nk) {                                                                                  \
-      const bf16_t* src_ = p.qkv + (size_t)(krow0_ + k0 + row_) * p.ld_qkv + D + h * 64 + schunk * 8;      \
-      RK = *reinterpret_cast<const u32x4*>(src_);                                                          \
-      RV = *reinterpret_cast<const u32x4*>(src_ + D);                                                      \
-    } else {                                                                                               \
-      RK = RV = (u32x4){0u, 0u, 0u, 0u};                                                                   \
-    }                                                                                                      \
-  }
-#define DB_STAGE_LOAD(B_)                                                                                  \
-  {                                                                                                        \
-    const int krow0_ = kbase + (B_) * nk;                                                                  \
-    DB_LOAD_KV(0, rk0, rv0) DB_LOAD_KV(1, rk1, rv1) DB_LOAD_KV(2, rk2, rv2) DB_LOAD_KV(3, rk3, rv3)        \
-    const int rowbase_ = qbase + (B_) * qn;                                                                \
-    const int qq_ = q0 + srow;                                                                             \
-    if (qq_ < qn) {                                                                                        \
-      rq = *reinterpret_cast<const u32x4*>(p.qkv + (size_t)(rowbase_ + qq_) * p.ld_qkv + h * 64 + schunk * 8); \
-      ro = *reinterpret_cast<const u32x4*>(bp.d_o + (size_t)(rowbase_ + qq_) * bp.ld_do + h * 64 + schunk * 8); \
-    } else {                                                                                               \
-      rq = ro = (u32x4){0u, 0u, 0u, 0u};                                                                   \
-    }                                                                                                      \
-    if (tid < 64) {                                                                                        \
-      const int q2_ = q0 + (tid & 31);                                                                     \
-      const bool ok_ = q2_ < qn;                                                                           \
-      const size_t rw_ = (size_t)rowbase_ + (ok_ ? q2_ : 0);                                               \
-      const float* sp_ = (tid < 32) ? bp.lse : bp.delta;                                                   \
-      s_st = ok_ ? sp_[(size_t)h * p.total_rows + rw_] : (tid < 32 ? INFINITY : 0.f);                      \
-    }                                                                                                      \
-  }
-#define DB_STORE_KV(U, RK, RV)                                                                             \
-  {                                                                                                        \
-    const int row_ = srow + 32 * (U);                                                                      \
-    const int byte_ = row_ * 128 + ((schunk ^ (row_ & 7)) << 4);                                           \
-    *reinterpret_cast<u32x4*>(ldsK + byte_) = RK;                                                          \
-    *reinterpret_cast<u32x4*>(ldsV + byte_) = RV;                                                          \
-  }
-#define DB_STAGE_STORE()                                                                                   \
-  {                                                                                                        \
-    DB_STORE_KV(0, rk0, rv0) DB_STORE_KV(1, rk1, rv1) DB_STORE_KV(2, rk2, rv2) DB_STORE_KV(3, rk3, rv3)    \
-    const int byte_ = srow * 128 + ((schunk ^ (srow & 7)) << 4);                                           \
-    *reinterpret_cast<u32x4*>(ldsQ + byte_) = rq;                                                          \
-    *reinterpret_cast<u32x4*>(ldsO + byte_) = ro;                                                          \
-    if (tid < 64) qstat[tid] = s_st;                                                                       \
-  }
-  DB_STAGE_LOAD(0)
-  const float c1 = p.scale * ATT_LOG2E;
-  for (int b = 0; b < sq.B; ++b) {
-    __syncthreads();  // every wave is done with the previous sample's tiles
-    DB_STAGE_STORE()
-    __syncthreads();
-    if (b + 1 < sq.B) DB_STAGE_LOAD(b + 1)  // flies during this sample's MFMAs
-    const bool kkeep = kvalid && (!keep || keep[(size_t)b * nk + kc] != 0);
-    const float kmaskv = kkeep ? 0.f : -INFINITY;
-    f32x16 s, dp;
+  u32x4 gK[2], gV[2], gQ[2], gO[2];
+  float gstat = 0.f;
+  auto row_off = [&](int b, int pos, int lim, uint32_t ld) -> uint32_t {  // byte offset of the row of position pos, or out of bounds
+    const bool txt = pos < ps.n0, img = pos >= ps.pos1 && pos < ps.NP;
+    const bool ok = (txt || img) && pos < lim;
+    const int row = txt ? ps.base0 + b * ps.n0 + pos : ps.base1 + b * ps.n1 + (pos - ps.pos1);
+    return ok ? (uint32_t)row * ld * 2 : 0xFFFFF000u;
+  };
+  auto g_load = [&](int b) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t ko = row_off(b, sp.p0 + srow + 64 * u, sp.s_hi, p.ld_qkv);
+      gK[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, ko + (D + h * 64 + schunk * 8) * 2, 0, 0));
+      gV[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, ko + (2 * D + h * 64 + schunk * 8) * 2, 0, 0));
+      const uint32_t qo = row_off(b, qp0 + srow + 64 * u, sp.s_hi, p.ld_qkv);
+      gQ[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, qo + (h * 64 + schunk * 8) * 2, 0, 0));
+      const uint32_t oo = row_off(b, qp0 + srow + 64 * u, sp.s_hi, bp.ld_do);
+      gO[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, oo + (h * 64 + schunk * 8) * 2, 0, 0));
+    }
+    if (tid < 256) {  // threads 0..127: -lse, 128..255: -delta of the tile's 128 query positions
+      const int qq = qp0 + (tid & 127);
+      const int row = qq < sp.s_hi ? att_row_of(ps, b, qq) : -1;
+      const float* src = tid < 128 ? bp.lse : bp.delta;
+      gstat = row >= 0 ? -src[(size_t)h * p.total_rows + row] : (tid < 128 ? -INFINITY : 0.f);
+    }
+  };
+  auto l_store = [&](int stage) {
+    unsigned char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = srow + 64 * u;
+      const uint32_t at = row * 128 + ((schunk ^ (row & 7)) << 4);
+      *reinterpret_cast<u32x4*>(base + at) = gK[u];
+      *reinterpret_cast<u32x4*>(base + 2 * ATT_TILE_BYTES + at) = gV[u];
+      *reinterpret_cast<u32x4*>(base + 4 * ATT_TILE_BYTES + at) = gQ[u];
+      *reinterpret_cast<u32x4*>(base + 6 * ATT_TILE_BYTES + at) = gO[u];
+    }
+    if (tid < 256) reinterpret_cast<float*>(base + 8 * ATT_TILE_BYTES)[tid] = gstat;
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+  const float c1 = p.scale * ATT_LOG2E;
+  g_load(b_lo);
+  l_store(0);
+  if (b_lo + 1 < b_hi) g_load(b_lo + 1);
+  __syncthreads();
+  for (int b = b_lo; b < b_hi; ++b) {
+    const int cur = (b - b_lo) & 1;
+    if (b + 1 < b_hi) {
+      l_store(cur ^ 1);                   // loaded during the previous sample; that stage was last read two samples ago
+      if (b + 2 < b_hi) g_load(b + 2);    // flies during this sample's MFMAs
+    }
+    const unsigned char* ldsK = smem + cur * STAGE;
+    const unsigned char* ldsV = ldsK + 2 * ATT_TILE_BYTES;
+    const unsigned char* ldsQ = ldsK + 4 * ATT_TILE_BYTES;
+    const unsigned char* ldsO = ldsK + 6 * ATT_TILE_BYTES;
+    const float* qstat = reinterpret_cast<const float*>(ldsK + 8 * ATT_TILE_BYTES);
+    float kmaskv = kvalid ? 0.f : -INFINITY;
+    if (wave_keep && kvalid && keepk && keepk[(size_t)b * keep_n + keep_at] == 0) kmaskv = -INFINITY;
+    const bool wave_masked = __any(kmaskv != 0.f);
+    bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
-      const bf16x8 a = att_k_rowfrag(ldsQ, r, 2 * ss + hh);
-      const bf16x8 kf = att_k_rowfrag(ldsK, wave * 32 + r, 2 * ss + hh);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf, s, 0, 0, 0);
-      const bf16x8 oa = att_k_rowfrag(ldsO, r, 2 * ss + hh);
-      const bf16x8 vf = att_k_rowfrag(ldsV, wave * 32 + r, 2 * ss + hh);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf, dp, 0, 0, 0);
+      const bf16x8 raw = att_k_rowfrag(ldsK, kw * 32 + r, 2 * ss + hh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[ss][j] = (bf16_t)((float)raw[j] * c1);
+      vf[ss] = att_k_rowfrag(ldsV, kw * 32 + r, 2 * ss + hh);
     }
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int ql = 8 * g4 + 4 * hh;
-      const uint32_t w0 = ids[2 * g4], w1 = ids[2 * g4 + 1];
-      const float bv[4] = {att_tab(tab, w0 & 0xffff), att_tab(tab, w0 >> 16), att_tab(tab, w1 & 0xffff), att_tab(tab, w1 >> 16)};
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(qstat + ql);
-      const f32x4 dl = *reinterpret_cast<const f32x4*>(qstat + 32 + ql);
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q0 = qh * 64 + qb * 32;  // first query row of the block inside the 128-row tile
+      f32x16 e, dp;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = fmaf(s[4 * g4 + e], c1, bv[e]) + kmaskv;
-        const float pr = att_exp2(v - ls[e]);
-        acc[4 * g4 + e] += pr * (dp[4 * g4 + e] - dl[e]);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(qstat + q0 + 8 * g4 + 4 * hh);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(qstat + 128 + q0 + 8 * g4 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
       }
+      if (wave_masked) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] += kmaskv;
+      }
+      e = att_bias_mfma(sel0, sel1, bw.w[qb], e);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const bf16x8 qa = att_k_rowfrag(ldsQ, q0 + r, 2 * ss + hh), oa = att_k_rowfrag(ldsO, q0 + r, 2 * ss + hh);
+        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ss], e, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[qb][i] += att_exp2(e[i]) * dp[i];
     }
+    __syncthreads();  // stage cur is free for sample b + 2, stage cur ^ 1 is published
   }
-  // ---- histogram of the batch-summed dS (in the LDS that held the K/V tiles) ---------------------------------------
+
+  // ---- histogram of the batch-summed dS (in the LDS that held the tiles) ---------------------------------------------------
   __syncthreads();
-  for (int i = tid; i < p.R; i += ATT_THREADS) hist[i] = 0.f;
+  for (int i = tid; i < p.R; i += ATT_DB_THREADS) hist[i] = 0.f;
   __syncthreads();
   {
-    bool same = true;
+    // byte offsets (4 x relative-position index) of this lane's 32 (query, key) pairs: element (qb, j) <-> query row
+    // q0 + (j & 3) + 8 * (j >> 2) + 4 * hh, this lane's key; read through the transposed index (row = key position)
+    const bool kin = kp < p.idx_t_rows;
+    const int16_t* irow = p.idx_t + (size_t)(kin ? kp : 0) * p.ld_idx_t;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) same = same && (ids[i] == ids[0]) && ((ids[i] >> 16) == (ids[i] & 0xffff));
-    const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
-    same = same && (ids[0] == first);
-    if (__all(same)) {
-      float tsum = 0.f;
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qpos0 = qp0 + qh * 64 + qb * 32;
+      uint32_t ids[16];
+      bool same = true;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) tsum += acc[i];
-      tsum = wave_sum(tsum);
-      if (lane == 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + (first & 0xffff)), tsum);
-    } else {
+      for (int j = 0; j < 16; ++j) {
+        const int qq = qpos0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        ids[j] = (kin && qq < p.ld_idx_t) ? (uint32_t)(unsigned short)irow[qq] : 0u;
+        same = same && ids[j] == ids[0];
+      }
+      const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
+      same = same && ids[0] == first;
+      if (__all(same)) {  // text -> image pairs share ONE table row (vilt_module.py:180-181): reduce in registers
+        float tsum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint32_t w = ids[i >> 1];
-        atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + ((i & 1) ? (w >> 16) : (w & 0xffff))), acc[i]);
+        for (int j = 0; j < 16; ++j) tsum += acc[qb][j];
+        tsum = wave_sum(tsum);
+        if (lane == 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + first), tsum);
+      } else {
+#ifndef ATT_DIAG_NOHIST
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + ids[j]), acc[qb][j]);
+#else
+        hist[tid] = acc[qb][0] + (float)ids[3];
+#endif
       }
     }
   }
   __syncthreads();
-  float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
-  for (int i = tid; i < p.R; i += ATT_THREADS) {
-    const float v = hist[i];
-    if (v != 0.f) atomicAdd(g + i, v);
+  if (bp.dbias_part) {
+    // two-stage reduction: ~80 workgroups per head adding into the same 2 294 addresses serialise at the memory-side
+    // atomic units (measured: 25 us of fixed cost per workgroup); plain stores + one small summing launch instead
+    float* g = bp.dbias_part + (size_t)blockIdx.x * p.R;
+    for (int i = tid; i < p.R; i += ATT_DB_THREADS) g[i] = hist[i];
+  } else {
+    float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
+    for (int i = tid; i < p.R; i += ATT_DB_THREADS) {
+      const float v = hist[i];
+      if (v != 0.f) atomicAdd(g + i, v);
+    }
   }
 }
 
+// dbias_t[head_row0 + h][i] += sum over the work items of head h (item = (pair * H + h) * groups + grp) of part[item][i]
+__global__ __launch_bounds__(256) void attn_dbias_fold_kernel(const float* __restrict__ part, int R, int H, int groups, int pairs,
+                                                              float* __restrict__ dbias_t, int head_row0) {
+  const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  if (i >= R) return;
+  float sum = 0.f;
+  for (int pr = 0; pr < pairs; ++pr)
+    for (int g = 0; g < groups; ++g) sum += part[((size_t)(pr * H + h) * groups + g) * R + i];
+  dbias_t[(size_t)(head_row0 + h) * R + i] += sum;
+}
+
+// work items of the bias-gradient kernel for this geometry: (key tile, query tile) pairs and sample groups
+static void att_dbias_items(const attn_params_t& p, int& pairs, int& groups) {
+  const int NP = p.seq.pos1 + p.seq.n1;
+  if (p.mode == VLM_ATTN_SEPARATE) {
+    const int a = (p.seq.n0 + ATT_BQ - 1) / ATT_BQ, c = (p.seq.n1 + ATT_BQ - 1) / ATT_BQ;
+    pairs = a * a + c * c;
+  } else {
+    const int a = (NP + ATT_BQ - 1) / ATT_BQ;
+    pairs = a * a;
+  }
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  groups = pairs > 0 ? (3 * cus + pairs * p.H - 1) / (pairs * p.H) : 1;  // ~3 items per CU
+  if (groups > p.seq.B) groups = p.seq.B;
+  if (groups > 8) groups = 8;
+  if (groups < 1) groups = 1;
+}
+
+extern "C" size_t vlm_attention_bwd_ws_floats(const vlm_attn_desc_t* d, int with_dbias) {
+  attn_params_t p;
+  if (att_fill_params(d, p) != VLM_OK) return 0;
+  size_t n = (size_t)p.H * p.total_rows;  // delta
+  if (with_dbias && p.bias_t) {
+    int pairs, groups;
+    att_dbias_items(p, pairs, groups);
+    n += (size_t)pairs * p.H * groups * p.R;
+  }
+  return n;
+}
+
 extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int ld_out, const void* d_out,
-                                 int ld_dout, const float* lse, float* delta_ws, void* dqkv, int ld_dqkv,
+                                 int ld_dout, const float* lse, float* delta_ws, size_t ws_floats, void* dqkv, int ld_dqkv,
                                  float* dbias_t, const vlm_attn_colsum_t* colsum, void* stream) {
   attn_bwd_params_t bp;
   int rc = att_fill_params(d, bp.f);
   if (rc != VLM_OK) return rc;
   if (!out || !d_out || !lse || !delta_ws || !dqkv) return VLM_ERR_ARG;
+  bp.dbias_part = nullptr;
   if ((ld_out & 7) || (ld_dout & 7) || (ld_dqkv & 3) || ((uintptr_t)out & 15) || ((uintptr_t)d_out & 15))
     return VLM_ERR_ARG;
   if (bp.f.bias_t && (!bp.f.idx || (bp.f.ld_idx & 3))) return VLM_ERR_ARG;
@@ -666,13 +757,19 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, s, bp);
     if (dbias_t) {
       VLM_CHECK_LAUNCH();
-      const size_t Rp = (size_t)((p.R + 3) & ~3);
-      const size_t smem_db = 4 * ATT_TILE_BYTES + 2 * 4096 + 256 + Rp * 4;  // histogram aliases the K/V tiles (R*4 <= 32 KiB)
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dbias_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_db) != hipSuccess)
-        return VLM_ERR_LAUNCH;
-      const int ntq = (p.seq.n0 + 31) / 32 + (p.seq.n1 + 31) / 32;  // upper bound of 32-row query tiles per key tile
-      hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(nt0 + nt1, p.H, ntq), block, smem_db, s, bp);
+      if ((size_t)p.R * 4 > 16 * ATT_TILE_BYTES || !p.idx_t) return VLM_ERR_UNSUPPORTED;  // the histogram lives in the tile LDS
+      // work items: every (128-key tile, 128-query tile of its span) pair x heads x sample groups; the samples are cut
+      // into groups until the grid has ~3 items per CU (the per-item histogram is the price of every extra group)
+      int pairs, groups;
+      att_dbias_items(p, pairs, groups);
+      const size_t items = (size_t)pairs * p.H * groups, need = (size_t)p.H * p.total_rows + items * p.R;
+      bp.dbias_part = ws_floats >= need ? delta_ws + (size_t)p.H * p.total_rows : nullptr;
+      hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3((unsigned)items), dim3(ATT_DB_THREADS), 0, s, bp, groups);
+      if (bp.dbias_part) {
+        VLM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_dbias_fold_kernel, dim3((p.R + 255) / 256, p.H), dim3(256), 0, s, bp.dbias_part, p.R, p.H, groups,
+                           pairs, dbias_t, p.head_row0);
+      }
     }
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, block, 0, s, bp);

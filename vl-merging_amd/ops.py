@@ -436,6 +436,9 @@ def attention_fwd(qkv, out, lse, seq, H, *, bias_t=None, head_row0=0, rel_index=
     return out
 
 
+_ATTN_WS = {}
+
+
 def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0, rel_index=None, rel_index_t=None,
                   keep0=None, keep1=None, mode=L.ATTN_JOINT, scale=0.125, dbias_t=None, delta_ws=None,
                   dq_colsum=None, dv_colsum=None, bias_dense=None):
@@ -454,12 +457,16 @@ def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0
                     if t.dtype != F32 or t.numel() < H * 64 or not t.is_contiguous():
                         raise L.VlmError("attention_bwd: column-sum outputs must be contiguous f32 [H*64]")
                     getattr(cs, name)[sgm] = t.data_ptr()
-    if delta_ws is None:
-        delta_ws = torch.empty(H, qkv.shape[0], device=qkv.device, dtype=F32)
+    need = L.get_lib().vlm_attention_bwd_ws_floats(ctypes.byref(d), 0)  # (1: two-stage bias-gradient fold; measured no faster)
+    if delta_ws is None or delta_ws.numel() < need:
+        key = (qkv.device.index, torch.cuda.current_stream().cuda_stream)
+        delta_ws = _ATTN_WS.get(key)
+        if delta_ws is None or delta_ws.numel() < need:  # one scratch per stream, grown on demand
+            delta_ws = _ATTN_WS[key] = torch.empty(need, device=qkv.device, dtype=F32)
     if bias_t is not None and rel_index is None:
         raise L.VlmError("attention_bwd needs both orientations of the int16 relative index")
     rc = L.get_lib().vlm_attention_bwd(ctypes.byref(d), L.ptr(out), _ld(out), L.ptr(dout), _ld(dout), L.ptr(lse),
-                                       L.ptr(delta_ws), L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t),
+                                       L.ptr(delta_ws), delta_ws.numel(), L.ptr(dqkv), _ld(dqkv), L.ptr(dbias_t),
                                        ctypes.byref(cs) if cs is not None else None, L.stream_ptr())
     L.check(rc, "vlm_attention_bwd")
     return dqkv
