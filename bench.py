@@ -97,12 +97,14 @@ def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same bench command
     (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units,
     FETCH_SIZE doubled on gfx950).  Counters cannot be read from inside the timed process; None if the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # the newest committed PMC passes
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def calibrate(dev):
@@ -375,7 +377,7 @@ def main():
         if gs:
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("vlm_gemm_kernel"),
-                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
                                "kernel": "vlm_gemm_kernel",
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "timed_steps": len(range(0, args.steps, max(1, args.gemm_timer_every))),
