@@ -391,3 +391,90 @@ def test_gemm_col_sum_through_fold_workspace(ops, L):
     assert_close(direct, want, 2e-3, 2e-2, "direct col_sum")
     assert_close(viafold, want, 2e-3, 2e-2, "col_sum through the fold workspace")
     assert float((part - 1.5).abs().max()) < float((want - 1.5).abs().max())  # before the fold: only the ragged tile's 50 rows
+
+
+@pytest.fixture
+def big_tile(L):
+    """Force the 256x256 kernel wherever it is legal for the duration of a test, then hand the choice back."""
+    lib = L.get_lib()
+    L.check(lib.vlm_gemm_set_big_tile_mode(2), "vlm_gemm_set_big_tile_mode")
+    yield lib
+    L.check(lib.vlm_gemm_set_big_tile_mode(-1), "vlm_gemm_set_big_tile_mode")
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 5 + 77, 768, 768), (13574, 2304, 768), (256 * 3 + 130, 256, 128), (1000, 3072, 3072)])
+def test_gemm_big_tile_every_epilogue_variant(ops, L, big_tile, M, N, K):
+    """The 256x256 kernel's looped epilogue (LDS transpose, buffer loads/stores, rows >= M falling off the descriptors)
+    in every variant the launcher offers, against fp32 matmul of the bf16 operands AND against the 128x128 kernel."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    B = bf(torch.randn(N, K, device="cuda", generator=gen))
+    alpha = 1.0 / math.sqrt(K)
+    ref = (A.float() @ B.float().t()) * alpha
+    bias = torch.randn(N, device="cuda", generator=gen)
+    gamma = torch.randn(N, device="cuda", generator=gen) * 0.5
+    rs = (torch.rand(M, device="cuda", generator=gen) > 0.3).float() / 0.7
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    hpre = bf(torch.randn(M, N, device="cuda", generator=gen))
+
+    def run(mode):
+        L.check(big_tile.vlm_gemm_set_big_tile_mode(mode), "mode")
+        r = {}
+        o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)       # guard rows behind the output
+        ops.gemm(A, B, o[:M], bias=bias, alpha=alpha)
+        r["bf16+bias"] = o
+        o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        h = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, B, o[:M], bias=bias, act=L.ACT_GELU, aux=h[:M], alpha=alpha)
+        r["gelu"], r["preact"] = o, h
+        o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        cs = torch.full((N,), 0.25, device="cuda")
+        ops.gemm(A, B, o[:M], act=L.ACT_GELU_BWD, aux=hpre, alpha=alpha, col_sum=cs)
+        r["gelu_bwd"], r["col_sum"] = o, cs
+        x = torch.full((M + 3, N), 7.0, device="cuda")
+        x[:M] = res
+        y = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(A, B, x[:M], bias=bias, col_scale=gamma, row_scale=rs, residual=x[:M], aux=y[:M], alpha=alpha)  # in place
+        r["residual stream"], r["branch"] = x, y
+        x = torch.full((M + 3, N), 7.0, device="cuda")
+        ops.gemm(A, B, x[:M], bias=bias, residual=res, alpha=alpha)
+        r["f32 residual"] = x
+        x = torch.full((M + 3, N), 7.0, device="cuda")
+        ops.gemm(A, B, x[:M], alpha=alpha)
+        r["f32 plain"] = x
+        return r
+
+    big, small = run(2), run(0)
+    hh = hpre.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward(ref)
+    want = {"bf16+bias": ref + bias, "gelu": torch.nn.functional.gelu(ref + bias), "preact": ref + bias, "gelu_bwd": hh.grad,
+            "residual stream": res + rs[:, None] * gamma[None] * (ref + bias), "branch": ref + bias,
+            "f32 residual": res + ref + bias, "f32 plain": ref}
+    for k, w in want.items():
+        tol = (1e-2, 2e-2) if big[k].dtype == torch.bfloat16 else (1e-3, 5e-3)
+        assert_close(big[k][:M], w, tol[0], tol[1], "256-tile " + k)
+        assert float((big[k][M:].float() - 7.0).abs().max()) == 0.0, "rows behind M were written: " + k
+        # same operation order in both epilogues: the two kernels differ only by the K-order of the fp32 accumulation
+        assert_close(big[k][:M], small[k][:M].float(), tol[0], tol[1], "256-tile vs 128-tile " + k)
+    assert_close(big["col_sum"], hh.grad.sum(0) + 0.25, 2e-3, 3e-2, "256-tile col_sum")
+    assert_close(big["col_sum"], small["col_sum"], 1e-3, 1e-2, "col_sum 256 vs 128")
+
+
+def test_gemm_big_tile_col_sum_workspace(ops, L, big_tile):
+    """Column sums of the 256x256 kernel through the fold workspace: a wave covers a 128-row half alone and stores slot
+    2 tm + wm; the ragged last half adds directly."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+    M, N, K = 256 * 4 + 128 + 50, 512, 256
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    B = bf(torch.randn(N, K, device="cuda", generator=gen))
+    h = bf(torch.randn(M, N, device="cuda", generator=gen))
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    fold = ops.FoldBatch(A.device, N)
+    got = torch.full((N,), 1.5, device="cuda")
+    ops.gemm(A, B, out, act=L.ACT_GELU_BWD, aux=h, alpha=0.1, col_sum=got, col_sum_fold=fold)
+    assert len(fold.jobs) == 1 and fold.jobs[0][1] == M // 128
+    fold.flush()
+    hh = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward((A.float() @ B.float().t()) * 0.1)
+    assert_close(got, hh.grad.sum(0) + 1.5, 2e-3, 2e-2, "256-tile col_sum through the fold workspace")
+    assert_close(out, hh.grad, 1e-2, 2e-2, "256-tile gelu_bwd")

@@ -90,6 +90,7 @@ SIGNATURES = {
     "vlm_layerscale_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
     "vlm_colreduce_batch": (c_int, [ctypes.POINTER(FoldJob), c_int, c_void_p]),
+    "vlm_gemm_set_big_tile_mode": (c_int, [c_int]),
     "vlm_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_float, c_float, c_float,
                                c_float, c_float, c_float, c_float, c_int, c_void_p]),

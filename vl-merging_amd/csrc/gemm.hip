@@ -290,7 +290,13 @@ __device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4
             bf16x8 o;
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+#if defined(EPI_DIAG) && EPI_DIAG == 1  // diagnostic timing build: no stores
+            asm volatile("" ::"v"(o));
+#elif defined(EPI_DIAG) && EPI_DIAG == 2  // diagnostic timing build (wrong results): row-contiguous 128-B segments
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)(mw0 + (hf * 2 + jp) * 8 + (lane >> 3)) * p.ldc + nw0 + (lane & 7) * 8) = o;
+#else
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
+#endif
           }
         }
       }
@@ -634,6 +640,521 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
   return VLM_OK;
 }
 
+// ======================================================================================================================
+// 256x256 macro tile, ONE workgroup per CU: 4 waves (2x2) of 128x128, both operands K-contiguous (forward, and dgrad
+// against the transposed weight shadow).  Why a second kernel: at the MFMA bound a 128x128 workgroup tile with 64x64
+// waves asks for 64 B/clk/CU of global->LDS traffic (the vector-memory path's peak) AND 256 B/clk/CU of LDS reads + DMA
+// writes (the LDS array's peak) -- every pipe is at 100 % together, which in practice is the ~1500 cycles per 1024 MFMA
+// cycles that tools/stamp_gemm.py shows.  Waves of 128x128 halve the fragment bytes per MFMA and the 256x256 tile halves
+// the staged bytes per MFMA, so the matrix pipe is the only pipe near its limit.  With one wave per SIMD nothing but the
+// wave's own instruction stream hides latency, so the K loop is software-pipelined by hand:
+//   * K steps of 32, FOUR 32-KiB LDS stages (separate __shared__ objects: the compiler proves a stage's DMA and another
+//     stage's ds_reads disjoint and the waits can be counted): during step k the wave issues the DMA of stage k+3,
+//     reads the fragments of stage k+1 into the second fragment buffer and runs the 64 MFMAs of stage k out of the
+//     first; sched_group_barrier spreads the 16 ds_read_b128 and 8 DMA instructions between the MFMAs;
+//   * one barrier per step (top of the step): stage k+1 has landed for every wave (vmcnt(8): only stage k+2 may still be
+//     in flight) and nobody reads the buffer that stage k+3 is about to overwrite.
+// LDS image of an operand stage: [256 rows][32 k] bf16, 64-B rows, 16-B slot s of row r holds chunk s ^ f((r>>2)&3),
+// f = (0,2,3,1): conflict-free for ds_read_b128's lane groups (rows {0-3,12-15} x chunk c with rows {4-11} x chunk c^1).
+// diagnostic timing builds only (tools/scratch/gemm_bench.hip; results are wrong): knock out one part of the K loop
+#ifndef BIG_DIAG_DMA
+#define BIG_DIAG_DMA 1
+#endif
+#ifndef BIG_DIAG_READ
+#define BIG_DIAG_READ 1
+#endif
+#ifndef BIG_DIAG_BARRIER
+#define BIG_DIAG_BARRIER 1
+#endif
+#ifndef BIG_STAGE_REGS
+#define BIG_STAGE_REGS 1  // 1: global -> registers -> ds_write_b128 (two LDS buffers); 0: LDS-DMA (four LDS buffers)
+#endif
+#define BIG_BM 256
+#define BIG_BN 256
+#define BIG_BK 32
+#define BIG_OP_BYTES (256 * BIG_BK * 2)  // 16 KiB per operand per stage
+
+__device__ __forceinline__ uint32_t big_swz(uint32_t q) { return (0x78u >> (2 * q)) & 3u; }  // f = (0,2,3,1)
+
+// this wave's 4 DMA instructions of one operand stage: instruction j = wave + 4u covers rows 16j .. 16j+15
+__device__ __forceinline__ void big_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* stage, const uint32_t (&off)[4],
+                                        uint32_t soff, int wave) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(stage + (wave + 4 * u) * 1024), 16, off[u], soff, 0, 0);
+}
+
+__device__ __forceinline__ void big_wait_vm(int later_stages) {  // all but the newest `later_stages` stages have landed
+  if (later_stages >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (later_stages == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- looped epilogue of a 128x128 wave tile through a wave-private LDS transpose ------------------------------------
+// The straight-line epilogue above is executed once per wave and is instruction-FETCH bound (tools/scratch/gemm_bench.hip:
+// with every store removed a 128x128 wave tile still took 50k cycles in it).  Here a 16-row block of accumulators is
+// dropped into LDS as it stands (ds_write_b128, 528-B row pitch: conflict-free) and read back row-major: lane -> row
+// 4t + (lane>>4), 8 consecutive columns (lane&15)*8 -- so one short loop body serves all 8 row blocks out of the
+// instruction cache, every global access of a wave instruction is 4 rows x 512 contiguous bytes (f32) / 256 (bf16), and the
+// per-element inputs (residual, GELU' argument, row scale) of the next block are in flight while this one is processed.
+#ifndef EPIL_DIAG
+#define EPIL_DIAG 0  // diagnostic timing builds (wrong results): 1 no C stores, 2 no input loads, 4 no aux stores, 8 no finish wait
+#endif
+#define EPIL_PITCH (128 * 4 + 16)
+#define EPIL_WAVE_BYTES (32 * EPIL_PITCH)
+struct epil_in_t {
+  f32x4 rsd[4][2];
+  bf16x8 hx[4];
+  float rs[4];
+};
+
+// Everything of the looped epilogue that never touches an accumulator.  The accumulators stay in the kernel body, where
+// each is named statically (handing the arrays through a function or a closure left one of them in scratch).
+// Every per-element access is a raw buffer operation: an input the call does not have gets a zero-length descriptor
+// (loads return 0, stores are dropped, nothing reaches memory) and rows >= M fall off the end of the real ones -- so the
+// loop body has NO branch around a memory operation and a fixed number of them, which is what lets the compiler wait for
+// the next block's inputs with a counted vmcnt instead of vmcnt(0) (= draining this block's stores every time).
+// RES: residual (+ optional row scale) inputs; AUX: 0 none, 1 the pre-activation copy is stored, 2 GELU' argument is loaded.
+// What a variant does not have costs nothing (a zero-length descriptor would still cost the round trip: the dummy loads
+// of an all-in-one version took 14k of its 25k cycles).
+template <bool OUT_F32, bool RES, int AUX>
+struct big_epilogue_t {
+  const gemm_params_t& p;
+  const unsigned char* rd;  // this lane's read address in the wave's LDS transpose: row lane>>4, 8 columns (lane&15)*8
+  __amdgpu_buffer_rsrc_t r_c, r_res, r_aux, r_rs;
+  uint32_t mw0, lr, n;
+  bool bwd;
+  float bia[8], gam[8], csum[8];
+
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, const void* fallback, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base ? base : fallback), 0, base ? (int)bytes : 0, 0x00020000);
+  }
+
+  __device__ __forceinline__ big_epilogue_t(const gemm_params_t& p_, const unsigned char* wl, uint32_t mw0_, uint32_t nw0, int lane)
+      : p(p_), mw0(mw0_) {
+    const vlm_epilogue_t& e = p.epi;
+    bwd = AUX == 2;
+    lr = lane >> 4;
+    n = nw0 + (lane & 15) * 8;
+    rd = wl + lr * EPIL_PITCH + (lane & 15) * 32;
+    const uint64_t c_bytes = (uint64_t)p.M * p.ldc * (OUT_F32 ? 4 : 2);
+    r_c = rsrc(p.C, p.C, c_bytes);
+    r_res = rsrc(e.residual, p.C, (uint64_t)p.M * e.ld_res * 4);
+    r_aux = rsrc(e.aux, p.C, (uint64_t)p.M * e.ld_aux * 2);
+    r_rs = rsrc(e.row_scale, p.C, (uint64_t)p.M * 4);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 b4 = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 g4 = e.col_scale ? *reinterpret_cast<const f32x4*>(e.col_scale + n + q * 4) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bia[q * 4 + r] = b4[r];
+        gam[q * 4 + r] = g4[r];
+        csum[q * 4 + r] = 0.f;
+      }
+    }
+  }
+
+  // per-element inputs of the 16-row block i (4 rows per lane): a fixed number of loads per variant, no branch
+  __device__ __forceinline__ void load_inputs(epil_in_t& in, int i) const {
+    const vlm_epilogue_t& e = p.epi;
+    if (EPIL_DIAG & 2) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t m = mw0 + 16 * i + 4 * t + lr;
+      if (RES) {
+        in.rs[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rs, m * 4, 0, 0));
+        const uint32_t ro = (m * (uint32_t)e.ld_res + n) * 4;
+        in.rsd[t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, ro, 0, 0));
+        in.rsd[t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, ro + 16, 0, 0));
+      }
+      if (AUX == 2) in.hx[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, 0));
+    }
+  }
+
+  // the 16-row block i, read back from LDS at lds_off: same operation order as gemm_epilogue
+  __device__ __forceinline__ void process(const epil_in_t& in, int i, int lds_off) {
+    const vlm_epilogue_t& e = p.epi;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t m = mw0 + 16 * i + 4 * t + lr;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(rd + lds_off + t * 4 * EPIL_PITCH);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(rd + lds_off + t * 4 * EPIL_PITCH + 16);
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = lo[r] * e.alpha + bia[r];
+        v[4 + r] = hi[r] * e.alpha + bia[4 + r];
+      }
+      if (bwd) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)in.hx[t][r]);
+      } else {
+        if (AUX == 1) {
+          bf16x8 h;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) h[r] = (bf16_t)v[r];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, 0);
+        }
+        if (e.act == VLM_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+        }
+      }
+      if (e.col_scale) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gam[r];
+      }
+      if (RES) {
+        if (e.row_scale) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] *= in.rs[t];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += in.rsd[t][r >> 2][r & 3];
+      }
+      if (m < (uint32_t)p.M) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) csum[r] += v[r];
+      }
+      if (OUT_F32) {
+        const uint32_t co = (m * (uint32_t)p.ldc + n) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), r_c, co, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), r_c, co + 16, 0, 0);
+      } else {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+        if (EPIL_DIAG & 1) asm volatile("" ::"v"(o));
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_c, (m * (uint32_t)p.ldc + n) * 2, 0, 0);
+      }
+    }
+  }
+
+  // column sums of the wave tile: the 4 lane groups hold the same columns for rows = lane>>4 (mod 4)
+  __device__ __forceinline__ void finish(int lane, float* ws_row) {
+    const vlm_epilogue_t& e = p.epi;
+    if (!e.col_sum) return;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      csum[r] += __shfl_xor(csum[r], 16);
+      csum[r] += __shfl_xor(csum[r], 32);
+    }
+    if (lane < 16) {
+      if (ws_row) {
+        *reinterpret_cast<f32x4*>(ws_row + n) = (f32x4){csum[0], csum[1], csum[2], csum[3]};
+        *reinterpret_cast<f32x4*>(ws_row + n + 4) = (f32x4){csum[4], csum[5], csum[6], csum[7]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) atomicAdd(e.col_sum + n + r, csum[r]);
+      }
+    }
+  }
+};
+
+template <bool OUT_F32, bool RES, int AUX>
+__global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gemm_params_t p) {
+#if BIG_STAGE_REGS
+  __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES];
+#else
+  __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sA2[BIG_OP_BYTES], sA3[BIG_OP_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES], sB2[BIG_OP_BYTES], sB3[BIG_OP_BYTES];
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned char epl[4 * EPIL_WAVE_BYTES];  // wave-private epilogue transposes
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  STAMP(0)
+
+  const uint32_t nblk = gridDim.x, bid = blockIdx.x;
+  const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  uint32_t tm, tn;
+  {
+    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;
+    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;
+    tm = first + in % rows;
+    tn = in / rows;
+  }
+  const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG_BN;
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
+
+  // per-lane DMA source offsets (k0 = 0; the step adds 64 B per stage through the scalar offset): lane -> row
+  // 16j + (lane>>2), LDS slot (lane&3) <- global chunk (lane&3) ^ f(lane>>4)
+  uint32_t offa[4], offb[4];
+  {
+    const uint32_t chunk = (lane & 3) ^ big_swz(lane >> 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t row = (wave + 4 * u) * 16 + (lane >> 2);
+      offa[u] = ((m0 + row) * (uint32_t)p.lda + chunk * 8) * 2;
+      offb[u] = ((n0 + row) * (uint32_t)p.ldb + chunk * 8) * 2;
+    }
+  }
+  // fragment read addresses: 16-row block i of this wave's 128 rows: row = w*128 + 16 i + (lane&15), chunk lane>>4
+  const uint32_t rd_slot = ((uint32_t)(lane >> 4) ^ big_swz((lane & 15) >> 2)) * 16 + (lane & 15) * 64;
+  const uint32_t rda = wm * 128 * 64 + rd_slot, rdb = wn * 128 * 64 + rd_slot;
+
+  // four separate 64x64 quadrants (static objects: a 4-D array indexed through unrolled loops stayed in scratch)
+  f32x4 acc00[4][4], acc01[4][4], acc10[4][4], acc11[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc00[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc01[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc10[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc11[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  const int nk = p.K / BIG_BK;
+  const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+  unsigned char* const wl = epl + wave * EPIL_WAVE_BYTES;
+#define EPIL_SETUP()                                       \
+  big_epilogue_t<OUT_F32, RES, AUX> ep(p, wl, mw0, nw0, lane); \
+  epil_in_t inA, inB;                                      \
+  ep.load_inputs(inA, 0);
+  bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+
+#define BIG_READ(FA, FB, SA, SB)                                                         \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                        \
+    FA[i] = *reinterpret_cast<const bf16x8*>((SA) + rda + i * 1024);                     \
+    FB[i] = *reinterpret_cast<const bf16x8*>((SB) + rdb + i * 1024);                     \
+  }
+#define BIG_MFMA_Q(ACC, FA, FB, I0, J0)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                         \
+      ACC[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[(J0) + j], FA[(I0) + i], ACC[i][j], 0, 0, 0);
+#define BIG_MFMA(FA, FB)        \
+  BIG_MFMA_Q(acc00, FA, FB, 0, 0) \
+  BIG_MFMA_Q(acc01, FA, FB, 0, 4) \
+  BIG_MFMA_Q(acc11, FA, FB, 4, 4) \
+  BIG_MFMA_Q(acc10, FA, FB, 4, 0)
+#if !BIG_STAGE_REGS
+  // step K: consume fragments FC (stage K), read stage K+1 (RA/RB) into FN, DMA stage K+3 into WA/WB.  DMA / READ / VM
+  // are literals so that a step is ONE basic block (sched_group_barrier cannot move anything across a branch); VM = the
+  // vmcnt that leaves only stage K+2 in flight.
+#define BIG_STEP(K, DMA, READ, VM, FCA, FCB, FNA, FNB, RA, RB, WA, WB)                   \
+  {                                                                                      \
+    if (READ) {                                                                          \
+      asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                             \
+      if (BIG_DIAG_BARRIER) __builtin_amdgcn_s_barrier();                                \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (DMA && BIG_DIAG_DMA) {                                                           \
+      big_dma(ra, WA, offa, ((K) + 3) * (BIG_BK * 2), wave);                             \
+      big_dma(rb, WB, offb, ((K) + 3) * (BIG_BK * 2), wave);                             \
+    }                                                                                    \
+    if (READ && BIG_DIAG_READ) { BIG_READ(FNA, FNB, RA, RB) }                            \
+    BIG_MFMA(FCA, FCB)                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) { /* fragment reads first: they are consumed next step */ \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+    }                                                                                    \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  }
+
+  // prologue: stages 0..2 in flight, stage 0 landed, its fragments in registers (nk >= 4 and nk % 4 == 0: launcher)
+  big_dma(ra, sA0, offa, 0, wave);
+  big_dma(rb, sB0, offb, 0, wave);
+  big_dma(ra, sA1, offa, 1 * BIG_BK * 2, wave);
+  big_dma(rb, sB1, offb, 1 * BIG_BK * 2, wave);
+  big_dma(ra, sA2, offa, 2 * BIG_BK * 2, wave);
+  big_dma(rb, sB2, offb, 2 * BIG_BK * 2, wave);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  BIG_READ(fa0, fb0, sA0, sB0)
+  if (!BIG_DIAG_READ) { BIG_READ(fa1, fb1, sA0, sB0) }
+
+  int kt = 0;
+  for (; kt < nk - 4; kt += 4) {
+    BIG_STEP(kt + 0, 1, 1, 8, fa0, fb0, fa1, fb1, sA1, sB1, sA3, sB3)
+    BIG_STEP(kt + 1, 1, 1, 8, fa1, fb1, fa0, fb0, sA2, sB2, sA0, sB0)
+    BIG_STEP(kt + 2, 1, 1, 8, fa0, fb0, fa1, fb1, sA3, sB3, sA1, sB1)
+    BIG_STEP(kt + 3, 1, 1, 8, fa1, fb1, fa0, fb0, sA0, sB0, sA2, sB2)
+  }
+  EPIL_SETUP()
+  BIG_STEP(kt + 0, 1, 1, 8, fa0, fb0, fa1, fb1, sA1, sB1, sA3, sB3)
+  BIG_STEP(kt + 1, 0, 1, 8, fa1, fb1, fa0, fb0, sA2, sB2, sA0, sB0)
+  BIG_STEP(kt + 2, 0, 1, 0, fa0, fb0, fa1, fb1, sA3, sB3, sA1, sB1)
+  BIG_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, sA0, sB0, sA2, sB2)
+
+#else
+  // Register staging: stage S is loaded global -> registers in step S-4 (two register sets, by parity), written to LDS
+  // buffer S&1 in step S-2, read as fragments in step S-1 and consumed in step S.  ds_write_b128: lane -> row
+  // 16j + (lane>>2), global chunk lane&3 -> slot (lane&3) ^ f(lane>>4); 8 consecutive lanes cover 128 contiguous bytes.
+  uint32_t wr_off[4];
+  {
+    const uint32_t slot = (lane & 3) ^ big_swz(lane >> 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wr_off[u] = ((wave + 4 * u) * 16 + (lane >> 2)) * 64 + slot * 16;
+  }
+  // DMA offsets above carry the swizzle on the SOURCE side; register staging reads chunk lane&3 and swizzles the write
+  {
+    const uint32_t unswz = (((lane & 3) ^ big_swz(lane >> 4)) - (lane & 3)) * 16;  // bytes, may wrap: uint32 arithmetic
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { offa[u] -= unswz; offb[u] -= unswz; }
+  }
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+#define BIG_GLOAD(RA_, RB_, S)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                     \
+    RA_[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, offa[u], (S) * (BIG_BK * 2), 0);               \
+    RB_[u] = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[u], (S) * (BIG_BK * 2), 0);               \
+  }
+#define BIG_LWRITE(RA_, RB_, SA, SB)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                     \
+    *reinterpret_cast<u32x4*>((SA) + wr_off[u]) = RA_[u];                                             \
+    *reinterpret_cast<u32x4*>((SB) + wr_off[u]) = RB_[u];                                             \
+  }
+  // step K: [barrier] write stage K+2 (register set K&1 -> LDS buffer K&1), load stage K+4 into that set, read the
+  // fragments of stage K+1 (buffer (K+1)&1), 64 MFMAs on stage K.  GL / WR / RD are literals (one basic block).
+#define BIG_STEP(K, GL, WR, RD, FCA, FCB, FNA, FNB, RSA, RSB, BUFA_W, BUFB_W, BUFA_R, BUFB_R)   \
+  {                                                                                      \
+    if (RD) {                                                                            \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+      if (BIG_DIAG_BARRIER) __builtin_amdgcn_s_barrier();                                \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (WR && BIG_DIAG_DMA) { BIG_LWRITE(RSA, RSB, BUFA_W, BUFB_W) }                     \
+    if (GL && BIG_DIAG_DMA) { BIG_GLOAD(RSA, RSB, (K) + 4) }                             \
+    if (RD && BIG_DIAG_READ) { BIG_READ(FNA, FNB, BUFA_R, BUFB_R) }                      \
+    BIG_MFMA(FCA, FCB)                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+    }                                                                                    \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  }
+
+  // prologue (nk >= 4, nk even: launcher): stages 0, 1 in LDS, 2, 3 in flight to registers, fragments of stage 0 read
+  BIG_GLOAD(ra0, rb0, 0)
+  BIG_GLOAD(ra1, rb1, 1)
+  BIG_LWRITE(ra0, rb0, sA0, sB0)
+  BIG_GLOAD(ra0, rb0, 2)
+  BIG_LWRITE(ra1, rb1, sA1, sB1)
+  BIG_GLOAD(ra1, rb1, 3)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  BIG_READ(fa0, fb0, sA0, sB0)
+  if (!BIG_DIAG_READ) { BIG_READ(fa1, fb1, sA0, sB0) }
+  STAMP(1)
+
+  int kt = 0;
+  for (; kt < nk - 4; kt += 2) {
+    BIG_STEP(kt + 0, 1, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+    BIG_STEP(kt + 1, 1, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
+  }
+  // the epilogue's first inputs (bias / scale vectors, the first 16-row block) are requested here, four K steps
+  // before they are needed: nothing else loads from memory any more and the staging registers are free
+  EPIL_SETUP()
+  BIG_STEP(kt + 0, 0, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+  BIG_STEP(kt + 1, 0, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
+  BIG_STEP(kt + 2, 0, 0, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+  BIG_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
+#endif
+
+  STAMP(2)
+  // epilogue.  Wave tiles that are whole in N and keep the 16-B alignments go through the looped LDS-transpose epilogue
+  // (column sums: a wave covers its 128-row half alone -- workspace slot 2 tm + wm when the half is complete, else
+  // atomics); the rest (ragged N, odd leading dimensions) take the generic 64x64 epilogue, column sums by atomics.
+  {  // the launcher sends only shapes here whose wave tiles are whole in N and keep the 16-B alignments
+    float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm * 2 + wm) * 2) * p.N : nullptr;
+    unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;  // accumulator (i, j) of a block: + 64 j
+    ep.load_inputs(inB, 1);
+#define EPIL_DUMP_ROW(A0, A1, II, OFF)                                                           \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+    *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * j) = A0[II][j];                                  \
+    *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * (4 + j)) = A1[II][j];                            \
+  }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {  // 32 rows per trip: ONE body in the instruction cache for the whole wave tile
+      switch (q) {  // q is a loop counter; the accumulators themselves are only ever indexed statically
+        case 0: EPIL_DUMP_ROW(acc00, acc01, 0, 0) EPIL_DUMP_ROW(acc00, acc01, 1, 16 * EPIL_PITCH) break;
+        case 1: EPIL_DUMP_ROW(acc00, acc01, 2, 0) EPIL_DUMP_ROW(acc00, acc01, 3, 16 * EPIL_PITCH) break;
+        case 2: EPIL_DUMP_ROW(acc10, acc11, 0, 0) EPIL_DUMP_ROW(acc10, acc11, 1, 16 * EPIL_PITCH) break;
+        default: EPIL_DUMP_ROW(acc10, acc11, 2, 0) EPIL_DUMP_ROW(acc10, acc11, 3, 16 * EPIL_PITCH) break;
+      }
+      ep.process(inA, 2 * q, 0);
+      ep.load_inputs(inA, q < 3 ? 2 * q + 2 : 7);  // unconditional (the last trip re-reads): the operation count stays fixed
+      ep.process(inB, 2 * q + 1, 16 * EPIL_PITCH);
+      ep.load_inputs(inB, q < 3 ? 2 * q + 3 : 7);
+    }
+#undef EPIL_DUMP_ROW
+    ep.finish(lane, ws_row);
+  }
+#ifdef VLM_GEMM_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP(3)
+#endif
+}
+
+template <bool OUT_F32, bool RES, int AUX>
+static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
+  p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+  p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
+  static int group_m = -1;
+  if (group_m < 0) {
+    const char* e = getenv("VLM_GEMM_BIG_GROUP_M");
+    group_m = e ? atoi(e) : 0;
+    if (group_m < 0) group_m = 0;
+  }
+  p.group_m = group_m ? group_m : (p.tiles_n >= 6 ? 4 : 1);
+#ifdef VLM_GEMM_STAMPS
+  p.stamps = g_stamp_buffer;
+#endif
+  hipLaunchKernelGGL((vlm_gemm_big_kernel<OUT_F32, RES, AUX>), dim3(p.tiles_m * p.tiles_n), dim3(GEMM_THREADS), 0, stream, p);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// The epilogue variants the 256x256 kernel is built for; anything else runs on the 128x128 kernel (return 1: not offered).
+static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStream_t s) {
+  const vlm_epilogue_t& e = p.epi;
+  const bool res = e.residual != nullptr;
+  const int aux = e.aux ? (e.act == VLM_ACT_GELU_BWD ? 2 : 1) : 0;
+  if (e.row_scale && !res) return 1;
+  if (!c_is_f32 && !res) {
+    if (aux == 0) return launch_gemm_big<false, false, 0>(p, s);
+    if (aux == 1) return launch_gemm_big<false, false, 1>(p, s);
+    return launch_gemm_big<false, false, 2>(p, s);
+  }
+  if (c_is_f32 && aux != 2) {
+    if (res) return aux ? launch_gemm_big<true, true, 1>(p, s) : launch_gemm_big<true, true, 0>(p, s);
+    if (aux == 0) return launch_gemm_big<true, false, 0>(p, s);
+  }
+  return 1;
+}
+
+// VLM_GEMM_BIG: 0 = never, 1 = by shape (default), 2 = whenever the kernel is legal (tests); vlm_gemm_set_big_tile_mode
+// overrides the environment (tests compare the two kernels in one process), -1 returns to it
+static int g_big_mode = -1;
+static int gemm_big_mode() {
+  if (g_big_mode < 0) {
+    const char* e = getenv("VLM_GEMM_BIG");
+    g_big_mode = e ? atoi(e) : 1;
+  }
+  return g_big_mode;
+}
+extern "C" int vlm_gemm_set_big_tile_mode(int mode) {
+  if (mode < -1 || mode > 2) return VLM_ERR_ARG;
+  g_big_mode = mode;
+  return VLM_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------------------------
 // Tile-shape experiments (round 1, removed from the build; see DESIGN.md section 4 and git history for the code):
 //  * 256x128x32, 4 waves of 128x64, three 24-KiB stages, two workgroups per CU: same ~1500 cycles per 32 MFMAs per wave
@@ -753,6 +1274,23 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
   }
+  if (!ta && !tb && (K % (4 * BIG_BK)) == 0 && gemm_big_mode() > 0) {
+    // by shape: enough 256x256 tiles to fill the chip for several rounds, and an N that the 256-wide tiles cover well
+    const long big_tiles = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BIG_BN - 1) / BIG_BN);
+    int cus = vlm_device_cus();
+    if (cus <= 0) cus = 256;
+    // the kernel has only the looped 128-column epilogue: whole wave tiles in N, 16-B epilogue vectors
+    const bool off32 = (uint64_t)M * ldc * 4 < (1ull << 31) && (!epi->residual || (uint64_t)M * epi->ld_res * 4 < (1ull << 31)) &&
+                       (!epi->aux || (uint64_t)M * epi->ld_aux * 2 < (1ull << 31));  // the epilogue's buffer descriptors
+    const bool ws_ok = (N % 128) == 0 && p.epi.reserved == 1 && off32 && !epi->accumulate;
+    if (ws_ok && (gemm_big_mode() >= 2 || big_tiles >= 3L * cus)) {
+      const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, s);
+      if (rc <= 0) return rc;
+    }
+  }
+#ifdef GEMM_ONLY_BIG  // tools/scratch/gemm_bench.hip: skip the other instantiations (compile time)
+  return VLM_ERR_UNSUPPORTED;
+#endif
   const int key = (ta ? 4 : 0) | (tb ? 2 : 0) | (c_is_f32 ? 1 : 0);
   switch (key) {
     case 0: return dispatch_stage<false, false, false>(p, s);
