@@ -1,7 +1,7 @@
 // Standalone timing harness for the 256x256 GEMM kernel (diagnostic, never part of the product library).
 // Build (CPU container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGEMM_ONLY_BIG [-DBIG_DIAG_DMA=0 ...] -I include \
 //                           tools/scratch/gemm_bench.hip -o tools/scratch/gemm_bench[_variant]
-// Run (GPU box):          tools/scratch/gemm_bench M N K [f32out]
+// Run (GPU box):          tools/scratch/gemm_bench M N K [epilogue variant 0..4]
 #include "../../vl-merging_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstring>
@@ -13,7 +13,10 @@ extern "C" int vlm_device_cus(void) { return 256; }
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
-  const int f32 = argc > 4 ? atoi(argv[4]) : 0;
+  // variant: 0 plain bf16, 1 bias + GELU + pre-activation copy (fc1 fwd), 2 GELU' + column sums (fc2 dgrad),
+  //          3 f32 residual stream: bias, gamma, row scale, residual in place, branch copy (proj / fc2 fwd), 4 plain f32
+  const int variant = argc > 4 ? atoi(argv[4]) : 0;
+  const int f32 = variant >= 3;
   std::vector<uint16_t> h((size_t)(M > N ? M : N) * K);
   uint32_t s = 12345;
   for (auto& v : h) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; uint32_t u; memcpy(&u, &f, 4); v = u >> 16; }
@@ -23,6 +26,14 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
   vlm_epilogue_t e = {};
   e.alpha = 1.0f;
+  void *aux = nullptr; float *vec = nullptr, *ws = nullptr;
+  CK(hipMalloc(&aux, (size_t)M * N * 2)); CK(hipMemset(aux, 0, (size_t)M * N * 2));
+  CK(hipMalloc(&vec, (size_t)(4 * N + M) * 4)); CK(hipMemset(vec, 0, (size_t)(4 * N + M) * 4));
+  CK(hipMalloc(&ws, (size_t)(M / 128 + 2) * 2 * N * 4));
+  if (variant == 1) { e.bias = vec; e.act = VLM_ACT_GELU; e.aux = aux; e.ld_aux = N; }
+  if (variant == 2) { e.act = VLM_ACT_GELU_BWD; e.aux = aux; e.ld_aux = N; e.col_sum = vec + N; e.col_sum_ws = ws; }
+  if (variant == 3) { e.bias = vec; e.col_scale = vec + 2 * N; e.row_scale = vec + 4 * N; e.residual = (float*)nullptr; e.aux = aux; e.ld_aux = N; }
+  if (variant == 3) { e.residual = (const float*)C; e.ld_res = N; }
   setenv("VLM_GEMM_BIG", "2", 1);
   auto run = [&]() {
     int rc = vlm_gemm_bf16(0, 0, M, N, K, A, K, B, K, C, N, f32, &e, 0);

@@ -1275,7 +1275,6 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     }
   }
   if (!ta && !tb && (K % (4 * BIG_BK)) == 0 && gemm_big_mode() > 0) {
-    // by shape: enough 256x256 tiles to fill the chip for several rounds, and an N that the 256-wide tiles cover well
     const long big_tiles = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BIG_BN - 1) / BIG_BN);
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;
@@ -1283,7 +1282,8 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     const bool off32 = (uint64_t)M * ldc * 4 < (1ull << 31) && (!epi->residual || (uint64_t)M * epi->ld_res * 4 < (1ull << 31)) &&
                        (!epi->aux || (uint64_t)M * epi->ld_aux * 2 < (1ull << 31));  // the epilogue's buffer descriptors
     const bool ws_ok = (N % 128) == 0 && p.epi.reserved == 1 && off32 && !epi->accumulate;
-    if (ws_ok && (gemm_big_mode() >= 2 || big_tiles >= 3L * cus)) {
+    // measured (tools/bench_gemm.py, M = 13 574 and 54 296): ahead of the 128x128 kernel from half a round of tiles up
+    if (ws_ok && (gemm_big_mode() >= 2 || 2 * big_tiles >= cus)) {
       const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, s);
       if (rc <= 0) return rc;
     }
