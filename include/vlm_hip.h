@@ -28,7 +28,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 3
+#define VLM_ABI_VERSION 4
 int vlm_abi_version(void);
 /* Number of compute units of the current device (grid sizing), or negative error. */
 int vlm_device_cus(void);
@@ -106,6 +106,11 @@ typedef struct {
   float* col_sum_ws;       /* optional with col_sum (N % 128 == 0): f32 [M/128][2][N]; complete 128-row tiles store their
                               column sums at [tile][0][:] instead of adding them to col_sum -- the caller folds rows
                               0 .. M/128-1 into col_sum with vlm_colreduce_batch; the ragged last tile still adds directly */
+  float* splitk_ws;        /* optional scratch for ta = tb = 1 (wgrad) calls: with it the reduction over K may be cut into
+                              slices that store fp32 tiles [slice][M][N] here and are added into C by a second launch on
+                              the same stream (no float atomics); NULL or too small: the atomic split-K path.  The caller
+                              keeps one scratch per stream that runs such calls */
+  uint64_t splitk_ws_bytes;
 } vlm_epilogue_t;
 
 int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,

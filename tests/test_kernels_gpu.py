@@ -478,3 +478,32 @@ def test_gemm_big_tile_col_sum_workspace(ops, L, big_tile):
     torch.nn.functional.gelu(hh).backward((A.float() @ B.float().t()) * 0.1)
     assert_close(got, hh.grad.sum(0) + 1.5, 2e-3, 2e-2, "256-tile col_sum through the fold workspace")
     assert_close(out, hh.grad, 1e-2, 2e-2, "256-tile gelu_bwd")
+
+
+@pytest.mark.parametrize("M,N,K", [(3072, 768, 13574), (768, 3072, 5000), (768, 768, 2048 + 8), (2304, 768, 54296), (1000, 256, 4100)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_big_tile_wgrad(ops, L, big_tile, M, N, K, accumulate):
+    """dW = A^T B with both operands K-strided through the 256x256 kernel: K slices (ragged K: 13574 = 424*32 + 6) stored
+    to the workspace and added by the reduce launch -- against fp32 matmul and against the atomic split-K path."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N + K)
+    A = bf(torch.randn(K, M, device="cuda", generator=gen))
+    B = bf(torch.randn(K, N, device="cuda", generator=gen))
+    base = torch.randn(M, N, device="cuda", generator=gen)
+    want = A.float().t() @ B.float() * 0.01 + (base if accumulate else 0)
+    got = {}
+    for mode in (2, 0):
+        L.check(big_tile.vlm_gemm_set_big_tile_mode(mode), "mode")
+        c = torch.full((M + 2, N), 3.0, device="cuda")
+        c[:M] = base
+        ops.gemm(A, B, c[:M], ta=True, tb=True, alpha=0.01, accumulate=accumulate)
+        got[mode] = c
+    tol = 2e-3 * math.sqrt(K) * 0.01
+    assert_close(got[2][:M], want, 1e-3, tol, "256-tile wgrad")
+    assert float((got[2][M:] - 3.0).abs().max()) == 0.0
+    assert_close(got[2][:M], got[0][:M], 1e-3, tol, "256-tile wgrad vs atomic split-K")
+    # the workspace path is deterministic (fixed slice order), the atomic one is not required to be
+    L.check(big_tile.vlm_gemm_set_big_tile_mode(2), "mode")
+    c2 = torch.full((M + 2, N), 3.0, device="cuda")
+    c2[:M] = base
+    ops.gemm(A, B, c2[:M], ta=True, tb=True, alpha=0.01, accumulate=accumulate)
+    assert torch.equal(c2, got[2])

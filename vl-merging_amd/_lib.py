@@ -33,7 +33,7 @@ class Epilogue(ctypes.Structure):
         ("bias", c_void_p), ("col_scale", c_void_p), ("row_scale", c_void_p), ("residual", c_void_p),
         ("ld_res", ctypes.c_int64), ("aux", c_void_p), ("ld_aux", ctypes.c_int64), ("act", ctypes.c_int32),
         ("alpha", c_float), ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32), ("col_sum", c_void_p),
-        ("col_sum_ws", c_void_p),
+        ("col_sum_ws", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", ctypes.c_uint64),
     ]
 
 

@@ -852,6 +852,31 @@ struct big_epilogue_t {
   }
 };
 
+// The loop both 256x256 kernels run over their wave tile once `ep`, `inA` (block 0 requested) and `wl` exist: 32 rows per
+// trip -- two 16-row blocks dropped into LDS, read back row-major, finished and stored, the inputs of the blocks after
+// them requested meanwhile.  ONE loop body in the instruction cache for the whole wave tile; the trip counter only
+// picks which (statically named) accumulators are dropped.
+#define EPIL_DUMP_ROW(A0, A1, II, OFF)                                                           \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+    *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * j) = A0[II][j];                                  \
+    *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * (4 + j)) = A1[II][j];                            \
+  }
+#define BIG_EPILOGUE_LOOP()                                                                                        \
+  unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16; /* accumulator (i, j) of a block: + 64 j */ \
+  ep.load_inputs(inB, 1);                                                                                          \
+  _Pragma("unroll 1") for (int q = 0; q < 4; ++q) {                                                                \
+    switch (q) {                                                                                                   \
+      case 0: EPIL_DUMP_ROW(acc00, acc01, 0, 0) EPIL_DUMP_ROW(acc00, acc01, 1, 16 * EPIL_PITCH) break;             \
+      case 1: EPIL_DUMP_ROW(acc00, acc01, 2, 0) EPIL_DUMP_ROW(acc00, acc01, 3, 16 * EPIL_PITCH) break;             \
+      case 2: EPIL_DUMP_ROW(acc10, acc11, 0, 0) EPIL_DUMP_ROW(acc10, acc11, 1, 16 * EPIL_PITCH) break;             \
+      default: EPIL_DUMP_ROW(acc10, acc11, 2, 0) EPIL_DUMP_ROW(acc10, acc11, 3, 16 * EPIL_PITCH) break;            \
+    }                                                                                                              \
+    ep.process(inA, 2 * q, 0);                                                                                     \
+    ep.load_inputs(inA, q < 3 ? 2 * q + 2 : 7); /* unconditional (the last trip re-reads): fixed operation count */ \
+    ep.process(inB, 2 * q + 1, 16 * EPIL_PITCH);                                                                   \
+    ep.load_inputs(inB, q < 3 ? 2 * q + 3 : 7);                                                                    \
+  }
+
 template <bool OUT_F32, bool RES, int AUX>
 __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gemm_params_t p) {
 #if BIG_STAGE_REGS
@@ -1073,33 +1098,185 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   // atomics); the rest (ragged N, odd leading dimensions) take the generic 64x64 epilogue, column sums by atomics.
   {  // the launcher sends only shapes here whose wave tiles are whole in N and keep the 16-B alignments
     float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm * 2 + wm) * 2) * p.N : nullptr;
-    unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;  // accumulator (i, j) of a block: + 64 j
-    ep.load_inputs(inB, 1);
-#define EPIL_DUMP_ROW(A0, A1, II, OFF)                                                           \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
-    *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * j) = A0[II][j];                                  \
-    *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * (4 + j)) = A1[II][j];                            \
-  }
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {  // 32 rows per trip: ONE body in the instruction cache for the whole wave tile
-      switch (q) {  // q is a loop counter; the accumulators themselves are only ever indexed statically
-        case 0: EPIL_DUMP_ROW(acc00, acc01, 0, 0) EPIL_DUMP_ROW(acc00, acc01, 1, 16 * EPIL_PITCH) break;
-        case 1: EPIL_DUMP_ROW(acc00, acc01, 2, 0) EPIL_DUMP_ROW(acc00, acc01, 3, 16 * EPIL_PITCH) break;
-        case 2: EPIL_DUMP_ROW(acc10, acc11, 0, 0) EPIL_DUMP_ROW(acc10, acc11, 1, 16 * EPIL_PITCH) break;
-        default: EPIL_DUMP_ROW(acc10, acc11, 2, 0) EPIL_DUMP_ROW(acc10, acc11, 3, 16 * EPIL_PITCH) break;
-      }
-      ep.process(inA, 2 * q, 0);
-      ep.load_inputs(inA, q < 3 ? 2 * q + 2 : 7);  // unconditional (the last trip re-reads): the operation count stays fixed
-      ep.process(inB, 2 * q + 1, 16 * EPIL_PITCH);
-      ep.load_inputs(inB, q < 3 ? 2 * q + 3 : 7);
-    }
-#undef EPIL_DUMP_ROW
+    BIG_EPILOGUE_LOOP()
     ep.finish(lane, ws_row);
   }
 #ifdef VLM_GEMM_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
   STAMP(3)
 #endif
+}
+
+// ---- 256x256 tile for wgrad: dW[M,N] = A^T B with BOTH operands K-strided (A stored [K][M], B stored [K][N]) ---------
+// Same pipeline as vlm_gemm_big_kernel (register staging, two LDS buffers, 32-deep steps, one barrier per step); the LDS
+// image of an operand stage is [32 k][256 x] bf16 (512-B rows, 32-B chunks XOR-swizzled by (k&3) | ((k>>3)&1)<<2) and a
+// fragment is two ds_read_b64_tr_b16.  The reduction over tokens is cut over gridDim.x / tiles slices (36 or fewer
+// output tiles on 256 CUs); a slice does not add into C with atomics (1 024 256-B float atomics per workgroup would cost
+// as much as 80 K steps, MI355X_MICROARCH.md "Global float atomics") but stores its fp32 tile into the caller's
+// workspace [slice][M][N] through the looped epilogue, and splitk_reduce_kernel adds the slices into C.
+__global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const gemm_params_t p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char epl[4 * EPIL_WAVE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t ntile = p.tiles_m * p.tiles_n, tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  const uint32_t tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG_BN;
+  const uint32_t k_first = split * (uint32_t)p.ksteps_per_split * BIG_BK;
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.K * p.lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.K * p.ldb * 2), 0x00020000);
+
+  // staging: wave instruction j = wave + 4u covers k-rows 2j, 2j+1; lane -> k-row 2j + (lane>>5), 16-B chunk lane&31.
+  // Rows k >= K fall off the descriptor (zeros); x >= M or N reads the next row's head: those accumulators are dropped.
+  uint32_t offa[4], offb[4], wr_off[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t row = 2 * (wave + 4 * u) + (lane >> 5), c16 = lane & 31;
+    offa[u] = ((k_first + row) * (uint32_t)p.lda + m0 + c16 * 8) * 2;
+    offb[u] = ((k_first + row) * (uint32_t)p.ldb + n0 + c16 * 8) * 2;
+    wr_off[u] = row * 512 + (((c16 >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 5) + (c16 & 1) * 16;
+  }
+  // fragments: 16-wide x block i of this wave's 128, lane -> k-rows 8g + q (+4), g = lane>>4, q = (lane&15)>>2
+  uint32_t rda[8], rdb[8];
+  {
+    const uint32_t g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, sw = q | ((g & 1) << 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rda[i] = (8 * g + q) * 512 + wm * 256 + ((i ^ sw) << 5) + 8 * pp;
+      rdb[i] = (8 * g + q) * 512 + wn * 256 + ((i ^ sw) << 5) + 8 * pp;
+    }
+  }
+  f32x4 acc00[4][4], acc01[4][4], acc10[4][4], acc11[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc00[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc01[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc10[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc11[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  const int nk = p.ksteps_per_split;  // even, >= 4: launcher
+  const uint32_t stepa = BIG_BK * (uint32_t)p.lda * 2, stepb = BIG_BK * (uint32_t)p.ldb * 2;
+  bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+#define BIGT_TR(PTR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(PTR))
+#define BIGT_READ(FA, FB, SA, SB)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                    \
+    const s16x4 al = BIGT_TR((SA) + rda[i]), ah = BIGT_TR((SA) + rda[i] + 4 * 512);                  \
+    const s16x4 bl = BIGT_TR((SB) + rdb[i]), bh = BIGT_TR((SB) + rdb[i] + 4 * 512);                  \
+    FA[i] = __builtin_bit_cast(bf16x8, (s16x8){al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]}); \
+    FB[i] = __builtin_bit_cast(bf16x8, (s16x8){bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]}); \
+  }
+#define BIGT_GLOAD(RA_, RB_, S)                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
+    RA_[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, offa[u], (S) * stepa, 0);                     \
+    RB_[u] = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[u], (S) * stepb, 0);                     \
+  }
+#define BIGT_LWRITE(RA_, RB_, SA, SB)                                                                \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
+    *reinterpret_cast<u32x4*>((SA) + wr_off[u]) = RA_[u];                                            \
+    *reinterpret_cast<u32x4*>((SB) + wr_off[u]) = RB_[u];                                            \
+  }
+#define BIGT_STEP(K, GL, WR, RD, FCA, FCB, FNA, FNB, RSA, RSB, BUFA_W, BUFB_W, BUFA_R, BUFB_R)      \
+  {                                                                                      \
+    if (RD) {                                                                            \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+      __builtin_amdgcn_s_barrier();                                                      \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    if (WR) { BIGT_LWRITE(RSA, RSB, BUFA_W, BUFB_W) }                                    \
+    if (GL) { BIGT_GLOAD(RSA, RSB, (K) + 4) }                                            \
+    if (RD) { BIGT_READ(FNA, FNB, BUFA_R, BUFB_R) }                                      \
+    BIG_MFMA(FCA, FCB)                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 32; ++g) {                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
+    }                                                                                    \
+    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+    }                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  }
+  BIGT_GLOAD(ra0, rb0, 0)
+  BIGT_GLOAD(ra1, rb1, 1)
+  BIGT_LWRITE(ra0, rb0, sA0, sB0)
+  BIGT_GLOAD(ra0, rb0, 2)
+  BIGT_LWRITE(ra1, rb1, sA1, sB1)
+  BIGT_GLOAD(ra1, rb1, 3)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  BIGT_READ(fa0, fb0, sA0, sB0)
+  int kt = 0;
+  for (; kt < nk - 4; kt += 2) {
+    BIGT_STEP(kt + 0, 1, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+    BIGT_STEP(kt + 1, 1, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
+  }
+  BIGT_STEP(kt + 0, 0, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+  BIGT_STEP(kt + 1, 0, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
+  BIGT_STEP(kt + 2, 0, 0, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+  BIGT_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
+
+  // this slice's fp32 tile -> workspace [split][M][N] (plain f32 epilogue, alpha applied; rows >= M dropped)
+  gemm_params_t pl = p;
+  pl.C = reinterpret_cast<float*>(p.C) + (size_t)split * p.M * p.N;
+  pl.ldc = p.N;
+  const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+  unsigned char* const wl = epl + wave * EPIL_WAVE_BYTES;
+  big_epilogue_t<true, false, 0> ep(pl, wl, mw0, nw0, lane);
+  epil_in_t inA, inB;
+  ep.load_inputs(inA, 0);
+  BIG_EPILOGUE_LOOP()
+}
+
+// C[m][n] (+)= sum over slices of ws[s][m][n]: one f32x4 per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float* __restrict__ C,
+                                                            int ldc, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)M * N / 4;
+  if (i >= per) return;
+  const size_t e = i * 4, m = e / N, n = e - m * N;
+  f32x4 t = accumulate ? *reinterpret_cast<const f32x4*>(C + m * ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) t += *reinterpret_cast<const f32x4*>(ws + (size_t)s * M * N + e);
+  *reinterpret_cast<f32x4*>(C + m * ldc + n) = t;
+}
+
+// wgrad through the 256x256 kernel: 1 = not offered (no / too small workspace, shape), else the launch's return code
+static int launch_gemm_bigT(gemm_params_t p, const vlm_epilogue_t* epi, hipStream_t stream) {
+  if (!epi->splitk_ws || (p.N % 128) || (p.N % 4) || (p.ldc % 4)) return 1;
+  if ((uint64_t)p.M * p.N * 4 >= (1ull << 31)) return 1;
+  p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+  p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
+  const int ntile = p.tiles_m * p.tiles_n, nk = (p.K + BIG_BK - 1) / BIG_BK;
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  int splits = cus / ntile;  // one round of workgroups, never a little more
+  if (splits < 1) splits = 1;
+  if (splits > nk / 16) splits = nk / 16;  // >= 16 steps per slice
+  if (splits < 1) return 1;
+  int kps = (nk + splits - 1) / splits;
+  kps += kps & 1;
+  if (kps < 4) kps = 4;
+  splits = (nk + kps - 1) / kps;
+  if ((size_t)splits * p.M * p.N * 4 > (size_t)epi->splitk_ws_bytes) return 1;
+  p.ksteps_per_split = kps;
+  p.splits = splits;
+  float* const out = reinterpret_cast<float*>(p.C);
+  const int ldc = p.ldc;
+  p.C = epi->splitk_ws;
+  hipLaunchKernelGGL(vlm_gemm_bigT_kernel, dim3(ntile * splits), dim3(GEMM_THREADS), 0, stream, p);
+  VLM_CHECK_LAUNCH();
+  const size_t per = (size_t)p.M * p.N / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const float*>(epi->splitk_ws), splits, p.M, p.N, out, ldc, epi->accumulate);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
 }
 
 template <bool OUT_F32, bool RES, int AUX>
@@ -1252,6 +1429,16 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   const int ntile = p.tiles_m * p.tiles_n, nk = (K + GEMM_BK - 1) / GEMM_BK;
   const bool plain_acc = epi->accumulate && c_is_f32 && !epi->bias && !epi->col_scale && !epi->row_scale &&
                          !epi->residual && !epi->aux && !epi->col_sum && epi->act == VLM_ACT_NONE;
+  static int bigt = -1;  // VLM_GEMM_BIGT=0: wgrad stays on the 128x128 atomic split-K kernel (A/B runs)
+  if (bigt < 0) {
+    const char* e = getenv("VLM_GEMM_BIGT");
+    bigt = e ? atoi(e) : 1;
+  }
+  if (bigt && gemm_big_mode() > 0 && ta && tb && c_is_f32 && !epi->bias && !epi->col_scale && !epi->row_scale && !epi->residual &&
+      !epi->aux && !epi->col_sum && epi->act == VLM_ACT_NONE && K >= 2048) {
+    const int rc = launch_gemm_bigT(p, epi, s);
+    if (rc <= 0) return rc;
+  }
   if (gemm_splitk_enabled() && ta && tb && plain_acc && ntile < 512 && nk >= 32) {
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;

@@ -58,6 +58,10 @@ def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, 
             e.col_sum_ws = region.data_ptr()
         else:
             region = None
+    if ta and tb and out.dtype == F32 and K >= 2048 and bias is None and col_sum is None:
+        ws = _splitk_workspace(out.device)
+        e.splitk_ws = ws.data_ptr()
+        e.splitk_ws_bytes = ws.numel() * 4
     if col_sum is not None and (col_sum.numel() < N or not col_sum.is_contiguous()):
         raise L.VlmError("gemm: col_sum must be a contiguous f32 vector of at least N elements")
     for t, dt in ((bias, F32), (col_scale, F32), (row_scale, F32), (residual, F32), (aux, BF16), (col_sum, F32)):
@@ -71,6 +75,20 @@ def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, 
     if region is not None:
         col_sum_fold.add(region, M // 128, N, col_sum, None)
     return out
+
+
+_SPLITK_WS = {}
+SPLITK_WS_BYTES = 96 << 20
+
+
+def _splitk_workspace(device):
+    """Per (device, stream) scratch for the wgrad GEMM's K slices (vlm_epilogue_t.splitk_ws): fp32 [slice][M][N] tiles,
+    at most 256 CUs / tiles slices of an M x N <= 3072 x 768 weight -- 66 MB at the base width."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=F32)
+    return ws
 
 
 def layernorm_fwd(x, gamma, beta, eps, out, stats=None):
