@@ -648,12 +648,16 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 // cycles that tools/stamp_gemm.py shows.  Waves of 128x128 halve the fragment bytes per MFMA and the 256x256 tile halves
 // the staged bytes per MFMA, so the matrix pipe is the only pipe near its limit.  With one wave per SIMD nothing but the
 // wave's own instruction stream hides latency, so the K loop is software-pipelined by hand:
-//   * K steps of 32, FOUR 32-KiB LDS stages (separate __shared__ objects: the compiler proves a stage's DMA and another
-//     stage's ds_reads disjoint and the waits can be counted): during step k the wave issues the DMA of stage k+3,
-//     reads the fragments of stage k+1 into the second fragment buffer and runs the 64 MFMAs of stage k out of the
-//     first; sched_group_barrier spreads the 16 ds_read_b128 and 8 DMA instructions between the MFMAs;
-//   * one barrier per step (top of the step): stage k+1 has landed for every wave (vmcnt(8): only stage k+2 may still be
-//     in flight) and nobody reads the buffer that stage k+3 is about to overwrite.
+//   * K steps of 32.  Stage S is loaded global -> registers in step S-4 (two register sets, by parity), written to LDS
+//     buffer S&1 in step S-2 (ds_write_b128), read as fragments in step S-1 and consumed by 64 MFMAs in step S;
+//     sched_group_barrier spreads the 16 ds_read_b128, 8 ds_write_b128 and 8 buffer loads of a step between its MFMAs;
+//   * one barrier per step (top of the step): the writes of stage S+1 are visible and nobody still reads the buffer that
+//     stage S+2 is about to overwrite.
+// Tried and dropped (tools/scratch/gemm_bench.hip; git history): an LDS-DMA version with four LDS stages and counted vmcnt
+// (tie: 1128 vs 1092 TFLOP/s at 4096x4096x8192, twice the LDS); a PERSISTENT version whose next tile's first stages went
+// out by inline-asm LDS-DMA under the last two K steps with a hand-counted vmcnt in front of their use (tie: 319 vs 321 us
+// at 54296x3072x768 -- vmcnt is one in-order counter, so the next tile's first register-staged loads still wait for
+// the epilogue's stores; with the C stores removed the same kernel takes 270 us: the store drain is what remains).
 // LDS image of an operand stage: [256 rows][32 k] bf16, 64-B rows, 16-B slot s of row r holds chunk s ^ f((r>>2)&3),
 // f = (0,2,3,1): conflict-free for ds_read_b128's lane groups (rows {0-3,12-15} x chunk c with rows {4-11} x chunk c^1).
 // diagnostic timing builds only (tools/scratch/gemm_bench.hip; results are wrong): knock out one part of the K loop
@@ -666,29 +670,12 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 #ifndef BIG_DIAG_BARRIER
 #define BIG_DIAG_BARRIER 1
 #endif
-#ifndef BIG_STAGE_REGS
-#define BIG_STAGE_REGS 1  // 1: global -> registers -> ds_write_b128 (two LDS buffers); 0: LDS-DMA (four LDS buffers)
-#endif
 #define BIG_BM 256
 #define BIG_BN 256
 #define BIG_BK 32
 #define BIG_OP_BYTES (256 * BIG_BK * 2)  // 16 KiB per operand per stage
 
 __device__ __forceinline__ uint32_t big_swz(uint32_t q) { return (0x78u >> (2 * q)) & 3u; }  // f = (0,2,3,1)
-
-// this wave's 4 DMA instructions of one operand stage: instruction j = wave + 4u covers rows 16j .. 16j+15
-__device__ __forceinline__ void big_dma(__amdgpu_buffer_rsrc_t rsrc, unsigned char* stage, const uint32_t (&off)[4],
-                                        uint32_t soff, int wave) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(stage + (wave + 4 * u) * 1024), 16, off[u], soff, 0, 0);
-}
-
-__device__ __forceinline__ void big_wait_vm(int later_stages) {  // all but the newest `later_stages` stages have landed
-  if (later_stages >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (later_stages == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 
 // ---- looped epilogue of a 128x128 wave tile through a wave-private LDS transpose ------------------------------------
 // The straight-line epilogue above is executed once per wave and is instruction-FETCH bound (tools/scratch/gemm_bench.hip:
@@ -855,14 +842,17 @@ struct big_epilogue_t {
 // The loop both 256x256 kernels run over their wave tile once `ep`, `inA` (block 0 requested) and `wl` exist: 32 rows per
 // trip -- two 16-row blocks dropped into LDS, read back row-major, finished and stored, the inputs of the blocks after
 // them requested meanwhile.  ONE loop body in the instruction cache for the whole wave tile; the trip counter only
-// picks which (statically named) accumulators are dropped.
+// picks which (statically named) accumulators are dropped.  Every load is unconditional (the last trip re-reads block 7):
+// the operation count of a trip stays fixed and the compiler's vmcnt waits stay counted.  (Four rotating input sets,
+// inputs three blocks ahead: no gain for the GELU' variant -- its epilogue is VALU-bound -- spills for the residual
+// variants, and 40 more VGPRs that slowed the K loop of the others from 1488 to 1828 cycles per step.)
 #define EPIL_DUMP_ROW(A0, A1, II, OFF)                                                           \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
     *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * j) = A0[II][j];                                  \
     *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * (4 + j)) = A1[II][j];                            \
   }
-#define BIG_EPILOGUE_LOOP()                                                                                        \
-  unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16; /* accumulator (i, j) of a block: + 64 j */ \
+#define BIG_EPILOGUE_LOOP()                                                                                       \
+  unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;                                            \
   ep.load_inputs(inB, 1);                                                                                          \
   _Pragma("unroll 1") for (int q = 0; q < 4; ++q) {                                                                \
     switch (q) {                                                                                                   \
@@ -872,19 +862,14 @@ struct big_epilogue_t {
       default: EPIL_DUMP_ROW(acc10, acc11, 2, 0) EPIL_DUMP_ROW(acc10, acc11, 3, 16 * EPIL_PITCH) break;            \
     }                                                                                                              \
     ep.process(inA, 2 * q, 0);                                                                                     \
-    ep.load_inputs(inA, q < 3 ? 2 * q + 2 : 7); /* unconditional (the last trip re-reads): fixed operation count */ \
+    ep.load_inputs(inA, q < 3 ? 2 * q + 2 : 7);                                                                    \
     ep.process(inB, 2 * q + 1, 16 * EPIL_PITCH);                                                                   \
     ep.load_inputs(inB, q < 3 ? 2 * q + 3 : 7);                                                                    \
   }
 
 template <bool OUT_F32, bool RES, int AUX>
 __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gemm_params_t p) {
-#if BIG_STAGE_REGS
   __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES];
-#else
-  __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sA2[BIG_OP_BYTES], sA3[BIG_OP_BYTES];
-  __shared__ __attribute__((aligned(1024))) unsigned char sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES], sB2[BIG_OP_BYTES], sB3[BIG_OP_BYTES];
-#endif
   __shared__ __attribute__((aligned(16))) unsigned char epl[4 * EPIL_WAVE_BYTES];  // wave-private epilogue transposes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -908,17 +893,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   const __amdgpu_buffer_rsrc_t rb =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
 
-  // per-lane DMA source offsets (k0 = 0; the step adds 64 B per stage through the scalar offset): lane -> row
-  // 16j + (lane>>2), LDS slot (lane&3) <- global chunk (lane&3) ^ f(lane>>4)
+  // per-lane staging offsets (k0 = 0; the step adds 64 B per stage through the scalar offset): instruction j = wave + 4u
+  // covers rows 16j .. 16j+15, lane -> row 16j + (lane>>2), global chunk lane&3
   uint32_t offa[4], offb[4];
-  {
-    const uint32_t chunk = (lane & 3) ^ big_swz(lane >> 4);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t row = (wave + 4 * u) * 16 + (lane >> 2);
-      offa[u] = ((m0 + row) * (uint32_t)p.lda + chunk * 8) * 2;
-      offb[u] = ((n0 + row) * (uint32_t)p.ldb + chunk * 8) * 2;
-    }
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t row = (wave + 4 * u) * 16 + (lane >> 2);
+    offa[u] = ((m0 + row) * (uint32_t)p.lda + (lane & 3) * 8) * 2;
+    offb[u] = ((n0 + row) * (uint32_t)p.ldb + (lane & 3) * 8) * 2;
   }
   // fragment read addresses: 16-row block i of this wave's 128 rows: row = w*128 + 16 i + (lane&15), chunk lane>>4
   const uint32_t rd_slot = ((uint32_t)(lane >> 4) ^ big_swz((lane & 15) >> 2)) * 16 + (lane & 15) * 64;
@@ -958,61 +940,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   BIG_MFMA_Q(acc01, FA, FB, 0, 4) \
   BIG_MFMA_Q(acc11, FA, FB, 4, 4) \
   BIG_MFMA_Q(acc10, FA, FB, 4, 0)
-#if !BIG_STAGE_REGS
-  // step K: consume fragments FC (stage K), read stage K+1 (RA/RB) into FN, DMA stage K+3 into WA/WB.  DMA / READ / VM
-  // are literals so that a step is ONE basic block (sched_group_barrier cannot move anything across a branch); VM = the
-  // vmcnt that leaves only stage K+2 in flight.
-#define BIG_STEP(K, DMA, READ, VM, FCA, FCB, FNA, FNB, RA, RB, WA, WB)                   \
-  {                                                                                      \
-    if (READ) {                                                                          \
-      asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                             \
-      if (BIG_DIAG_BARRIER) __builtin_amdgcn_s_barrier();                                \
-    }                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-    if (DMA && BIG_DIAG_DMA) {                                                           \
-      big_dma(ra, WA, offa, ((K) + 3) * (BIG_BK * 2), wave);                             \
-      big_dma(rb, WB, offb, ((K) + 3) * (BIG_BK * 2), wave);                             \
-    }                                                                                    \
-    if (READ && BIG_DIAG_READ) { BIG_READ(FNA, FNB, RA, RB) }                            \
-    BIG_MFMA(FCA, FCB)                                                                   \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) { /* fragment reads first: they are consumed next step */ \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-    }                                                                                    \
-    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                      \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
-    }                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                   \
-  }
-
-  // prologue: stages 0..2 in flight, stage 0 landed, its fragments in registers (nk >= 4 and nk % 4 == 0: launcher)
-  big_dma(ra, sA0, offa, 0, wave);
-  big_dma(rb, sB0, offb, 0, wave);
-  big_dma(ra, sA1, offa, 1 * BIG_BK * 2, wave);
-  big_dma(rb, sB1, offb, 1 * BIG_BK * 2, wave);
-  big_dma(ra, sA2, offa, 2 * BIG_BK * 2, wave);
-  big_dma(rb, sB2, offb, 2 * BIG_BK * 2, wave);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  BIG_READ(fa0, fb0, sA0, sB0)
-  if (!BIG_DIAG_READ) { BIG_READ(fa1, fb1, sA0, sB0) }
-
-  int kt = 0;
-  for (; kt < nk - 4; kt += 4) {
-    BIG_STEP(kt + 0, 1, 1, 8, fa0, fb0, fa1, fb1, sA1, sB1, sA3, sB3)
-    BIG_STEP(kt + 1, 1, 1, 8, fa1, fb1, fa0, fb0, sA2, sB2, sA0, sB0)
-    BIG_STEP(kt + 2, 1, 1, 8, fa0, fb0, fa1, fb1, sA3, sB3, sA1, sB1)
-    BIG_STEP(kt + 3, 1, 1, 8, fa1, fb1, fa0, fb0, sA0, sB0, sA2, sB2)
-  }
-  EPIL_SETUP()
-  BIG_STEP(kt + 0, 1, 1, 8, fa0, fb0, fa1, fb1, sA1, sB1, sA3, sB3)
-  BIG_STEP(kt + 1, 0, 1, 8, fa1, fb1, fa0, fb0, sA2, sB2, sA0, sB0)
-  BIG_STEP(kt + 2, 0, 1, 0, fa0, fb0, fa1, fb1, sA3, sB3, sA1, sB1)
-  BIG_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, sA0, sB0, sA2, sB2)
-
-#else
   // Register staging: stage S is loaded global -> registers in step S-4 (two register sets, by parity), written to LDS
   // buffer S&1 in step S-2, read as fragments in step S-1 and consumed in step S.  ds_write_b128: lane -> row
   // 16j + (lane>>2), global chunk lane&3 -> slot (lane&3) ^ f(lane>>4); 8 consecutive lanes cover 128 contiguous bytes.
@@ -1021,12 +948,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
     const uint32_t slot = (lane & 3) ^ big_swz(lane >> 4);
 #pragma unroll
     for (int u = 0; u < 4; ++u) wr_off[u] = ((wave + 4 * u) * 16 + (lane >> 2)) * 64 + slot * 16;
-  }
-  // DMA offsets above carry the swizzle on the SOURCE side; register staging reads chunk lane&3 and swizzles the write
-  {
-    const uint32_t unswz = (((lane & 3) ^ big_swz(lane >> 4)) - (lane & 3)) * 16;  // bytes, may wrap: uint32 arithmetic
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { offa[u] -= unswz; offb[u] -= unswz; }
   }
   u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
 #define BIG_GLOAD(RA_, RB_, S)                                                                        \
@@ -1090,7 +1011,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   BIG_STEP(kt + 1, 0, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
   BIG_STEP(kt + 2, 0, 0, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
   BIG_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
-#endif
 
   STAMP(2)
   // epilogue.  Wave tiles that are whole in N and keep the 16-B alignments go through the looped LDS-transpose epilogue
