@@ -93,17 +93,29 @@ class GemmTimer:
         return {"launches": n, "seconds": t, "flop": fl, "avg_us": t / n * 1e6, "tflops": fl / t / 1e12}
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same bench command
-    (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units,
-    FETCH_SIZE doubled on gfx950).  Counters cannot be read from inside the timed process; None if the file is absent."""
+GEMM_KERNELS = ("vlm_gemm_big_kernel", "vlm_gemm_bigT_kernel", "vlm_gemm_kernel")  # one vlm_gemm_bf16 call runs one of them
+GEMM_HELPERS = ("splitk_reduce_kernel",)  # second launch of a wgrad call: its bytes count, its launches do not
+
+
+def pmc_traffic(kernels, helpers=()):
+    """HBM-side bytes per launch of a kernel (or, launch-weighted, of a family of kernels that serve the same call) from the
+    committed rocprofv3 --pmc passes over this same bench command (profiles/r02_pmc_traffic.json, made by
+    tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950).
+    Counters cannot be read from inside the timed process; None if the file is absent."""
+    if isinstance(kernels, str):
+        kernels = (kernels,)
     here = os.path.dirname(os.path.abspath(__file__))
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # the newest committed PMC passes
         try:
             with open(os.path.join(here, "profiles", name)) as f:
-                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+                ks = json.load(f)["kernels"]
         except (OSError, KeyError, ValueError):
             continue
+        found = [ks[k] for k in kernels if k in ks]
+        if not found:
+            continue
+        total = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in found + [ks[h] for h in helpers if h in ks])
+        return total / sum(k["launches"] for k in found)
     return None
 
 
@@ -376,9 +388,12 @@ def main():
         out["model_tflops"] = value * flop_per_sample / 1e12 / world
         if gs:
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("vlm_gemm_kernel"),
-                               "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
-                               "kernel": "vlm_gemm_kernel",
+                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(GEMM_KERNELS, GEMM_HELPERS),
+                               "traffic_unit": "HBM-side bytes per vlm_gemm_bf16 call, launch-weighted over the kernels "
+                                               "that serve it (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
+                               "kernel": "vlm_gemm_bf16: " + " / ".join(GEMM_KERNELS),
+                               "note": "peak = nominal dense bf16; a loop of nothing but independent MFMAs reaches 1515 "
+                                       "TFLOP/s on this chip (clock drops to 1.45 GHz: DESIGN.md 4.1)",
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "timed_steps": len(range(0, args.steps, max(1, args.gemm_timer_every))),
                                "gemm_share_of_step": gs["seconds"] / (dt / args.steps *
