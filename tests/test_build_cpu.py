@@ -1,0 +1,52 @@
+"""The register allocator's verdict on the 256x256 GEMM kernels, recorded by the build (lib/kernel_resources.json).
+
+hipcc 7.2 flips between two allocations of vlm_gemm_big_kernel on edits that do not change a single value (the staging
+offsets written directly instead of "swizzled, then un-swizzled"): in the bad one 40 accumulator registers live in VGPRs
+and are shuffled through a[52:55] inside the K loop -- 1 832 instead of 1 488 cycles per 32-deep step, -11 % on the
+forward / dgrad GEMMs, with every numerics test still green.  This test is the tripwire."""
+import json
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RES = os.path.join(HERE, "..", "vl-merging_amd", "lib", "kernel_resources.json")
+
+
+@pytest.fixture(scope="module")
+def resources():
+    if not os.path.exists(RES):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(HERE, "..", "__graft_entry__.py"))
+        ge = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ge)
+        ge.build()
+    if not os.path.exists(RES):
+        pytest.skip("objects were cached from a build that did not record resources; touch csrc/*.hip and rebuild")
+    with open(RES) as f:
+        return json.load(f)
+
+
+def test_big_gemm_accumulators_stay_in_agprs(resources):
+    big = {k: v for k, v in resources.items() if "vlm_gemm_big_kernel" in k}
+    assert len(big) == 6, sorted(big)
+    for name, r in big.items():
+        assert r["AGPRs"] == 256, (name, r)            # the 4 x 64 accumulator registers of a 128x128 wave tile
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
+        assert r["Occupancy"] == 1 and r["LDS Size"] <= 160 * 1024, (name, r)
+        residual = "ILb1ELb1E" in name                 # <OUT_F32, RES, AUX>: the residual variants hold 36-register input sets
+        assert r["VGPRs"] <= (248 if residual else 232), (name, r)
+
+
+def test_wgrad_kernel_resources(resources):
+    (name, r), = [(k, v) for k, v in resources.items() if "vlm_gemm_bigT_kernel" in k]
+    assert r["AGPRs"] == 256 and r["Occupancy"] == 1, (name, r)
+    assert r["VGPRs Spill"] <= 32, (name, r)           # the tail's epilogue setup spills a few; the K loop does not
+
+
+def test_attention_kernels_keep_their_occupancy(resources):
+    occ = {k: v["Occupancy"] for k, v in resources.items() if "attn_" in k and "kernel" in k}
+    assert occ, "no attention kernels recorded"
+    for name, o in occ.items():
+        if "attn_fwd_kernel" in name or "attn_bwd_dq" in name or "attn_bwd_dkv" in name or "attn_bwd_dbias" in name:
+            assert o >= 2, (name, o)

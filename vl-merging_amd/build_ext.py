@@ -3,7 +3,9 @@
 hipcc cross-compiles without a GPU; objects are cached by mtime under csrc/_build/.
 """
 import concurrent.futures as cf
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -11,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "lib", "libvlm_hip.so")
+RESOURCES = os.path.join(HERE, "lib", "kernel_resources.json")  # per-kernel register / LDS use of the last full compile
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -27,12 +30,26 @@ def _compile(src):
     obj = os.path.join(BUILD, os.path.basename(src) + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime()):
         return obj, False
-    cmd = [HIPCC] + COMMON + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + COMMON + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout[-2000:], r.stderr[:3000]))
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr[-4000:])
+    res, name, rest = {}, None, []
+    for line in r.stderr.splitlines():  # the register allocator's verdict per kernel (tests/test_build_cpu.py watches it)
+        if "-Rpass-analysis=kernel-resource-usage" not in line:
+            rest.append(line)
+            continue
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            res[name] = {}
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and name:
+            res[name][m.group(1).strip()] = int(m.group(2))
+    with open(obj + ".resources.json", "w") as f:
+        json.dump(res, f)
+    if "\n".join(rest).strip():
+        sys.stderr.write("\n".join(rest)[-4000:] + "\n")
     return obj, True
 
 
@@ -52,6 +69,16 @@ def build(verbose=True, jobs=None):
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])
         if verbose:
             print("built", LIB)
+    merged = {}
+    for o in objs:
+        try:
+            with open(o + ".resources.json") as f:
+                merged.update(json.load(f))
+        except OSError:
+            pass
+    if merged:
+        with open(RESOURCES, "w") as f:
+            json.dump(merged, f, indent=0, sort_keys=True)
     return LIB
 
 
