@@ -657,7 +657,10 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 // (tie: 1128 vs 1092 TFLOP/s at 4096x4096x8192, twice the LDS); a PERSISTENT version whose next tile's first stages went
 // out by inline-asm LDS-DMA under the last two K steps with a hand-counted vmcnt in front of their use (tie: 319 vs 321 us
 // at 54296x3072x768 -- vmcnt is one in-order counter, so the next tile's first register-staged loads still wait for
-// the epilogue's stores; with the C stores removed the same kernel takes 270 us: the store drain is what remains).
+// the epilogue's stores; with the C stores removed the same kernel takes 270 us: the store drain is what remains); a
+// 256x128 tile with 128x64 waves and TWO workgroups per CU, so that one's epilogue runs under the other's K loop (same
+// LDS image and looped epilogue, no fragment double buffer: 351 vs 329 us at 54296x3072x768, 335 vs 302 at K = 3072,
+// 949 vs 1262 TFLOP/s at 4096^3 -- 1.5x the staged and fragment bytes per MFMA cost more than the overlap returns).
 // LDS image of an operand stage: [256 rows][32 k] bf16, 64-B rows, 16-B slot s of row r holds chunk s ^ f((r>>2)&3),
 // f = (0,2,3,1): conflict-free for ds_read_b128's lane groups (rows {0-3,12-15} x chunk c with rows {4-11} x chunk c^1).
 // diagnostic timing builds only (tools/scratch/gemm_bench.hip; results are wrong): knock out one part of the K loop
@@ -704,7 +707,7 @@ struct epil_in_t {
 // RES: residual (+ optional row scale) inputs; AUX: 0 none, 1 the pre-activation copy is stored, 2 GELU' argument is loaded.
 // What a variant does not have costs nothing (a zero-length descriptor would still cost the round trip: the dummy loads
 // of an all-in-one version took 14k of its 25k cycles).
-// WCOLS: columns of the wave tile (128, or 64 for the 256x128 kernel): WCOLS/8 lanes cover a row, 512/WCOLS rows per wave
+// WCOLS: columns of the wave tile (128; 64 served the 256x128 experiment): WCOLS/8 lanes cover a row, 512/WCOLS rows per wave
 // instruction, WCOLS*4+16 bytes of LDS row pitch.
 template <bool OUT_F32, bool RES, int AUX, int WCOLS = 128>
 struct big_epilogue_t {
@@ -1042,164 +1045,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
 #endif
 }
 
-// ---- 256x128 tile, TWO workgroups per CU --------------------------------------------------------------------------------
-// 4 waves (2x2) of 128x64: 128 accumulator registers per wave, so two workgroups share a CU and one's epilogue, prologue
-// and store drain run under the other's K loop -- what the one-workgroup 256x256 kernel cannot hide (a third of a
-// K = 768 tile).  The price is 1.5x the staged and fragment bytes per MFMA of the 256x256 tile (still 0.75x the
-// 128x128 kernel's).  With a partner wave on every SIMD the K loop needs no fragment double buffer: step K reads its
-// own fragments (stage K: loaded global -> registers in step K-3, written to LDS buffer K&1 in step K-1), writes stage
-// K+1 into the other buffer, requests stage K+3 and runs its 32 MFMAs; one barrier per step.  Same LDS image and the
-// same looped epilogue as the 256x256 kernel (64-column wave tile: 8 lanes per row, 272-B pitch, one 16-row block in
-// LDS at a time).
-#define BIG2_BN 128
-#define BIG2_PITCH (64 * 4 + 16)
-template <bool OUT_F32, bool RES, int AUX>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_big2_kernel(const gemm_params_t p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sB0[BIG_OP_BYTES / 2], sB1[BIG_OP_BYTES / 2];
-  __shared__ __attribute__((aligned(16))) unsigned char epl[4 * 16 * BIG2_PITCH];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const uint32_t nblk = gridDim.x, bid = blockIdx.x;
-  const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  uint32_t tm, tn;
-  {
-    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;
-    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;
-    tm = first + in % rows;
-    tn = in / rows;
-  }
-  const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG2_BN;
-  const __amdgpu_buffer_rsrc_t ra =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.N * p.ldb * 2), 0x00020000);
-  // staging: piece j = wave + 4u covers rows 16j .. 16j+15 (A: 16 pieces, B: 8); lane -> row 16j + (lane>>2), chunk lane&3
-  uint32_t offa[4], offb[2], wr_off[4];
-  {
-    const uint32_t slot = (lane & 3) ^ big_swz(lane >> 4);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t row = (wave + 4 * u) * 16 + (lane >> 2);
-      offa[u] = ((m0 + row) * (uint32_t)p.lda + (lane & 3) * 8) * 2;
-      if (u < 2) offb[u] = ((n0 + row) * (uint32_t)p.ldb + (lane & 3) * 8) * 2;
-      wr_off[u] = row * 64 + slot * 16;
-    }
-  }
-  const uint32_t rd_slot = ((uint32_t)(lane >> 4) ^ big_swz((lane & 15) >> 2)) * 16 + (lane & 15) * 64;
-  const uint32_t rda = wm * 128 * 64 + rd_slot, rdb = wn * 64 * 64 + rd_slot;
-
-  f32x4 acc00[4][4], acc10[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc00[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc10[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  const int nk = p.K / BIG_BK;  // even, >= 4: launcher
-  const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
-  unsigned char* const wl = epl + wave * (16 * BIG2_PITCH);
-  bf16x8 fa[8], fb[4];
-  u32x4 a0[4], b0[2], a1[4], b1[2];
-#define BIG2_GLOAD(RA_, RB_, S)                                                                       \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                     \
-    RA_[u] = __builtin_amdgcn_raw_buffer_load_b128(ra, offa[u], (S) * (BIG_BK * 2), 0);               \
-    if (u < 2) RB_[u] = __builtin_amdgcn_raw_buffer_load_b128(rb, offb[u], (S) * (BIG_BK * 2), 0);    \
-  }
-#define BIG2_LWRITE(RA_, RB_, SA, SB)                                                                 \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                     \
-    *reinterpret_cast<u32x4*>((SA) + wr_off[u]) = RA_[u];                                             \
-    if (u < 2) *reinterpret_cast<u32x4*>((SB) + wr_off[u]) = RB_[u];                                  \
-  }
-  // step K (stage K in buffer BUF_R): barrier, read its fragments, write stage K+1 (register set RS) into BUF_W, request
-  // stage K+3 into RS, 32 MFMAs.  WR / GL are literals.
-#define BIG2_STEP(K, WR, GL, RSA, RSB, BUFA_R, BUFB_R, BUFA_W, BUFB_W)                                \
-  {                                                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-    __builtin_amdgcn_s_barrier();                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>((BUFA_R) + rda + i * 1024); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>((BUFB_R) + rdb + j * 1024); \
-    if (WR) { BIG2_LWRITE(RSA, RSB, BUFA_W, BUFB_W) }                                                 \
-    if (GL) { BIG2_GLOAD(RSA, RSB, (K) + 3) }                                                         \
-    BIG_MFMA_Q(acc00, fa, fb, 0, 0)                                                                   \
-    BIG_MFMA_Q(acc10, fa, fb, 4, 0)                                                                   \
-    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                               \
-    _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                   \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                              \
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                              \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                              \
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
-    }                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-  }
-  BIG2_GLOAD(a0, b0, 0)
-  BIG2_GLOAD(a1, b1, 1)
-  BIG2_LWRITE(a0, b0, sA0, sB0)
-  BIG2_GLOAD(a0, b0, 2)
-  int kt = 0;
-  for (; kt < nk - 4; kt += 2) {
-    BIG2_STEP(kt + 0, 1, 1, a1, b1, sA0, sB0, sA1, sB1)
-    BIG2_STEP(kt + 1, 1, 1, a0, b0, sA1, sB1, sA0, sB0)
-  }
-  BIG2_STEP(kt + 0, 1, 1, a1, b1, sA0, sB0, sA1, sB1)
-  BIG2_STEP(kt + 1, 1, 0, a0, b0, sA1, sB1, sA0, sB0)
-  // the epilogue's first inputs fly during the last two K steps
-  big_epilogue_t<OUT_F32, RES, AUX, 64> ep(p, wl, mw0, nw0, lane);
-  epil_in_t inA, inB;
-  ep.load_inputs(inA, 0);
-  BIG2_STEP(kt + 2, 1, 0, a1, b1, sA0, sB0, sA1, sB1)
-  BIG2_STEP(kt + 3, 0, 0, a0, b0, sA1, sB1, sA0, sB0)
-  {
-    // column sums: the wave covers 64 columns of its 128-row half alone (workspace slot 2 tm + wm, or atomics)
-    float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm * 2 + wm) * 2) * p.N : nullptr;
-    unsigned char* wr = wl + (lane & 15) * BIG2_PITCH + (lane >> 4) * 16;  // accumulator (i, j) of the block: + 64 j
-#define BIG2_DUMP(A0, II) \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wr + 64 * j) = A0[II][j];
-    ep.load_inputs(inB, 1);
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {  // two 16-row blocks per trip; the counter only picks statically named accumulators
-      switch (q) {
-        case 0: BIG2_DUMP(acc00, 0) break;
-        case 1: BIG2_DUMP(acc00, 2) break;
-        case 2: BIG2_DUMP(acc10, 0) break;
-        default: BIG2_DUMP(acc10, 2) break;
-      }
-      ep.process(inA, 2 * q, 0);
-      ep.load_inputs(inA, q < 3 ? 2 * q + 2 : 7);
-      switch (q) {
-        case 0: BIG2_DUMP(acc00, 1) break;
-        case 1: BIG2_DUMP(acc00, 3) break;
-        case 2: BIG2_DUMP(acc10, 1) break;
-        default: BIG2_DUMP(acc10, 3) break;
-      }
-      ep.process(inB, 2 * q + 1, 0);
-      ep.load_inputs(inB, q < 3 ? 2 * q + 3 : 7);
-    }
-#undef BIG2_DUMP
-    ep.finish(lane, ws_row);
-  }
-}
-
-template <bool OUT_F32, bool RES, int AUX>
-static int launch_gemm_big2(gemm_params_t p, hipStream_t stream) {
-  p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
-  p.tiles_n = (p.N + BIG2_BN - 1) / BIG2_BN;
-  static int group_m = -1;
-  if (group_m < 0) {
-    const char* e = getenv("VLM_GEMM_BIG_GROUP_M");
-    group_m = e ? atoi(e) : 0;
-    if (group_m < 0) group_m = 0;
-  }
-  p.group_m = group_m ? group_m : (p.tiles_n >= 12 ? 4 : 1);
-  hipLaunchKernelGGL((vlm_gemm_big2_kernel<OUT_F32, RES, AUX>), dim3(p.tiles_m * p.tiles_n), dim3(GEMM_THREADS), 0, stream, p);
-  VLM_CHECK_LAUNCH();
-  return VLM_OK;
-}
-
 // ---- 256x256 tile for wgrad: dW[M,N] = A^T B with BOTH operands K-strided (A stored [K][M], B stored [K][N]) ---------
 // Same pipeline as vlm_gemm_big_kernel (register staging, two LDS buffers, 32-deep steps, one barrier per step); the LDS
 // image of an operand stage is [32 k][256 x] bf16 (512-B rows, 32-B chunks XOR-swizzled by (k&3) | ((k>>3)&1)<<2) and a
@@ -1399,24 +1244,19 @@ static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
 }
 
 // The epilogue variants the 256x256 kernel is built for; anything else runs on the 128x128 kernel (return 1: not offered).
-template <bool OUT_F32, bool RES, int AUX>
-static int launch_gemm_big_either(const gemm_params_t& p, bool two, hipStream_t s) {
-  return two ? launch_gemm_big2<OUT_F32, RES, AUX>(p, s) : launch_gemm_big<OUT_F32, RES, AUX>(p, s);
-}
-// two: the 256x128 kernel (two workgroups per CU) instead of the 256x256 one
-static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, bool two, hipStream_t s) {
+static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStream_t s) {
   const vlm_epilogue_t& e = p.epi;
   const bool res = e.residual != nullptr;
   const int aux = e.aux ? (e.act == VLM_ACT_GELU_BWD ? 2 : 1) : 0;
   if (e.row_scale && !res) return 1;
   if (!c_is_f32 && !res) {
-    if (aux == 0) return launch_gemm_big_either<false, false, 0>(p, two, s);
-    if (aux == 1) return launch_gemm_big_either<false, false, 1>(p, two, s);
-    return launch_gemm_big_either<false, false, 2>(p, two, s);
+    if (aux == 0) return launch_gemm_big<false, false, 0>(p, s);
+    if (aux == 1) return launch_gemm_big<false, false, 1>(p, s);
+    return launch_gemm_big<false, false, 2>(p, s);
   }
   if (c_is_f32 && aux != 2) {
-    if (res) return aux ? launch_gemm_big_either<true, true, 1>(p, two, s) : launch_gemm_big_either<true, true, 0>(p, two, s);
-    if (aux == 0) return launch_gemm_big_either<true, false, 0>(p, two, s);
+    if (res) return aux ? launch_gemm_big<true, true, 1>(p, s) : launch_gemm_big<true, true, 0>(p, s);
+    if (aux == 0) return launch_gemm_big<true, false, 0>(p, s);
   }
   return 1;
 }
@@ -1576,12 +1416,7 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     const bool ws_ok = (N % 128) == 0 && p.epi.reserved == 1 && off32 && !epi->accumulate;
     // measured (tools/bench_gemm.py, M = 13 574 and 54 296): ahead of the 128x128 kernel from half a round of tiles up
     if (ws_ok && (gemm_big_mode() >= 2 || 2 * big_tiles >= cus)) {
-      static int two = -1;  // VLM_GEMM_BIG2: 1 = the 256x128 two-workgroup kernel for these calls (experiments)
-      if (two < 0) {
-        const char* e2 = getenv("VLM_GEMM_BIG2");
-        two = e2 ? atoi(e2) : 0;
-      }
-      const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, two != 0, s);
+      const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, s);
       if (rc <= 0) return rc;
     }
   }
