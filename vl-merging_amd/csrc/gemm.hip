@@ -710,9 +710,9 @@ struct epil_in_t {
 // RES: residual (+ optional row scale) inputs; AUX: 0 none, 1 the pre-activation copy is stored, 2 GELU' argument is loaded.
 // What a variant does not have costs nothing (a zero-length descriptor would still cost the round trip: the dummy loads
 // of an all-in-one version took 14k of its 25k cycles).
-// WCOLS: columns of the wave tile (128; 64 served the 256x128 experiment): WCOLS/8 lanes cover a row, 512/WCOLS rows per wave
+// STORE_AUX: cache policy of the C / aux stores.  WCOLS: columns of the wave tile (128; 64 served the 256x128 experiment): WCOLS/8 lanes cover a row, 512/WCOLS rows per wave
 // instruction, WCOLS*4+16 bytes of LDS row pitch.
-template <bool OUT_F32, bool RES, int AUX, int WCOLS = 128>
+template <bool OUT_F32, bool RES, int AUX, int WCOLS = 128, int STORE_AUX = EPIL_STORE_AUX>
 struct big_epilogue_t {
   static constexpr int LPR = WCOLS / 8, RPG = 64 / LPR, T = 16 / RPG, PITCH = WCOLS * 4 + 16;
   const gemm_params_t& p;
@@ -790,7 +790,7 @@ struct big_epilogue_t {
           bf16x8 h;
 #pragma unroll
           for (int r = 0; r < 8; ++r) h[r] = (bf16_t)v[r];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, EPIL_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, STORE_AUX);
         }
         if (e.act == VLM_ACT_GELU) {
 #pragma unroll
@@ -815,14 +815,14 @@ struct big_epilogue_t {
       }
       if (OUT_F32) {
         const uint32_t co = (m * (uint32_t)p.ldc + n) * 4;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), r_c, co, 0, EPIL_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), r_c, co + 16, 0, EPIL_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}), r_c, co, 0, STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){v[4], v[5], v[6], v[7]}), r_c, co + 16, 0, STORE_AUX);
       } else {
         bf16x8 o;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
         if (EPIL_DIAG & 1) asm volatile("" ::"v"(o));
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_c, (m * (uint32_t)p.ldc + n) * 2, 0, EPIL_STORE_AUX);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_c, (m * (uint32_t)p.ldc + n) * 2, 0, STORE_AUX);
       }
     }
   }
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const ge
   pl.ldc = p.N;
   const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
   unsigned char* const wl = epl + wave * EPIL_WAVE_BYTES;
-  big_epilogue_t<true, false, 0> ep(pl, wl, mw0, nw0, lane);
+  big_epilogue_t<true, false, 0, 128, 0> ep(pl, wl, mw0, nw0, lane);  // plain stores: the reduce launch reads the slices right away
   epil_in_t inA, inB;
   ep.load_inputs(inA, 0);
   BIG_EPILOGUE_LOOP()
