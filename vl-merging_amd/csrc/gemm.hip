@@ -660,7 +660,9 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 // the epilogue's stores; with the C stores removed the same kernel takes 270 us: the store drain is what remains); a
 // 256x128 tile with 128x64 waves and TWO workgroups per CU, so that one's epilogue runs under the other's K loop (same
 // LDS image and looped epilogue, no fragment double buffer: 351 vs 329 us at 54296x3072x768, 335 vs 302 at K = 3072,
-// 949 vs 1262 TFLOP/s at 4096^3 -- 1.5x the staged and fragment bytes per MFMA cost more than the overlap returns).
+// 949 vs 1262 TFLOP/s at 4096^3 -- 1.5x the staged and fragment bytes per MFMA cost more than the overlap returns); all four
+// prologue stages requested at once through two more register sets (one round trip instead of two: the allocator then
+// keeps accumulators in VGPRs, 1675 vs 1345 cycles per step).
 // LDS image of an operand stage: [256 rows][32 k] bf16, 64-B rows, 16-B slot s of row r holds chunk s ^ f((r>>2)&3),
 // f = (0,2,3,1): conflict-free for ds_read_b128's lane groups (rows {0-3,12-15} x chunk c with rows {4-11} x chunk c^1).
 // diagnostic timing builds only (tools/scratch/gemm_bench.hip; results are wrong): knock out one part of the K loop
