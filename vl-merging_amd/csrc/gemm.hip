@@ -692,6 +692,13 @@ __device__ __forceinline__ uint32_t big_swz(uint32_t q) { return (0x78u >> (2 * 
 #ifndef EPIL_STORE_AUX
 #define EPIL_STORE_AUX 2  // cache policy of the epilogue's C / aux stores: 2 = nt (54296x3072x768 plain 331 -> 299 us, GELU 421 -> 394; in situ +0.9 %: the consumer then reads more from HBM); 0 plain, 16 sc1 (no gain)
 #endif
+#ifndef EPIL_AUX_STORE_AUX
+#define EPIL_AUX_STORE_AUX 2  // the saved pre-activation / branch copy is not read again before the backward pass: nt
+#endif
+#ifndef EPIL_LOAD_AUX
+#define EPIL_LOAD_AUX 2  // cache policy of the GELU' argument's loads (the pre-activation saved by the forward pass, read once): 2 = nt
+                         // (54296x3072x768: 419 -> 403 us).  The residual loads stay plain: nt there cost 3-40 % (in-place stream)
+#endif
 #ifndef EPIL_DIAG
 #define EPIL_DIAG 0  // diagnostic timing builds (wrong results): 1 no C stores, 2 no input loads, 4 no aux stores, 8 no finish wait
 #endif
@@ -766,7 +773,7 @@ struct big_epilogue_t {
         in.rsd[t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, ro, 0, 0));
         in.rsd[t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, ro + 16, 0, 0));
       }
-      if (AUX == 2) in.hx[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, 0));
+      if (AUX == 2) in.hx[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, EPIL_LOAD_AUX));
     }
   }
 
@@ -792,7 +799,7 @@ struct big_epilogue_t {
           bf16x8 h;
 #pragma unroll
           for (int r = 0; r < 8; ++r) h[r] = (bf16_t)v[r];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, EPIL_AUX_STORE_AUX);
         }
         if (e.act == VLM_ACT_GELU) {
 #pragma unroll
