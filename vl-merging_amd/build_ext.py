@@ -34,11 +34,13 @@ def _compile(src):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout[-2000:], r.stderr[:3000]))
-    res, name, rest = {}, None, []
+    res, name, rest, rest_skip = {}, None, [], False
     for line in r.stderr.splitlines():  # the register allocator's verdict per kernel (tests/test_build_cpu.py watches it)
         if "-Rpass-analysis=kernel-resource-usage" not in line:
-            rest.append(line)
+            if not (rest_skip and re.match(r"^\s*(\d+\s*)?\|", line)):  # the source excerpt under a remark
+                rest.append(line)
             continue
+        rest_skip = True
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
