@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- VL samples/sec (fwd+bwd+optimizer) of the VLMo hot path on MI355X, plus the merge kernel's GB/s.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: this process starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
@@ -275,6 +275,74 @@ def cpu_baseline():
     return res
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (reference: `run.py:263-288`, `gpus=N, accelerator="ddp"` makes
+    Lightning start one process per GPU): this parent starts N fresh rank processes BEFORE anything here touches the
+    GPU, stays off the GPU itself, relays rank 0's JSON line as its own last line and fails if any rank fails."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):  # a rank that dies leaves its peers waiting in a collective: end them (our own PIDs)
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c for c in codes if c is not None):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=30)
+    out0 = buf[0] if buf else ""
+    lines = [ln for ln in out0.splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        sys.stderr.write(ln + "\n")
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %r\n" % (codes,))
+        if lines:
+            sys.stderr.write(lines[-1] + "\n")
+        sys.exit(next(c for c in codes if c) or 1)
+    line = lines[-1] if lines else ""
+    got = json.loads(line)  # rank 0 must have produced the JSON line
+    assert got["n_gpus"] == n, "rank 0 reported n_gpus=%r for --gpus %d" % (got.get("n_gpus"), n)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+
+
+def dry_run(args, rank, world):
+    """VLM_BENCH_DRY_RUN=1: rendezvous + one MAX all-reduce over gloo on the CPU, no model, no GPU (launcher test)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t) == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher + rendezvous only)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,9 +360,17 @@ def main():
     ap.add_argument("--no-calibrate", action="store_true", help="skip the attainable-peak probes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (the number is whole-job: they must agree)" % (args.gpus, world))
+    if os.environ.get("VLM_BENCH_DRY_RUN", "0") != "0":
+        if os.environ.get("VLM_BENCH_TEST_FAIL_RANK") == str(rank):  # launcher test: a rank that dies before rendezvous
+            sys.exit(3)
+        return dry_run(args, rank, world)
     if rank != 0:  # RCCL prints a version banner on stdout in every process: only rank 0 may write there
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     # VLM_BENCH_ONE_DEVICE=1 + VLM_DIST_BACKEND=gloo: several ranks on ONE GPU (a functional test of the multi-rank

@@ -29,3 +29,39 @@ def test_bench_json_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
     m = d["merge"]
     assert m["roofline"]["bound"] == "hbm" and m["algorithmic_bytes"] == 1077239808 and 0.3 < m["roofline"]["frac"] < 1.0
+
+
+def _run_bench(argv, env=None, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    return r
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-calibrate", "--no-merge", "--batch", "2",
+         "--image-size", "224"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_launches_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must start two rank processes itself (reference:
+    run.py:263-288, Lightning spawns one process per GPU).  The test box has one GPU: both ranks share it and talk gloo."""
+    env = {"VLM_BENCH_ONE_DEVICE": "1", "VLM_DIST_BACKEND": "gloo"}
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT, env=dict(env_clean, **env))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 4 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"] + 1e-3
+    assert "exposed_comm_ms_per_step" in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_bench_rccl_branch_at_world_one(sharded):
+    """VLM_BENCH_FORCE_DIST=1: the nccl (= RCCL) process group, the reducer's collectives (all-reduce, and with
+    VLM_SHARDED=1 reduce_scatter_tensor / all_gather_into_tensor) and the barrier-fenced timing run on the one device."""
+    r = _run_bench(SMALL, {"VLM_BENCH_FORCE_DIST": "1", "VLM_SHARDED": sharded})
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
