@@ -547,6 +547,52 @@ def gold_irtr_merged_base():
     np.savez_compressed(os.path.join(HERE, "irtr_merged_base.npz"), **out)
 
 
+GRAM_BASE_PICKS = ("transformer.blocks.0.attn.v", "transformer.blocks.0.attn.l.proj", "transformer.blocks.0.mlp.v.fc1",
+                   "transformer.blocks.0.mlp.l.fc2", "transformer.blocks.11.attn.l", "transformer.blocks.11.attn.v.proj",
+                   "transformer.blocks.11.mlp.l.fc1", "transformer.blocks.11.mlp.v.fc2")
+
+
+def gold_gram_base():
+    """configs[3]'s capture leg at BASE width (hidden 768, F 3072, 384^2): the reference's gram hook
+    (src/cache_gram_matrices.py:246-281; a closure inside its main(), so the same module selection and arithmetic are
+    re-registered here) on the all_moe irtr model, one eval forward over B = 3.  Kept: key list, (shape, norm, sum) of all
+    96 matrices, the leading 256 x 256 block of a v / l attn, proj, fc1, fc2 Gram at layers 0 and 11 (float32)."""
+    _dist_once()
+    vm, vit, obj = import_reference()
+    from collections import defaultdict
+    from vilt.modules import vilt_utils
+    cfg = base_config(loss_names={"irtr": 1}, **BASE)
+    model, _ = build_reference_model(cfg, "all_moe")
+    load_det_weights(model)  # same deterministic weights as keys_base_irtr_all_moe.json
+    model.eval()
+    grams = defaultdict(float)
+    all_keys = ["mlp.fc1", "mlp.fc1", "mlp.v.fc1", "mlp.l.fc1", "mlp.vl.fc1", "mlp.v.fc2", "mlp.l.fc2", "mlp.vl.fc2", "attn",
+                "attn.v", "attn.l", "attn.vl", "attn.proj", "attn.v.proj", "attn.l.proj", "attn.vl.proj"]
+
+    def hook_gram_input(module, input, output):
+        if isinstance(input, tuple):
+            input = input[0]
+        fl = input.reshape(-1, input.shape[-1]).to(torch.float64)
+        grams[module.module_name] += torch.matmul(fl.T, fl).detach().cpu()
+
+    for name, module in model.named_modules():
+        if any(name.endswith(n) for n in all_keys) and ".bias" not in name:
+            module.module_name = name
+            module.register_forward_hook(hook_gram_input)
+    vilt_utils.set_task(model)
+    batch = to_batch(det_batch(3, 384, 40, 1024, seed=99))
+    with torch.no_grad():
+        model(batch)
+    gk = sorted(grams.keys())
+    out = {"gram_keys": np.array(json.dumps(gk)),
+           "gram_summary": np.array(json.dumps({k: [list(grams[k].shape), float(grams[k].norm()), float(grams[k].sum())]
+                                                for k in gk}))}
+    for k in GRAM_BASE_PICKS:
+        out["gram/" + k] = grams[k].numpy()[:256, :256].astype(np.float32)
+    print("gram base:", len(gk), "matrices;", {k: list(grams[k].shape) for k in GRAM_BASE_PICKS[2:4]})
+    np.savez_compressed(os.path.join(HERE, "gram_base.npz"), **out)
+
+
 def gold_train_tiny():
     """TRAIN mode (DropPath + text-embedding dropout live) with injected masks (ref_harness.inject_train_masks):
     one training_step of the reference at tiny width, B = 2."""
@@ -820,4 +866,4 @@ if __name__ == "__main__":
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
          "irtr": gold_irtr, "model_base": gold_model_base, "irtr_merged_base": gold_irtr_merged_base,
          "train_tiny": gold_train_tiny, "regmean_base": gold_regmean_base, "vlmo_resize": gold_vlmo_resize, "schedule": gold_schedule,
-         "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()
+         "gram_base": gold_gram_base, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()

@@ -1,0 +1,49 @@
+"""the Gram cache under data parallelism.  `cache_gram_matrices.py` run by TWO ranks (batches dealt
+round-robin, float64 accumulators all-reduced, rank 0 saves) must write the same file as ONE process over the same
+batches.  Reference: cache_gram_matrices.py:246-254 (hook: G += X^T X in float64), :339-349 (validate, torch.save).
+Both ranks share the one GPU of the test box and talk gloo (VLM_BENCH_ONE_DEVICE=1, VLM_DIST_BACKEND=gloo)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "vl-merging_amd", "cache_gram_matrices.py")
+ARGS = ["with", "task_finetune_irtr_coco_square_randaug_base_image384", "all_moe", "vit=vit_tiny_patch16_224",
+        "hidden_size=192", "num_heads=3", "image_size=224", "vocab_size=1024", "per_gpu_batchsize=2"]
+
+
+def run(world, log_dir, name, batches):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VLM_BENCH_ONE_DEVICE="1", VLM_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, SCRIPT] + ARGS + ["batches=%d" % batches, "log_dir=" + log_dir,
+                                       "representation_name=" + name], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, cwd=ROOT))
+    outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return torch.load(os.path.join(log_dir, name + ".pth"), weights_only=True)
+
+
+@pytest.mark.parametrize("world,batches", [(2, 4), (2, 1)])
+def test_two_rank_gram_cache_equals_one_process(tmp_path, world, batches):
+    """(2, 1): the second rank is dealt no batch at all -- the key set must still be agreed on before the all-reduce."""
+    one = run(1, str(tmp_path), "one", batches)
+    two = run(world, str(tmp_path), "two", batches)
+    assert sorted(one) == sorted(two) and len(one) == 96  # 12 layers x {v, l} x {attn, proj, fc1, fc2}
+    for k, a in one.items():
+        b = two[k]
+        assert a.dtype == torch.float64 and b.dtype == torch.float64 and a.shape == b.shape
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 1e-12 * scale, k

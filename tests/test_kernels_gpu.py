@@ -402,7 +402,8 @@ def big_tile(L):
     L.check(lib.vlm_gemm_set_big_tile_mode(-1), "vlm_gemm_set_big_tile_mode")
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 5 + 77, 768, 768), (13574, 2304, 768), (256 * 3 + 130, 256, 128), (1000, 3072, 3072)])
+@pytest.mark.parametrize("M,N,K", [(256 * 5 + 77, 768, 768), (13574, 2304, 768), (256 * 3 + 130, 256, 128), (1000, 3072, 3072),
+                                   (256 * 2 + 9, 384, 256), (700, 1152, 128)])  # N % 256 == 128: must not reach the 256x256 kernel
 def test_gemm_big_tile_every_epilogue_variant(ops, L, big_tile, M, N, K):
     """The 256x256 kernel's looped epilogue (LDS transpose, buffer loads/stores, rows >= M falling off the descriptors)
     in every variant the launcher offers, against fp32 matmul of the bf16 operands AND against the 128x128 kernel."""
@@ -480,7 +481,8 @@ def test_gemm_big_tile_col_sum_workspace(ops, L, big_tile):
     assert_close(out, hh.grad, 1e-2, 2e-2, "256-tile gelu_bwd")
 
 
-@pytest.mark.parametrize("M,N,K", [(3072, 768, 13574), (768, 3072, 5000), (768, 768, 2048 + 8), (2304, 768, 54296), (1000, 256, 4100)])
+@pytest.mark.parametrize("M,N,K", [(3072, 768, 13574), (768, 3072, 5000), (768, 768, 2048 + 8), (2304, 768, 54296), (1000, 256, 4100),
+                                   (512, 384, 4096), (304, 1152, 2560)])  # N % 256 == 128: the 128x128 split-K path
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_gemm_big_tile_wgrad(ops, L, big_tile, M, N, K, accumulate):
     """dW = A^T B with both operands K-strided through the 256x256 kernel: K slices (ragged K: 13574 = 424*32 + 6) stored
@@ -506,4 +508,5 @@ def test_gemm_big_tile_wgrad(ops, L, big_tile, M, N, K, accumulate):
     c2 = torch.full((M + 2, N), 3.0, device="cuda")
     c2[:M] = base
     ops.gemm(A, B, c2[:M], ta=True, tb=True, alpha=0.01, accumulate=accumulate)
-    assert torch.equal(c2, got[2])
+    if N % 256 == 0:  # N % 256 == 128 stays on the atomic split-K kernel, which is not required to be deterministic
+        assert torch.equal(c2, got[2])

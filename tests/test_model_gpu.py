@@ -577,6 +577,39 @@ def test_full_size_step_properties(mods, golden_dir, arch, B, losses):
     assert len(moved) >= 0.95 * len(used)
 
 
+def test_zero_gradient_is_not_no_gradient(mods, golden_dir):
+    """HF AdamW skips a parameter only when `p.grad is None` (vilt_utils.py:314-317).  A DropPath draw that drops every
+    sample's branch gives the branch's tensors an EXACT-ZERO gradient, which the reference still treats as a gradient:
+    Adam's update is 0 but the decoupled weight decay applies.  Here: every DropPath site with p > 0 drops the whole
+    batch in step 1 -- the optimizer's inactive set must be the structural one (what no pass reaches) and a dropped
+    block's decayed weights must have moved by exactly the decay."""
+    model = build(mods, "all_moe", "tiny_all_moe", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1}, train=True)
+    model.droppath_uniform_source = lambda pc, S, streams: torch.ones(streams, S, pc.seq.B)  # u >= keep: dropped
+    model.hparams.config["warmup_steps"] = 0
+    (opt,), (sch,) = mods[1].vilt_utils.set_schedule(model, max_steps=100)
+    batch = gpu_batch(det_batch(4, 224, 40, 1024, seed=5))
+    named = dict(model.named_parameters())
+    w = named["transformer.blocks.5.mlp.v.fc1.weight"]
+    b = named["transformer.blocks.5.mlp.v.fc1.bias"]
+    w0, b0 = w.detach().clone(), b.detach().clone()
+    loss = model.training_step({"vl": batch})
+    loss.backward()
+    torch.cuda.synchronize()
+    assert float(w.grad.abs().max()) == 0.0, "the injected draw must zero block 5's gradients"
+    assert float(named["transformer.blocks.0.mlp.v.fc1.weight"].grad.abs().max()) > 0  # block 0: DropPath p = 0
+    opt.step()
+    torch.cuda.synchronize()
+    inactive = set(opt.inactive_parameters())
+    assert "transformer.mask_token" in inactive and "text_embeddings.position_embeddings.weight" in inactive
+    assert not [n for n in inactive if n.startswith("transformer.blocks.")], sorted(inactive)
+    g = [g for g in opt.param_groups if any(lo <= model._flat.offsets["transformer.blocks.5.mlp.v.fc1.weight"][0] < hi
+                                            for lo, hi in g["ranges"])]
+    assert len(g) == 1 and g[0]["weight_decay"] > 0
+    want = w0 - g[0]["lr"] * g[0]["weight_decay"] * w0   # Adam update 0 / (0 + eps) = 0, then p -= lr * wd * p
+    assert torch.allclose(w.detach(), want, rtol=0, atol=1e-9) and not torch.equal(w.detach(), w0)
+    assert torch.equal(b.detach(), b0)                   # bias: no decay group, zero update
+
+
 @pytest.mark.parametrize("arch", ["ufo", "all_moe"])
 def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
     """TRAIN mode (DropPath + text-embedding dropout live) against the REFERENCE's train-mode step on the same injected

@@ -22,10 +22,11 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 
-def arrow_batches(cfg, B, dev):
+def arrow_batches(cfg, B, dev, rank=0, world=1, limit=None):
     """Validation batches of the retrieval task from Arrow shards under cfg["data_root"] (the reference drives its hooks
     with trainer.validate over the same shards, cache_gram_matrices.py:339): ArrowDataset + its collate, a
-    non-masking collator (evaluation reads the plain ids)."""
+    non-masking collator (evaluation reads the plain ids).  EVERY sample is hooked, as under trainer.validate: the last
+    batch may be ragged.  Batch j belongs to rank j % world; a rank decodes and collates only its own batches."""
     ds = importlib.import_module("vl_merging_amd.vilt.datasets")
     names = sorted(f[:-6] for f in os.listdir(cfg["data_root"]) if f.endswith(".arrow"))
     vocab = os.path.join(cfg["data_root"], "vocab.txt")
@@ -44,8 +45,13 @@ def arrow_batches(cfg, B, dev):
             ids[r, : len(e["input_ids"])] = torch.tensor(e["input_ids"])
         return {"input_ids": ids.clone(), "labels": torch.full_like(ids, -100)}
 
-    for lo in range(0, len(data) - B + 1, B):
-        b = data.collate([data[i] for i in range(lo, lo + B)], no_mask)
+    starts = list(range(0, len(data), B))
+    if limit is not None:
+        starts = starts[:limit]
+    for j, lo in enumerate(starts):
+        if j % world != rank:
+            continue
+        b = data.collate([data[i] for i in range(lo, min(lo + B, len(data)))], no_mask)
         yield {"image": [b["image"][0].to(dev)], "text_ids": b["text_ids"].to(dev), "text_masks": b["text_masks"].to(dev),
                "text_labels": b["text_labels"].to(dev), "text_ids_mlm": b["text_ids_mlm"].to(dev),
                "text_labels_mlm": b["text_labels_mlm"].to(dev)}
@@ -58,7 +64,7 @@ def main(argv):
     vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
     vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
     from bench import synthetic_batch
-    batches = 4
+    batches = None  # batches=N: stop after N batches (all ranks together); default: 4 synthetic batches / every Arrow sample
     rest = []
     for a in argv:
         if a.startswith("batches="):
@@ -80,18 +86,15 @@ def main(argv):
     cap = model.start_gram_capture()
     B = cfg["per_gpu_batchsize"] or 2
     if cfg["data_root"]:
-        source = arrow_batches(cfg, B, "cuda")
-    else:
+        source = arrow_batches(cfg, B, "cuda", rank, world, batches)
+    else:  # DistributedSampler-style round robin over the batches: batch i is built and hooked by rank i % world only
         source = (synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 4321 + i, "cuda")["vl"]
-                  for i in range(batches))
+                  for i in range(4 if batches is None else batches) if i % world == rank)
     n_seen = 0
     with torch.no_grad():
-        for i, batch in enumerate(source):
-            if i >= batches and not cfg["data_root"]:
-                break
-            if i % world == rank:  # DistributedSampler-style round robin over the batches
-                model(batch)
-                n_seen += 1
+        for batch in source:
+            model(batch)
+            n_seen += 1
     model.stop_gram_capture()
     cap.all_reduce()
     grams = cap.state_dict()

@@ -1206,7 +1206,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // wgrad through the 256x256 kernel: 1 = not offered (no / too small workspace, shape), else the launch's return code
 static int launch_gemm_bigT(gemm_params_t p, const vlm_epilogue_t* epi, hipStream_t stream) {
-  if (!epi->splitk_ws || (p.N % 128) || (p.N % 4) || (p.ldc % 4)) return 1;
+  // whole 256-column tiles only: the looped epilogue has no column bound (a 128-column tail's second wave would store into
+  // the next row of the [M][N] slice and read operand columns that belong to the next k-row)
+  if (!epi->splitk_ws || (p.N % BIG_BN) || (p.ldc % 4)) return 1;
   if ((uint64_t)p.M * p.N * 4 >= (1ull << 31)) return 1;
   p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
   p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
@@ -1422,10 +1424,10 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     const long big_tiles = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BIG_BN - 1) / BIG_BN);
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;
-    // the kernel has only the looped 128-column epilogue: whole wave tiles in N, 16-B epilogue vectors
+    // the kernel has only the looped epilogue without a column bound: whole 256-column tiles in N, 16-B epilogue vectors
     const bool off32 = (uint64_t)M * ldc * 4 < (1ull << 31) && (!epi->residual || (uint64_t)M * epi->ld_res * 4 < (1ull << 31)) &&
                        (!epi->aux || (uint64_t)M * epi->ld_aux * 2 < (1ull << 31));  // the epilogue's buffer descriptors
-    const bool ws_ok = (N % 128) == 0 && p.epi.reserved == 1 && off32 && !epi->accumulate;
+    const bool ws_ok = (N % BIG_BN) == 0 && p.epi.reserved == 1 && off32 && !epi->accumulate;  // no column bound in the epilogue
     // measured (tools/bench_gemm.py, M = 13 574 and 54 296): ahead of the 128x128 kernel from half a round of tiles up
     if (ws_ok && (gemm_big_mode() >= 2 || 2 * big_tiles >= cus)) {
       const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, s);

@@ -6,8 +6,8 @@ slice is final once every pass that used the block has run its backward (weights
 step); the fused block function reports each backward through `on_block_backward`, and the slice's all-reduce is
 launched on a side stream as soon as the count is complete, overlapping the remaining backward.  Parameters that get
 no gradient in a step (position_embeddings, mask_token, ...) stay zero in the flat buffer: the
-reducer needs no unused-parameter discovery (the optimizer does its own, once: FusedAdamW._discover_active skips tensors
-that never received a gradient, as HF AdamW skips p.grad is None).  The 1/world average is folded into the fused AdamW kernel (grad_scale).
+reducer needs no unused-parameter discovery (the optimizer keeps the structural set of parameters a backward pass has
+written, engine.FlatParams.touched, and skips the rest as HF AdamW skips p.grad is None).  The 1/world average is folded into the fused AdamW kernel (grad_scale).
 """
 import re
 

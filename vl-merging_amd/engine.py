@@ -24,6 +24,23 @@ BF16, F32 = torch.bfloat16, torch.float32
 ALIGN = 64  # elements: keeps every parameter 256-B aligned in the fp32 and 128-B in the bf16 buffer
 
 
+def _touch_hook(p):
+    p._vlm_flat.touched.add(p._vlm_name)
+
+
+def touch(*params):
+    """Record that the running backward pass writes a gradient for these parameters (straight into the flat buffer)."""
+    for p in params:
+        if p is not None:
+            f = getattr(p, "_vlm_flat", None)
+            if f is not None:
+                f.touched.add(p._vlm_name)
+
+
+def _touch_expert(e):
+    touch(e.n1w, e.n1b, e.qkvw, e.qb, e.vb, e.projw, e.projb, e.n2w, e.n2b, e.fc1w, e.fc1b, e.fc2w, e.fc2b)
+
+
 class FlatParams:
     """Flat fp32 master / grad / bf16-shadow storage for a module's parameters."""
 
@@ -50,6 +67,12 @@ class FlatParams:
             self.extent[n] = ext
             off += ext
         self.numel = off
+        # names of the parameters a backward pass has written a gradient for so far: what torch calls `p.grad is not None`
+        # (HF AdamW's `if p.grad is None: continue`, vilt_utils.py:314-317).  Kept structurally -- the engine's backward
+        # functions call touch() on what they write, autograd-managed parameters report through a post-accumulate hook --
+        # never by looking at gradient VALUES: a DropPath draw that drops a branch for the whole batch gives an exact-zero
+        # gradient that the reference still treats as a gradient (weight decay applies)
+        self.touched = set()
         dev = self.params[0].device
         pad = 64 * 4096  # tail slack: K-strided GEMM operands may be addressed a few rows past a ragged weight
         self.flat_p = torch.zeros(off + pad, device=dev, dtype=F32)
@@ -61,6 +84,8 @@ class FlatParams:
             p.data = self.flat_p[o:o + k].view_as(p)
             p.grad = self.flat_g[o:o + k].view_as(p)
             p._vlm_name = n
+            p._vlm_flat = self
+            p.register_post_accumulate_grad_hook(_touch_hook)
             p._vlm_bf16 = self.flat_b[o:o + k].view_as(p) if self.flat_b is not None else None
             span = getattr(p, "_vlm_qkv_bias_span", 0)
             p._vlm_qkv_bias = self.flat_p[o:o + span] if span else None
@@ -340,6 +365,15 @@ class GramCapture:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return self
+        # a rank that was dealt no batch (more ranks than batches) has hooked nothing: agree on the key set first
+        mine = {k: int(v.shape[0]) for k, v in self.grams.items()}
+        every = [None] * dist.get_world_size(group)
+        dist.all_gather_object(every, mine, group=group)
+        dev = next(iter(self.grams.values())).device if self.grams else torch.device("cuda", torch.cuda.current_device())
+        for d in every:
+            for k, D in d.items():
+                if k not in self.grams:
+                    self.grams[k] = torch.zeros(D, D, device=dev, dtype=torch.float64)
         for k in sorted(self.grams):
             dist.all_reduce(self.grams[k], group=group)
         return self
@@ -475,6 +509,9 @@ class _BlockFn(torch.autograd.Function):
         Fdim = h.shape[1]
         dx2 = dx2.contiguous()
         g1, g2 = plan.gamma1, plan.gamma2
+        touch(g1, g2)
+        for _, _, e in plan.ranges:
+            _touch_expert(e)
         dy2 = torch.empty(M, D, device=dev, dtype=BF16)
         dy1 = torch.empty(M, D, device=dev, dtype=BF16)
         dh = torch.empty(M, Fdim, device=dev, dtype=BF16)
@@ -584,6 +621,7 @@ class _LinearFn(torch.autograd.Function):
                 act = torch.nn.functional.gelu(hh)
             gy2 = torch.autograd.grad(act, hh, gy2.float())[0]
         dy[:, :N].copy_(gy2)
+        touch(weight if weight.requires_grad else None, bias if bias is not None and bias.requires_grad else None)
         if bias is not None and bias.requires_grad:
             if N % 8 == 0:
                 ops.colsum(dy[:, :N], bias.grad)
@@ -632,6 +670,7 @@ class _LayerNormFn(torch.autograd.Function):
         if g2.dtype not in (BF16, F32):
             g2 = g2.float()
         dx = torch.empty(M, D, device=x2.device, dtype=F32)
+        touch(ctx.weight if ctx.weight.requires_grad else None, ctx.bias if ctx.bias.requires_grad else None)
         ops.layernorm_bwd(g2, x2, st, ctx.weight, dx, dgamma=ctx.weight.grad if ctx.weight.requires_grad else None,
                           dbeta=ctx.bias.grad if ctx.bias.requires_grad else None)
         return dx.view(ctx.shape).to(ctx.in_dtype), None, None, None, None
@@ -671,6 +710,7 @@ class _PatchEmbedFn(torch.autograd.Function):
         # excluded because the reference's conv never produced that row
         gv = g16.view(ctx.B, ctx.rows, Dm)
         gv[:, 0].zero_()
+        touch(weight if weight.requires_grad else None, bias if bias is not None and bias.requires_grad else None)
         if weight.requires_grad:
             ops.gemm(g16, cols, weight.grad.view(Dm, -1), ta=True, tb=True, accumulate=True)
         if bias is not None and bias.requires_grad:

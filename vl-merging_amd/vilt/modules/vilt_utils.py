@@ -82,12 +82,13 @@ class FusedAdamW:
         self._after_step = None   # sharded mode: all-gather of the updated parameters
         self.grad_scale = 1.0
         self.tail_sync = None
-        # HF AdamW skips parameters whose .grad is None (`if p.grad is None: continue`): tensors no pass of the current
-        # task set touches (deep v / l experts under VQA, vl experts under irtr, mask_token, position_embeddings ...)
-        # get neither an Adam update nor weight decay and stay bit-constant.  Here every gradient lives in the flat
-        # buffer, so "has a gradient" is discovered once per task set from the first step's (all-reduced) gradients:
-        # a tensor whose slice is entirely zero after backward was not reached.  Once reached a tensor stays active
-        # (torch keeps a zeroed .grad after zero_grad()).
+        # HF AdamW skips parameters whose .grad is None (`if p.grad is None: continue`): tensors no pass of the task set
+        # touches (deep v / l experts under VQA, vl experts under irtr, mask_token, position_embeddings ...) get neither
+        # an Adam update nor weight decay and stay bit-constant.  "Has a gradient" is STRUCTURAL here, as in torch: the
+        # set of parameters some backward pass has written so far (engine.FlatParams.touched), never a test of gradient
+        # values -- a tensor whose gradient is exactly zero (DropPath dropped its branch for the whole batch) is still
+        # updated (weight decay) like the reference's zero-but-not-None .grad.  Once reached a tensor stays active
+        # (torch keeps a zeroed .grad after zero_grad()).  Rank-independent: every rank runs the same passes.
         self._group_of = {}
         for gi, g in enumerate(groups):
             for lo, hi in g["ranges"]:
@@ -97,7 +98,6 @@ class FusedAdamW:
                         self._group_of[n] = gi
         self._all_ranges = [list(g["ranges"]) for g in groups]
         self._active = set()
-        self._active_key = None
 
     def set_shard(self, ranges, after_step):
         """ddp_sharded (reference run.py:231-232): this rank updates only `ranges` (its chunk of every gradient bucket,
@@ -119,13 +119,9 @@ class FusedAdamW:
         return self.m.numel()
 
     def _discover_active(self):
-        """Re-derive each group's ranges from the parameters that have received a gradient so far."""
+        """Re-derive each group's ranges from the parameters a backward pass has written so far (no device work)."""
         f = self.flat
-        # one small reduction per parameter, queued back to back, ONE host read at the end (runs once per task set;
-        # a scatter-amax over the 140 M-element buffer took seconds)
-        flags = torch.stack([f.flat_g[f.offsets[n][0]: f.offsets[n][0] + f.offsets[n][1]].abs().max() for n in f.names])
-        hit = (flags > 0).cpu().tolist()
-        self._active |= {n for n, h in zip(f.names, hit) if h}
+        self._active |= f.touched
         per_group = [[] for _ in self.param_groups]
         for n in f.names:
             if n in self._active and n in self._group_of:
@@ -144,12 +140,8 @@ class FusedAdamW:
         self.step_count += 1
         engine.sync_wgrad()
         f = self.flat
-        key = tuple(getattr(self.model, "current_tasks", ()))
-        if key != self._active_key:
-            if self.tail_sync is not None:
-                self.tail_sync[2]()      # discovery reads the whole gradient buffer: every all-reduce must have landed
+        if not f.touched <= self._active:  # a pass reached parameters no earlier step had (first step, new task set)
             self._discover_active()
-            self._active_key = key
 
         def update_one(g, lo, hi, so):
             ops.adamw_step(f.flat_p[lo:hi], f.flat_g[lo:hi], self.m[so:so + hi - lo], self.v[so:so + hi - lo],
