@@ -31,8 +31,8 @@ def run(world, log_dir, name, batches):
                                        "representation_name=" + name], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, cwd=ROOT))
     outs = [p.communicate(timeout=900)[0].decode(errors="replace") for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
+    assert all(p.returncode == 0 for p in procs), "\n".join("---- rank %d (rc %s)\n%s" % (r, p.returncode, o[-2500:])
+                                                             for r, (p, o) in enumerate(zip(procs, outs)))
     return torch.load(os.path.join(log_dir, name + ".pth"), weights_only=True)
 
 

@@ -55,6 +55,46 @@ def test_gram_capture_matches_reference(mods, golden_dir):
     assert torch.allclose(cap2.grams[k0].cpu(), 2 * grams[k0], rtol=1e-6, atol=1e-9)
 
 
+def test_gram_capture_base_width_matches_reference(mods, golden_dir):
+    """configs[3]'s capture leg at the BASE geometry (hidden 768, F 3072, 384^2, N = 617, all_moe irtr model) through
+    engine.GramCapture, against the reference's own hook on the same deterministic weights and batch
+    (tests/golden/gram_base.npz, make_golden.py gram_base; reference cache_gram_matrices.py:246-281).
+    Tolerance 1e-2 relative Frobenius per matrix, stated next to what reduced precision does to a Gram: the products and
+    sums are float64 here as in the reference; the INPUTS are the engine's activations (bf16 GEMM operands: 8-bit
+    mantissa, rel. rounding 2^-9 = 2e-3 per element, compounding over up to 12 layers; the reference's fp16-AMP features
+    deviate 1.7e-3 of the scale at this width, amp_reference_errors.json).  Measured values go to parity_errors.json."""
+    from test_model_gpu import build_base, MEASURED
+    gold = np.load(os.path.join(golden_dir, "gram_base.npz"))
+    model = build_base(mods, "all_moe", golden_dir, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0}, tag="base_irtr_all_moe", max_vl=None)
+    batch = gpu_batch(det_batch(3, 384, 40, 1024, seed=99))
+    mods[1].vilt_utils.set_task(model)
+    cap = model.start_gram_capture()
+    with torch.no_grad():
+        model(batch)
+    model.stop_gram_capture()
+    grams = cap.state_dict()
+    assert sorted(grams) == json.loads(str(gold["gram_keys"])) and len(grams) == 96
+    summ = json.loads(str(gold["gram_summary"]))
+    worst_norm, worst_block = 0.0, 0.0
+    for k, (shape, nrm, sm) in summ.items():
+        g = grams[k]
+        assert g.dtype == torch.float64 and list(g.shape) == shape, k
+        rel = abs(float(g.norm()) - nrm) / nrm
+        worst_norm = max(worst_norm, rel)
+        assert rel <= 1e-2, (k, float(g.norm()), nrm)
+        assert float((g - g.t()).abs().max()) <= 1e-12 * float(g.abs().max()), k  # mirrored upper triangle (float64 atomics: order, not value)
+    picked = [key for key in gold.files if key.startswith("gram/")]
+    assert len(picked) == 8
+    for key in picked:
+        g = grams[key[5:]][:256, :256].numpy()
+        ref = gold[key].astype(np.float64)
+        rel = np.linalg.norm(g - ref) / np.linalg.norm(ref)
+        worst_block = max(worst_block, float(rel))
+        assert rel <= 1e-2, (key, rel)
+    MEASURED.setdefault("test_gram_capture_base_width_matches_reference", {}).update(
+        {"gram_norm_rel_max": worst_norm, "gram_256_block_rel_frobenius_max": worst_block})
+
+
 @pytest.mark.parametrize("case", [c for c in sorted(CASES) if CASES[c][0] == "regmean"])
 def test_regmean_matches_reference_tiny(case, pkg, golden_dir):
     rm = importlib.import_module("vl_merging_amd.regmean")

@@ -108,6 +108,26 @@ def test_oracle_irtr_and_grams_match_reference(arch, golden_dir):
                 close(g, gold[key], 1e-5)
 
 
+def test_oracle_grams_base_width_match_reference(golden_dir):
+    """The Gram hook at BASE width (hidden 768 / F 3072, 384^2, all_moe irtr model, B = 3) on the reference's own
+    output (tests/golden/gram_base.npz): pins oracle/vlmo_ref.py::gram_inputs at the size configs[3] names."""
+    gold = np.load(os.path.join(golden_dir, "gram_base.npz"))
+    sd, _ = load_state(golden_dir, "base_irtr_all_moe")
+    idx = index_buffers(golden_dir, "384")
+    a = R.Arch("all_moe")
+    batch = tb(det_batch(3, 384, 40, 1024, seed=99))
+    with torch.no_grad():
+        grams = R.gram_inputs(sd, a, idx, batch)
+    assert sorted(grams) == json.loads(str(gold["gram_keys"]))
+    summ = json.loads(str(gold["gram_summary"]))
+    for k, (shape, nrm, sm) in summ.items():
+        assert list(grams[k].shape) == shape
+        assert abs(float(grams[k].norm()) - nrm) <= 1e-5 * nrm, k
+    for key in gold.files:
+        if key.startswith("gram/"):
+            close(grams[key[5:]][:256, :256].float(), gold[key], 1e-4)
+
+
 def test_index_buffers_known_answers(golden_dir):
     """sha256 / sums recorded from the reference for both resolutions."""
     import hashlib

@@ -16,6 +16,7 @@ extern "C" int vlm_device_cus(void) { return 256; }
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 88, mode = argc > 2 ? atoi(argv[2]) : 0, with_bias = argc > 3 ? atoi(argv[3]) : 1;
   const int what = argc > 4 ? atoi(argv[4]) : 0;  // 0 fwd, 1 bwd
+  const int with_dbias = argc > 5 ? atoi(argv[5]) : 1;  // 0: no bias-table gradient (dQ + dK/dV kernels only)
   const int n0 = 40, n1 = 577, H = 12, D = H * 64, pos1 = 40, NP = pos1 + n1, R = 2294, ncols = 144;
   const int rows = B * (n0 + n1);
   std::vector<uint16_t> hq((size_t)rows * 3 * D);
@@ -45,7 +46,7 @@ int main(int argc, char** argv) {
   d.bias_dense = dense; d.bias_dense_t = dense_t; d.dense_tiles = (int)(cb / 4096);
   auto run = [&]() {
     int rc = what == 0 ? vlm_attention_fwd(&d, out, D, lse, 0)
-                       : vlm_attention_bwd(&d, out, D, dout, D, lse, delta, vlm_attention_bwd_ws_floats(&d, 1), dqkv, 3 * D, with_bias ? dbias : nullptr, nullptr, 0);
+                       : vlm_attention_bwd(&d, out, D, dout, D, lse, delta, vlm_attention_bwd_ws_floats(&d, 1), dqkv, 3 * D, with_bias && with_dbias ? dbias : nullptr, nullptr, 0);
     if (rc) { printf("launch failed rc=%d\n", rc); exit(1); }
   };
   if (what == 1) { int rc = vlm_attention_fwd(&d, out, D, lse, 0); if (rc) { printf("fwd rc=%d\n", rc); return 1; } }

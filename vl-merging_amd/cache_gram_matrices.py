@@ -91,7 +91,10 @@ def main(argv):
         source = (synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 4321 + i, "cuda")["vl"]
                   for i in range(4 if batches is None else batches) if i % world == rank)
     n_seen = 0
-    with torch.no_grad():
+    obj = importlib.import_module("vl_merging_amd.vilt.modules.objectives")
+    # the ranks run different numbers of forward passes (round robin over a ragged batch list) and only the hooks matter:
+    # the losses' cross-rank gathers are switched off for the sweep
+    with torch.no_grad(), obj.local_only():
         for batch in source:
             model(batch)
             n_seen += 1

@@ -259,6 +259,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   unsigned char* ldsO = smem + 4 * ATT_TILE_BYTES;      // [2] dO row image
   unsigned char* ldsOt = smem + 6 * ATT_TILE_BYTES;     // [2] dO transposed-read image
   float* qstat = reinterpret_cast<float*>(smem + 8 * ATT_TILE_BYTES);  // [2][-lse 64 | -delta 64]
+#ifdef ATT_DIAG_HIST  // experiment (tools/scratch/attn_bench.hip): what an LDS float histogram of every dS costs inside this kernel
+  __shared__ float diag_hist[2624];
+  for (int i = threadIdx.x; i < 2624; i += ATT_THREADS) diag_hist[i] = 0.f;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
@@ -384,6 +388,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
         e[i] = att_exp2(e[i]);  // P
         dp[i] *= e[i];          // dS (natural units)
       }
+#ifdef ATT_DIAG_HIST
+      {
+        const int base = 1300 + ((t * 2 + qb) * 29) % 1200;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#if ATT_DIAG_HIST == 1  // the Toeplitz pattern: r = a(q) - c(key); the two lane halves (queries 4 apart) collide on 28 lanes
+          const int at = base + (i & 3) + 8 * (i >> 2) + 4 * hh - r;
+#else                   // 64 distinct consecutive addresses per instruction
+          const int at = base + 64 * (i & 7) + lane;
+#endif
+          atomicAdd(&diag_hist[at], dp[i]);
+        }
+      }
+#endif
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pf, df;
@@ -406,6 +424,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
     __syncthreads();
   }
 
+#ifdef ATT_DIAG_HIST
+  __syncthreads();
+  if (diag_hist[tid] == 12345.f) dk[0][0] += 1.f;  // keep the histogram alive
+#endif
   // ---- store dK, dV: accumulator rows = keys (registers), column = d (lane & 31) ---------------------------------------
   {
     const int kp0w = sp.p0 + wave * 32;
@@ -585,8 +607,12 @@ __global__ __launch_bounds__(ATT_DB_THREADS, 2) void attn_bwd_dbias_kernel(const
   for (int b = b_lo; b < b_hi; ++b) {
     const int cur = (b - b_lo) & 1;
     if (b + 1 < b_hi) {
+#ifndef ATT_DB_NOSTORE
       l_store(cur ^ 1);                   // loaded during the previous sample; that stage was last read two samples ago
+#endif
+#ifndef ATT_DB_NOLOAD
       if (b + 2 < b_hi) g_load(b + 2);    // flies during this sample's MFMAs
+#endif
     }
     const unsigned char* ldsK = smem + cur * STAGE;
     const unsigned char* ldsV = ldsK + 2 * ATT_TILE_BYTES;
@@ -604,6 +630,10 @@ __global__ __launch_bounds__(ATT_DB_THREADS, 2) void attn_bwd_dbias_kernel(const
       for (int j = 0; j < 8; ++j) kf[ss][j] = (bf16_t)((float)raw[j] * c1);
       vf[ss] = att_k_rowfrag(ldsV, kw * 32 + r, 2 * ss + hh);
     }
+#ifdef ATT_DB_NOMATH
+    acc[0][0] += (float)kf[0][0] + (float)vf[1][1];
+    if (false)
+#endif
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int q0 = qh * 64 + qb * 32;  // first query row of the block inside the 128-row tile

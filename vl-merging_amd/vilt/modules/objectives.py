@@ -8,8 +8,26 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+_LOCAL_ONLY = [False]
+
+
+class local_only:
+    """with local_only(): the losses see a world of one -- no feature / candidate gathers.  For sweeps whose ranks run
+    DIFFERENT numbers of forward passes and do not need the loss (the Gram cache deals batches round-robin and only wants
+    the hooks to fire: cache_gram_matrices.py:339 drives them with trainer.validate, whose sampler pads instead)."""
+
+    def __enter__(self):
+        self.prev = _LOCAL_ONLY[0]
+        _LOCAL_ONLY[0] = True
+        return self
+
+    def __exit__(self, *a):
+        _LOCAL_ONLY[0] = self.prev
+        return False
+
+
 def _world():
-    if dist.is_available() and dist.is_initialized():
+    if not _LOCAL_ONLY[0] and dist.is_available() and dist.is_initialized():
         return dist.get_world_size(), dist.get_rank()
     return 1, 0
 
