@@ -689,6 +689,56 @@ def gold_ckpt():
         json.dump(meta, f, indent=0, sort_keys=True)
 
 
+def written_here_state(arch="ufo"):
+    """What tests/test_checkpoint_cpu.py writes with checkpoint.save_ckpt: the build's own model (CPU construction, no
+    engine), deterministic weights keyed by parameter name."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.import_package()
+    cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
+    vmod = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
+    cfg = cfgmod.make_config(arch, vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, vocab_size=1024, max_text_len=40,
+                             patch_size=16, vlffn_start_layer_index=10, image_size=224, max_vl_text_len=40, tasks=["vl"],
+                             loss_names=cfgmod._loss_names({"itm": 1, "mlm": 1, "ifm": 1}))
+    model = vmod.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    sd = {k: torch.from_numpy(det_array(k, v.shape, 11)) for k, v in model.state_dict().items()
+          if v.is_floating_point() and "index" not in k and "mask_for" not in k}
+    model.load_state_dict(sd, strict=False)
+    return model
+
+
+def gold_ckpt_written_here():
+    """The other direction of the .ckpt contract: a `last.ckpt` written by the build's checkpoint.save_ckpt must load in the
+    REFERENCE through its own `load_path=` route (torch.load -> modify_checkpoint_vlmo -> load_state_dict(strict=False),
+    vilt_module.py:270-295).  Kept: the reference's missing / unexpected key lists and the sha256 of every parameter the
+    reference model holds after the load."""
+    import importlib
+    _dist_once()
+    ours = written_here_state("ufo")
+    ck = importlib.import_module("vl_merging_amd.checkpoint")
+    tmp = os.path.join(HERE, "_written_here.ckpt")
+    ck.save_ckpt(tmp, ours, global_step=7, epoch=1)
+    try:
+        cfg = base_config(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3, max_text_len=40, vocab_size=1024,
+                          max_vl_text_len=40, tasks=["vl"], loss_names={"itm": 1, "mlm": 1, "ifm": 1}, load_path=tmp)
+        ref, _ = build_reference_model(cfg, "ufo")  # the reference's __init__ loads the file
+        raw = torch.load(tmp, map_location="cpu", weights_only=False)
+    finally:
+        os.remove(tmp)
+    import vilt.modules.vilt_module as vm_ref  # noqa
+    # the reference logs these itself (vilt_module.py:293-295); recompute them the same way for the fixture
+    info = ref.load_state_dict(ref.modify_checkpoint_vlmo({"state_dict": {k: v.clone() for k, v in raw["state_dict"].items()}}),
+                               strict=False)
+    out = {"missing_keys": sorted(info.missing_keys), "unexpected_keys": sorted(info.unexpected_keys),
+           "ckpt_top_level_keys": sorted(raw.keys()), "global_step": int(raw["global_step"]),
+           "param_sha": {n: sha(p.detach().contiguous().numpy()) for n, p in ref.named_parameters()}}
+    print("written-here ckpt in the reference: missing", out["missing_keys"], "unexpected", out["unexpected_keys"],
+          len(out["param_sha"]), "parameters")
+    with open(os.path.join(HERE, "ckpt_written_here.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 # ----------------------------------------------------------------------------- retrieval recall (SURVEY.md 8f rank 3)
 class _RecallDset(torch.utils.data.Dataset):
     """Stand-in for the datamodule's no-false test dataset: items are what BaseDataset.collate would have produced."""
@@ -866,4 +916,4 @@ if __name__ == "__main__":
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
          "irtr": gold_irtr, "model_base": gold_model_base, "irtr_merged_base": gold_irtr_merged_base,
          "train_tiny": gold_train_tiny, "regmean_base": gold_regmean_base, "vlmo_resize": gold_vlmo_resize, "schedule": gold_schedule,
-         "gram_base": gold_gram_base, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()
+         "gram_base": gold_gram_base, "ckpt_written_here": gold_ckpt_written_here, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()

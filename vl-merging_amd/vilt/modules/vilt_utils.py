@@ -133,6 +133,31 @@ class FusedAdamW:
     def inactive_parameters(self):
         return [n for n in self.flat.names if n not in self._active]
 
+    # ---- checkpoint / resume (Lightning keeps `optimizer_states` in the .ckpt, run.py:189-195, :218-223, :280) --------
+    def state_dict(self):
+        """Adam's moments as CPU tensors keyed by parameter name (layout-independent), the step count, the active set."""
+        if self._shard is not None:
+            raise NotImplementedError("sharded optimizer state is spread over the ranks: save from an unsharded run")
+        f = self.flat
+        state = {}
+        for n in f.names:
+            o, k = f.offsets[n]
+            state[n] = {"exp_avg": self.m[o:o + k].detach().cpu().clone(), "exp_avg_sq": self.v[o:o + k].detach().cpu().clone()}
+        return {"state": state, "step": self.step_count, "active": sorted(self._active),
+                "param_groups": [{k: v for k, v in g.items() if k != "ranges"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        f = self.flat
+        for n, st in sd["state"].items():
+            if n not in f.offsets:
+                continue
+            o, k = f.offsets[n]
+            self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+        self.step_count = int(sd["step"])
+        f.touched |= set(sd.get("active", ()))
+        self._discover_active()
+
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
@@ -189,6 +214,14 @@ class LambdaSchedule:
         self.opt, self.fn, self.last = optimizer, fn, 0
         for g in optimizer.param_groups:
             g["lr"] = g["initial_lr"] * fn(0)
+
+    def state_dict(self):
+        return {"last_epoch": self.last}
+
+    def load_state_dict(self, sd):
+        self.last = int(sd["last_epoch"])
+        for g in self.opt.param_groups:
+            g["lr"] = g["initial_lr"] * self.fn(self.last)
 
     def step(self):
         self.last += 1
