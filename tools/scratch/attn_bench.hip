@@ -74,8 +74,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(att_stamps), sizeof(st)));
     for (int w = 0; w < 8; w += 4) {
       printf("wave %d deltas:", w);
-      for (int i = 1; i < 64 && st[w * 64 + i]; ++i) printf(" %llu", st[w * 64 + i] - st[w * 64 + i - 1]);
+      for (int i = 1; i < 60 && st[w * 64 + i]; ++i) printf(" %llu", st[w * 64 + i] - st[w * 64 + i - 1]);
       printf("\n");
+      if (st[w * 64 + 61] > st[w * 64 + 60])
+        printf("wave %d clock: %.3f GHz (slots 20..50: %llu shader cycles in %llu x 10 ns)\n", w,
+               (double)(st[w * 64 + 50] - st[w * 64 + 20]) / ((double)(st[w * 64 + 61] - st[w * 64 + 60]) * 10.0),
+               st[w * 64 + 50] - st[w * 64 + 20], st[w * 64 + 61] - st[w * 64 + 60]);
     }
   }
 #endif

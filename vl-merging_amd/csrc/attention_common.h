@@ -18,6 +18,26 @@ __device__ __forceinline__ float att_max3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// single-instruction forms (hipcc -O3 SLP-packs adjacent f32 adds into v_pk_add_f32, slow beside MFMAs, and puts a
+// canonicalising v_max in front of fmaxf on MFMA outputs)
+__device__ __forceinline__ float att_add(float a, float b) {
+  float d;
+  asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float att_max2(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// the other 32-lane half's value of x (lane i <-> lane i ^ 32) on the vector pipe: v_permlane32_swap instead of the LDS
+// crossbar (ds_bpermute + lgkmcnt wait) behind __shfl_xor(x, 32)
+__device__ __forceinline__ float att_other_half(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  // v_permlane32_swap vdst, src exchanges vdst[32..63] with src[0..31]: the new vdst (r[0]) carries the lower half's values
+  // in its lanes 32..63, the new src (r[1]) the upper half's values in its lanes 0..31
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
 // bias-table gather: the relative-position index is stored PRE-MULTIPLIED by 4 (byte offset into the LDS column)
 __device__ __forceinline__ float att_tab(const float* tab, uint32_t byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(tab) + byte_off);
@@ -365,6 +385,13 @@ __device__ __forceinline__ void att_bias_load(att_bias_t& bw, __amdgpu_buffer_rs
   bw.w[0][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 1024, soff, 0));
   bw.w[1][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 2048, soff, 0));
   bw.w[1][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 3072, soff, 0));
+}
+// the two operands of ONE 32-position block of the next tile (the forward kernel re-requests a block's rows as soon as its
+// selection MFMAs have consumed them)
+__device__ __forceinline__ void att_bias_load_half(att_bias_t& bw, int blk, __amdgpu_buffer_rsrc_t mat, uint32_t voff, int st) {
+  const uint32_t soff = (uint32_t)st * 4096u + (uint32_t)blk * 2048u;
+  bw.w[blk][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff, soff, 0));
+  bw.w[blk][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(mat, voff + 1024, soff, 0));
 }
 // byte offset (inside a column) of stationary block `sb_in_part` of the part the workgroup's stationary tile lies in
 __device__ __forceinline__ uint32_t att_bias_voff(const att_dense_layout_t& L, int part, int sb_in_part, int lane) {

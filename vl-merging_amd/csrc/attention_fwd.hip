@@ -23,11 +23,15 @@
 #include <type_traits>
 
 #ifndef ATT_FWD_WAVES
-#define ATT_FWD_WAVES 2
+#define ATT_FWD_WAVES 3
 #endif
 #ifdef ATT_DIAG_STAMPS  // diagnostic builds only (tools/scratch/attn_bench.hip): s_memtime inside the tile loop
 __device__ unsigned long long att_stamps[8 * 64];
-#define ATT_STAMP(slot) do { const int s_ = (slot); if (blockIdx.x == 8 * 100 && lane == 0 && s_ < 64) att_stamps[wave * 64 + s_] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef ATT_STAMP_BLOCK
+#define ATT_STAMP_BLOCK (8 * 100)
+#endif
+// slots 0..59: s_memtime (shader clock); slots 60 / 61: s_memrealtime (100 MHz) taken together with slots 20 / 50 -> the clock
+#define ATT_STAMP(slot) do { const int s_ = (slot); if (blockIdx.x == ATT_STAMP_BLOCK && lane == 0 && s_ < 60) { att_stamps[wave * 64 + s_] = __builtin_amdgcn_s_memtime(); if (s_ == 20) att_stamps[wave * 64 + 60] = __builtin_amdgcn_s_memrealtime(); if (s_ == 50) att_stamps[wave * 64 + 61] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define ATT_STAMP(slot) do { } while (0)
 #endif
@@ -72,9 +76,16 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
       for (int j = 0; j < 8; ++j) qf[s][j] = (bf16_t)((float)raw[j] * c1);
     }
   }
-  bf16x8 ones;
+  // The running reference point m rides in a FIFTH k-step of the score product instead of a 16-register C tuple:
+  // k-slots 0, 1 of the extra step hold (1, 1) on the key side (a constant operand, no LDS read) and (-m_hi, -m_lo) on
+  // the query side (m is an fp16 value: bf16 high part + exact bf16 remainder), so the chain starts from C = 0 and the
+  // registers of the tuple are free (3 waves per SIMD need <= 168).
+  bf16x8 kone, qm;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+  for (int j = 0; j < 8; ++j) {
+    kone[j] = (bf16_t)((hh == 0 && j < 2) ? 1.0f : 0.0f);
+    qm[j] = (bf16_t)0.0f;
+  }
   f16x8 sel0, sel1;
   att_select_frags(lane, sel0, sel1);
   const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc(
@@ -88,10 +99,18 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   // m = the value subtracted from this row's exponents so far (0 until a score exceeds 2^6, then a running maximum
   // rounded to fp16 so that it is exact in every format it passes through); negm = -m in all 16 registers, the C
   // operand of each score chain; lacc = row sums (every register holds this lane's query's sum)
-  float m = 0.f;
-  f32x16 o[2], negm, lacc;
+  float m = 0.f, lsum = 0.f;  // lsum: this lane's half (keys 4*hh + {0..3} mod 8) of its query's row sum
+  f32x16 o[2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = negm[i] = lacc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
+#ifdef ATT_FWD_MFMA_ROWSUM
+  f32x16 lacc;
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+#endif
 
   // a tile needs the additive mask iff it can hold a padding token (keep masks) or -- without a bias table, whose
   // ATT_NEG_BIG entries mask every invalid position -- a gap, foreign or past-the-end position
@@ -114,29 +133,35 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   // every wave drains its own LDS-DMA pieces (and bias rows) before the barrier that publishes the tile
 #ifdef ATT_DIAG_NOSYNC
 #define ATT_PUBLISH() do { } while (0)
+#define ATT_PUBLISH_KEEP4() do { } while (0)
 #else
 #define ATT_PUBLISH()                                  \
   do {                                                 \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
     __syncthreads();                                   \
   } while (0)
+// inside the tile loop of the biased kernel the four bias loads of the NEXT tile are younger than this wave's LDS-DMA pieces
+// (vmcnt retires in order): the tile is published once all but those four have landed
+// (one asm statement: __syncthreads() would put its own vmcnt(0) in front of the barrier -- to the compiler every pending
+// vector-memory operation might be an LDS-DMA write)
+#define ATT_PUBLISH_KEEP4()                                                        \
+  do {                                                                             \
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+  } while (0)
 #endif
 
-  att_bias_t bwA, bwB;
-  if (HAS_BIAS) att_bias_load(bwA, rbias, bvoff, 0);  // issued BEFORE the DMA: vmcnt retires in order
+  att_bias_t bw;  // ONE set: the next tile's rows are requested as soon as this tile's selection MFMAs have been issued
+  if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);  // issued BEFORE the DMA: vmcnt retires in order
   stage(0, ldsK0, ldsV0, kmask0);
   ATT_PUBLISH();
 
   // one streamed tile; `bw` = this tile's bias rows (complete since the last publish), `bn` receives the next tile's
   int slot = 0;
-  auto tile = [&](int t, const att_bias_t& bw, att_bias_t& bn, const unsigned char* lk, const unsigned char* lv,
-                  const float* km, unsigned char* nk, unsigned char* nv, float* nm_) {
+  auto tile = [&](int t, const unsigned char* lk, const unsigned char* lv, const float* km, unsigned char* nk,
+                  unsigned char* nv, float* nm_) {
     const int kp0 = sp.s_lo + t * ATT_BK;
     ATT_STAMP(slot++);
     if (t + 1 < ntiles) {
-#ifndef ATT_DIAG_NOBIASLOAD
-      if (HAS_BIAS) att_bias_load(bn, rbias, bvoff, t + 1);
-#endif
 #ifndef ATT_DIAG_NODMA
       stage(t + 1, nk, nv, nm_);
 #endif
@@ -144,102 +169,118 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
 
     // ---- E^T = -m + Bias^T*log2e + K (c1 Q)^T : two 32-key chains of exponents ------------------------------------
     ATT_STAMP(slot++);  // after issuing the next tile's loads
-    // all eight K row fragments are requested up front (hipcc otherwise issues each ds_read right in front of its
-    // MFMA and waits out the full LDS latency eight times per tile); the bias MFMAs need no LDS data and cover it
-    bf16x8 kfr[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss) kfr[kb][ss] = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 s[2];
+    // One 32-key block at a time, start to finish: E^T = bias + (-m) + K (c1 Q)^T, its own reference-point decision, exp2,
+    // row sums, O^T += V^T P^T.  Only ONE 16-register score tuple is live (two blocks in flight cost 16 more registers and
+    // with them the third wave per SIMD); the other waves of the SIMD fill the chain's gaps.
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      s[kb] = negm;
-      if (HAS_BIAS) s[kb] = att_bias_mfma(sel0, sel1, bw.w[kb], s[kb]);
-    }
+      bf16x8 kfr[4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int ss = 0; ss < 4; ++ss) kfr[ss] = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh);
+      f32x16 s;
 #pragma unroll
-      for (int ss = 0; ss < 4; ++ss) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ss], qf[ss], s[kb], 0, 0, 0);
-    ATT_STAMP(slot++);  // S chain issued
-    if (tile_masked(kp0)) {  // workgroup-uniform
+      for (int i = 0; i < 16; ++i) s[i] = 0.f;
+      if (HAS_BIAS) s = att_bias_mfma(sel0, sel1, bw.w[kb], s);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qm, s, 0, 0, 0);  // - m
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int ss = 0; ss < 4; ++ss) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ss], qf[ss], s, 0, 0, 0);
+      ATT_STAMP(slot++);  // score chain issued
+#ifndef ATT_DIAG_NOBIASLOAD
+      // the next tile's rows of this block: same registers, consumed by the selection MFMAs above
+      if (HAS_BIAS && t + 1 < ntiles) att_bias_load_half(bw, kb, rbias, bvoff, t + 1);
+#endif
+      if (tile_masked(kp0)) {  // workgroup-uniform
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const f32x4 mk = *reinterpret_cast<const f32x4*>(km + kb * 32 + 8 * g4 + 4 * hh);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s[kb][4 * g4 + e] += mk[e];
+          for (int e = 0; e < 4; ++e) s[4 * g4 + e] += mk[e];
         }
-    }
+      }
 #ifdef ATT_DIAG_NOSOFTMAX
-    float mx = s[0][0];
+      float mx = s[0];
 #else
-    float mx = att_max3(s[0][0], s[0][1], s[0][2]);
+      float mx = att_max3(s[0], s[1], s[2]);
 #pragma unroll
-    for (int i = 3; i < 15; i += 2) mx = att_max3(mx, s[0][i], s[0][i + 1]);   // 3..14
-    mx = att_max3(mx, s[0][15], s[1][0]);
-#pragma unroll
-    for (int i = 1; i < 15; i += 2) mx = att_max3(mx, s[1][i], s[1][i + 1]);   // 1..14
-    mx = fmaxf(mx, s[1][15]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int i = 3; i < 15; i += 2) mx = att_max3(mx, s[i], s[i + 1]);   // 3..14
+      mx = att_max2(mx, s[15]);
+      mx = att_max2(mx, att_other_half(mx));
 #endif
-    ATT_STAMP(slot++);  // max known
-    if (__any(mx > 6.0f)) {  // some row's exponents exceed 2^6: move those rows' reference points (rare after tile 0)
-      const float m_new = mx > 0.f ? (float)(_Float16)(m + mx) : m;
-      const float delta = m_new - m;  // exact: both are fp16 values
-      const float alpha = att_exp2(-delta);
-      m = m_new;
+      ATT_STAMP(slot++);  // maximum known
+      if (__any(mx > 6.0f)) {  // some row's exponents exceed 2^6: move those rows' reference points (rare after tile 0)
+        const float m_new = mx > 0.f ? (float)(_Float16)(m + mx) : m;
+        const float delta = m_new - m;  // exact: both are fp16 values
+        const float alpha = att_exp2(-delta);
+        m = m_new;
+        lsum *= alpha;
+#ifdef ATT_FWD_MFMA_ROWSUM
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[0][i] -= delta;
-        s[1][i] -= delta;
-        o[0][i] *= alpha;
-        o[1][i] *= alpha;
-        lacc[i] *= alpha;
-        negm[i] = -m_new;
+        for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
+#endif
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[i] -= delta;
+          o[0][i] *= alpha;
+          o[1][i] *= alpha;
+        }
+        const bf16_t mh = (bf16_t)(-m_new);
+        const bf16_t ml = (bf16_t)(-m_new - (float)mh);  // exact: an fp16 value minus its 8-bit head
+        if (hh == 0) { qm[0] = mh; qm[1] = ml; }
       }
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
 #ifndef ATT_DIAG_NOSOFTMAX
-        s[kb][i] = att_exp2(s[kb][i]);
-#endif
-      }
-    ATT_STAMP(slot++);  // exps issued
-    // ---- O^T += V^T P^T ;  row sums += 1^T P^T -------------------------------------------------------------------
-#ifdef ATT_DIAG_NOPV
-    o[0][0] += s[0][0];
-    if (false)
-#endif
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int i = 0; i < 16; ++i) s[i] = att_exp2(s[i]);
+#endif
+      ATT_STAMP(slot++);  // exponentials issued
+      // row sums on the vector pipe: four independent partial sums
+#ifndef ATT_FWD_MFMA_ROWSUM
+      {
+        float p0 = att_add(s[0], s[1]), p1 = att_add(s[2], s[3]), p2 = att_add(s[4], s[5]), p3 = att_add(s[6], s[7]);
+        p0 = att_add(p0, att_add(s[8], s[9]));
+        p1 = att_add(p1, att_add(s[10], s[11]));
+        p2 = att_add(p2, att_add(s[12], s[13]));
+        p3 = att_add(p3, att_add(s[14], s[15]));
+        lsum = att_add(lsum, att_add(att_add(p0, p1), att_add(p2, p3)));
+      }
+#endif
+#ifdef ATT_DIAG_NOPV
+      o[0][0] += s[0];
+      if (false)
+#endif
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kb][8 * s2 + j];
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[8 * s2 + j];
+#ifdef ATT_FWD_MFMA_ROWSUM
         lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+#endif
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16x8 vf = att_tr_frag(lv, kb * 32 + 16 * s2, db, lane);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
         }
       }
+      ATT_STAMP(slot++);  // P V issued
     }
-    ATT_STAMP(slot++);  // PV issued
+#if defined(ATT_DIAG_NOBIASLOAD) || defined(ATT_DIAG_NODMA)
     ATT_PUBLISH();
+#else
+    if (HAS_BIAS && t + 1 < ntiles) ATT_PUBLISH_KEEP4();
+    else ATT_PUBLISH();
+#endif
   };
-  for (int t = 0; t < ntiles; t += 2) {  // two tiles per trip: the bias registers alternate without copies
-    tile(t, bwA, bwB, ldsK0, ldsV0, kmask0, ldsK1, ldsV1, kmask1);
-    if (t + 1 < ntiles) tile(t + 1, bwB, bwA, ldsK1, ldsV1, kmask1, ldsK0, ldsV0, kmask0);
+  for (int t = 0; t < ntiles; t += 2) {  // two tiles per trip: the LDS stages are distinct objects, selected at compile time
+    tile(t, ldsK0, ldsV0, kmask0, ldsK1, ldsV1, kmask1);
+    if (t + 1 < ntiles) tile(t + 1, ldsK1, ldsV1, kmask1, ldsK0, ldsV0, kmask0);
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
+#ifdef ATT_FWD_MFMA_ROWSUM
   const float lt = lacc[0];
+#else
+  const float lt = lsum + __shfl_xor(lsum, 32, 64);  // the two lane halves hold complementary keys of the same query
+#endif
   const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   if (qvalid) {
     bf16_t* op = p.out + qrow * p.ld_out + h * 64 + 4 * hh;
