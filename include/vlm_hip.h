@@ -6,7 +6,11 @@
  *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless named *_host;
  *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*), re-entrant, allocates
  *     nothing: the caller owns outputs and workspaces;
- *   - return 0 on success, a negative VLM_ERR_* otherwise; nothing throws across the boundary.
+ *   - return 0 on success, a negative VLM_ERR_* otherwise; nothing throws across the boundary;
+ *   - process-wide state is limited to (1) diagnostic switches read ONCE from the environment at first use (VLM_GEMM_BIG,
+ *     VLM_GEMM_BIGT, VLM_GEMM_STAGE, VLM_GEMM_SPLITK, VLM_GEMM_SPLITK_SLOTS, VLM_GEMM_GROUP_M, VLM_GEMM_BIG_GROUP_M,
+ *     VLM_MERGE_VARIANT: thread-safe function-local statics, immutable afterwards) and (2) the test hook
+ *     vlm_gemm_set_big_tile_mode (one atomic int).  Neither changes results beyond the fp32 summation order of a GEMM.
  *
  * Token layout ("segment-major"): a pass over B samples with n0 text and n1 image tokens per sample keeps
  * activations as a [rows, D] matrix whose rows are  base0 + b*n0 + t  (t < n0)  and  base1 + b*n1 + (t-n0).
@@ -60,8 +64,8 @@ typedef struct {
 
 /* Bytes of device workspace a plan for n_jobs jobs over total_elems elements needs. */
 size_t vlm_merge_plan_bytes(int n_jobs, uint64_t total_elems);
-/* Build the chunk table on the host and copy jobs + table into `workspace` (stream-ordered H2D from a
- * pageable host buffer: the call returns after the copy is enqueued and the source is no longer needed). */
+/* Build the chunk table on the host and copy jobs + table into `workspace`.  The source is a temporary pageable host
+ * buffer, so the call SYNCHRONISES `stream` before it returns (once per merge plan; vlm_merge_run is asynchronous). */
 int vlm_merge_plan_upload(const vlm_merge_job_t* jobs_host, int n_jobs, void* workspace, size_t workspace_bytes,
                           void* stream);
 /* Run an uploaded plan: ONE kernel launch over all jobs. */

@@ -13,16 +13,28 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 RES = os.path.join(HERE, "..", "vl-merging_amd", "lib", "kernel_resources.json")
 
 
+CSRC = os.path.join(HERE, "..", "vl-merging_amd", "csrc")
+
+
+def _stale():
+    """No record, or a kernel source / header newer than the record (an edit that was never rebuilt)."""
+    if not os.path.exists(RES):
+        return True
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    return max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(RES)
+
+
 @pytest.fixture(scope="module")
 def resources():
-    if not os.path.exists(RES):
+    """lib/kernel_resources.json is a BUILD product (git-ignored): rebuilt here whenever it is missing or older than a
+    source, so the tripwire can never pass on stale numbers."""
+    if _stale():
         import importlib.util
         spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(HERE, "..", "__graft_entry__.py"))
         ge = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(ge)
         ge.build()
-    if not os.path.exists(RES):
-        pytest.skip("objects were cached from a build that did not record resources; touch csrc/*.hip and rebuild")
+    assert os.path.exists(RES), "the build did not record kernel resources"
     with open(RES) as f:
         return json.load(f)
 

@@ -159,3 +159,39 @@ def test_ckpt_written_here_is_what_the_reference_loaded(tmp_path):
     # Lightning module; the only key it did not want is transformers-4.x's persistent position_ids
     assert all(("index" in k) or k.startswith(("train_", "val_")) or k == "mask_for_combining_temporal" for k in gold["missing_keys"])
     assert gold["unexpected_keys"] == ["text_embeddings.position_ids"]
+
+
+@pytest.mark.parametrize("name,arch,shared,kind,over", [c for c in CASES if c[0] in ("beit_moe_shared", "self_ufo_shared")])
+def test_load_path_dispatches_beit_and_self_adaptation(tmp_path, name, arch, shared, kind, over):
+    """The FLOW of vilt_module.py:276-295: `load_path=<file>` + `use_beit_weight` / `use_self_weight` in the config must route
+    the file through modify_checkpoint_beit / _self inside __init__ and load the result (strict=False) -- the parameters
+    of the constructed model carry the digests the reference produced for the direct method call."""
+    digests = json.load(open(os.path.join(HERE, "golden", "ckpt_rekey_digests.json")))[name]
+    sd = beit_state(192, 768, 3, 12, 7, shared)
+    if kind == "self":
+        sd["text_embeddings.position_embeddings.weight"] = torch.from_numpy(
+            det_array("text_embeddings.position_embeddings.weight", (60, 192), 3))
+        sd["text_embeddings.position_ids"] = torch.arange(60).view(1, 60)
+        payload, flag = dict(sd), "use_self_weight"
+    else:
+        payload, flag = {"state_dict": dict(sd)}, "use_beit_weight"
+    path = os.path.join(tmp_path, name + ".pth")
+    torch.save(payload, path)
+    cfg = cfgmod.make_config(arch, loss_names=cfgmod._loss_names({"irtr": 1}), vit="vit_tiny_patch16_224", hidden_size=192,
+                             num_heads=3, max_text_len=40, vocab_size=64, vlffn_start_layer_index=10, patch_size=16,
+                             load_path=path, **dict(over, **{flag: True}))
+    torch.manual_seed(0)
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    assert not [u for u in model.load_info.unexpected_keys if "position_ids" not in u], model.load_info.unexpected_keys
+    loaded = dict(model.named_parameters())
+    hit = 0
+    for k, (shape, dtype, digest) in digests.items():
+        if k == "relative_position_bias_table":
+            continue  # its text / cls rows are taken from the MODEL's current table (vilt_module.py:863-881): zeros at construction
+        if k in loaded:
+            assert sha(loaded[k].detach()) == digest, k
+            hit += 1
+    assert hit >= 150, hit  # every adapted tensor that names a parameter of the target architecture landed in it
+    # neither flag: the same file goes down the VLMo route and must NOT be re-keyed (all_moe keys stay absent)
+    if arch == "all_moe":
+        assert "transformer.blocks.0.attn.v.qkv.weight" in digests and "transformer.blocks.0.attn.v.qkv.weight" in loaded

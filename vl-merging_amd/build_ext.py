@@ -78,7 +78,8 @@ def build(verbose=True, jobs=None):
                 merged.update(json.load(f))
         except OSError:
             pass
-    if merged:
+    if len(merged) and all(os.path.exists(o + ".resources.json") for o in objs):
+        # rewritten on EVERY build (its mtime tells tests/test_build_cpu.py the record is not older than the sources)
         with open(RESOURCES, "w") as f:
             json.dump(merged, f, indent=0, sort_keys=True)
     return LIB

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   ATT_PUBLISH();
 
   // one streamed tile; `bw` = this tile's bias rows (complete since the last publish), `bn` receives the next tile's
-  int slot = 0;
+  [[maybe_unused]] int slot = 0;
   auto tile = [&](int t, const unsigned char* lk, const unsigned char* lv, const float* km, unsigned char* nk,
                   unsigned char* nv, float* nm_) {
     const int kp0 = sp.s_lo + t * ATT_BK;

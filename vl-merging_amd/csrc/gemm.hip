@@ -18,6 +18,7 @@
 // The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that each lane ends
 // up with 4 CONSECUTIVE output columns of one row: the epilogue then moves 16-B (fp32) / 8-B (bf16) vectors.
 #include "vlm_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 #ifndef GEMM_FRAG_MODE
@@ -1242,12 +1243,12 @@ template <bool OUT_F32, bool RES, int AUX>
 static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
   p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
   p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
-  static int group_m = -1;
-  if (group_m < 0) {
+  static const int group_m = [] {
     const char* e = getenv("VLM_GEMM_BIG_GROUP_M");
-    group_m = e ? atoi(e) : 0;
-    if (group_m < 0) group_m = 0;
-  }
+    int v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
+    return v;
+  }();
   p.group_m = group_m ? group_m : (p.tiles_n >= 6 ? 4 : 1);
 #ifdef VLM_GEMM_STAMPS
   p.stamps = g_stamp_buffer;
@@ -1277,17 +1278,20 @@ static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStr
 
 // VLM_GEMM_BIG: 0 = never, 1 = by shape (default), 2 = whenever the kernel is legal (tests); vlm_gemm_set_big_tile_mode
 // overrides the environment (tests compare the two kernels in one process), -1 returns to it
-static int g_big_mode = -1;
+static std::atomic<int> g_big_mode{-1};  // -1: follow the environment
 static int gemm_big_mode() {
-  if (g_big_mode < 0) {
+  const int m = g_big_mode.load(std::memory_order_relaxed);
+  if (m >= 0) return m;
+  static const int env_mode = [] {
     const char* e = getenv("VLM_GEMM_BIG");
-    g_big_mode = e ? atoi(e) : 1;
-  }
-  return g_big_mode;
+    int v = e ? atoi(e) : 1;
+    return v;
+  }();
+  return env_mode;
 }
 extern "C" int vlm_gemm_set_big_tile_mode(int mode) {
   if (mode < -1 || mode > 2) return VLM_ERR_ARG;
-  g_big_mode = mode;
+  g_big_mode.store(mode, std::memory_order_relaxed);
   return VLM_OK;
 }
 
@@ -1311,20 +1315,20 @@ extern "C" int vlm_gemm_set_big_tile_mode(int mode) {
 // staging policy: K-contiguous operands by LDS-DMA, K-strided operands through registers (VLM_GEMM_STAGE: 0 = all
 // registers, 1 = all DMA, 2 = hybrid [default]); VLM_GEMM_SPLITK=0 disables split-K
 static int gemm_stage_mode() {
-  static int mode = -1;
-  if (mode < 0) {
+  static const int mode = [] {
     const char* e = getenv("VLM_GEMM_STAGE");
-    mode = e ? atoi(e) : 2;
-  }
+    int v = e ? atoi(e) : 2;
+    return v;
+  }();
   return mode;
 }
 static int gemm_splitk_enabled() {
-  static int v = -1;
-  if (v < 0) {
+  static const int on = [] {
     const char* e = getenv("VLM_GEMM_SPLITK");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
+    int v = e ? atoi(e) : 1;
+    return v;
+  }();
+  return on;
 }
 
 template <bool TA, bool TB, bool OUT_F32>
@@ -1373,12 +1377,12 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   // 1 / 4 / 8 / 16 / 32:  qkv fwd (operands 87 MB) 523 / 485 / 346 / 526 / 906 MB;  fc1 fwd 879 / 623 / 431 / 663 / 1277;
   // fc2 dgrad 1462 / 626 / 460 / 676 / 1143;  fc2 fwd (N = 768, K = 3072, operands 338 MB) 534 / 620 / 851 / 1023 / 1323.
   // Times differ by < 3 %, so the choice follows the traffic: 8 for wide outputs, row-major for N = 768.
-  static int group_m = -1;
-  if (group_m < 0) {
+  static const int group_m = [] {
     const char* e = getenv("VLM_GEMM_GROUP_M");
-    group_m = e ? atoi(e) : 0;
-    if (group_m < 0) group_m = 0;
-  }
+    int v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
+    return v;
+  }();
   p.group_m = group_m ? group_m : (p.tiles_n >= 12 ? 8 : 1);
 #ifdef VLM_GEMM_STAMPS
   p.stamps = g_stamp_buffer;
@@ -1388,11 +1392,12 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
   const int ntile = p.tiles_m * p.tiles_n, nk = (K + GEMM_BK - 1) / GEMM_BK;
   const bool plain_acc = epi->accumulate && c_is_f32 && !epi->bias && !epi->col_scale && !epi->row_scale &&
                          !epi->residual && !epi->aux && !epi->col_sum && epi->act == VLM_ACT_NONE;
-  static int bigt = -1;  // VLM_GEMM_BIGT=0: wgrad stays on the 128x128 atomic split-K kernel (A/B runs)
-  if (bigt < 0) {
+  // VLM_GEMM_BIGT=0: wgrad stays on the 128x128 atomic split-K kernel (A/B runs)
+  static const int bigt = [] {
     const char* e = getenv("VLM_GEMM_BIGT");
-    bigt = e ? atoi(e) : 1;
-  }
+    int v = e ? atoi(e) : 1;
+    return v;
+  }();
   if (bigt && gemm_big_mode() > 0 && ta && tb && c_is_f32 && !epi->bias && !epi->col_scale && !epi->row_scale && !epi->residual &&
       !epi->aux && !epi->col_sum && epi->act == VLM_ACT_NONE && K >= 2048) {
     const int rc = launch_gemm_bigT(p, epi, s);
@@ -1404,11 +1409,11 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     // Slices so that the launch is ONE round of the 2 x CUs resident workgroups, never a little more: measured at
     // K = 13 574 / 54 296 (tools/bench_gemm.py): 432 workgroups 97 / 332 us, 576 (1.125 rounds) 118 / 402 us, 864 113 / 337 us
     // -- fewer slices also mean fewer fp32 atomics (25 us of a 113-us launch at K = 13 574).
-    static int slots_override = -1;
-    if (slots_override < 0) {
-      const char* e = getenv("VLM_GEMM_SPLITK_SLOTS");
-      slots_override = e ? atoi(e) : 0;
-    }
+    static const int slots_override = [] {
+    const char* e = getenv("VLM_GEMM_SPLITK_SLOTS");
+    int v = e ? atoi(e) : 0;
+    return v;
+  }();
     const int slots = slots_override > 0 ? slots_override : 2 * cus;
     int splits = slots / ntile;
     if (splits < 1) splits = 1;

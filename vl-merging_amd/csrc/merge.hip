@@ -201,7 +201,7 @@ extern "C" int vlm_merge_plan_upload(const vlm_merge_job_t* jobs, int n_jobs, vo
       ++c;
     }
   }
-  // pageable source: hipMemcpyAsync stages it before returning, so `img` may die at scope exit
+  // pageable temporary source: the copy is waited for before `img` dies (header: this call synchronises the stream)
   if (hipMemcpyAsync(workspace, img.data(), total, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
     return VLM_ERR_LAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return VLM_ERR_LAUNCH;
@@ -212,13 +212,15 @@ extern "C" int vlm_merge_run(const void* workspace, void* stream) {
   if (!workspace) return VLM_ERR_ARG;
   // grid: G blocks per CU keep >= 2 KiB x n_src of loads in flight per SIMD; the chunk loop strides the grid.
   // VLM_MERGE_VARIANT="<blocks per CU>,<nt loads 0/1>,<nt stores 0/1>" overrides the default (measurement switch).
-  static int blocks_per_cu = 96, ntl = 1, nts = 1, parsed = 0;
-  if (!parsed) {
-    parsed = 1;
-    const char* v = getenv("VLM_MERGE_VARIANT");
-    if (v) sscanf(v, "%d,%d,%d", &blocks_per_cu, &ntl, &nts);
-    if (blocks_per_cu < 1 || blocks_per_cu > 256) blocks_per_cu = 96;
-  }
+  struct variant_t { int blocks_per_cu, ntl, nts; };
+  static const variant_t var = [] {  // parsed once, thread-safe (C++11 static initialisation), immutable afterwards
+    variant_t v = {96, 1, 1};
+    const char* e = getenv("VLM_MERGE_VARIANT");
+    if (e) sscanf(e, "%d,%d,%d", &v.blocks_per_cu, &v.ntl, &v.nts);
+    if (v.blocks_per_cu < 1 || v.blocks_per_cu > 256) v.blocks_per_cu = 96;
+    return v;
+  }();
+  const int blocks_per_cu = var.blocks_per_cu, ntl = var.ntl, nts = var.nts;
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;
   // 96 blocks per CU (8 resident at a time): 5.74 TB/s against 5.53 at 24 and 5.50 at 8 on one box, 5.89 against 5.50 on another:
