@@ -403,8 +403,12 @@ def main():
     model.train()
     model.setup_engine()
     (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"])
+    # VLM_GRAD_COMM=bf16: gradients travel as bf16 (half the xGMI bytes); VLM_GRAD_COLLECTIVE=rs_ag: reduce-scatter + all-gather
+    # instead of one all-reduce per bucket.  Defaults: fp32, all-reduce (what the reference's DDP does).
     reducer = ddp.FlatGradReducer(model, force_collectives=force_dist,
-                                  sharded=os.environ.get("VLM_SHARDED", "0") != "0")  # ddp_sharded (run.py:231-232)
+                                  sharded=os.environ.get("VLM_SHARDED", "0") != "0",  # ddp_sharded (run.py:231-232)
+                                  comm_dtype=torch.bfloat16 if os.environ.get("VLM_GRAD_COMM", "fp32") == "bf16" else None,
+                                  collective=os.environ.get("VLM_GRAD_COLLECTIVE", "allreduce"))
     # the embeddings' all-reduce overlaps the AdamW update of everything else (same wiring as run.py)
     reducer.attach(opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
     batch = synthetic_batch(args.batch, args.image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
@@ -459,6 +463,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss_val},
             # time the compute stream waits for the tail of the gradient all-reduce (rank 0), per step
             "exposed_comm_ms_per_step": exposed_comm_ms,
+            "grad_comm": {"dtype": "bf16" if reducer.comm_dtype is not None else "fp32", "collective": reducer.collective,
+                          "sharded_optimizer": reducer.sharded, "bytes_per_step": int(reducer.flat.numel) * (2 if reducer.comm_dtype is not None else 4)},
         }
         flop_per_sample = FLOP_PER_SAMPLE_384 if args.image_size == 384 else 657.5e9
         out["model_tflops"] = value * flop_per_sample / 1e12 / world

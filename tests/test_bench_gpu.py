@@ -57,11 +57,15 @@ def test_bench_gpus2_launches_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sharded", ["0", "1"])
-def test_bench_rccl_branch_at_world_one(sharded):
-    """VLM_BENCH_FORCE_DIST=1: the nccl (= RCCL) process group, the reducer's collectives (all-reduce, and with
-    VLM_SHARDED=1 reduce_scatter_tensor / all_gather_into_tensor) and the barrier-fenced timing run on the one device."""
-    r = _run_bench(SMALL, {"VLM_BENCH_FORCE_DIST": "1", "VLM_SHARDED": sharded})
+@pytest.mark.parametrize("env", [{"VLM_SHARDED": "0"}, {"VLM_SHARDED": "1"},
+                                 {"VLM_GRAD_COMM": "bf16", "VLM_GRAD_COLLECTIVE": "rs_ag"}])
+def test_bench_rccl_branch_at_world_one(env):
+    """VLM_BENCH_FORCE_DIST=1: the nccl (= RCCL) process group, the reducer's collectives (all-reduce; with VLM_SHARDED=1
+    reduce_scatter_tensor / all_gather_into_tensor; with VLM_GRAD_COMM=bf16 + VLM_GRAD_COLLECTIVE=rs_ag the bf16 wire
+    buffer through reduce-scatter + all-gather) and the barrier-fenced timing run on the one device."""
+    r = _run_bench(SMALL, dict(env, VLM_BENCH_FORCE_DIST="1"))
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["grad_comm"]["dtype"] == ("bf16" if env.get("VLM_GRAD_COMM") == "bf16" else "fp32")
+    assert d["grad_comm"]["collective"] == env.get("VLM_GRAD_COLLECTIVE", "allreduce")

@@ -89,6 +89,23 @@ def _worker(rank, world, port, q):
             c = (hi - lo) // world
             for r in range(world):
                 assert torch.all(m2._flat.flat_p[lo + r * c: lo + (r + 1) * c] == float(r + 1))
+        # ---- bf16 wire buffer: the bucket is cast, reduced in bf16 and widened back (comm_dtype option) -------------------
+        m3 = Tiny()
+        m3._flat = engine.FlatParams(m3, order_key=vu.flat_order_key)
+        red3 = ddp.FlatGradReducer(m3, comm_dtype=torch.bfloat16, collective="rs_ag")  # rs_ag needs nccl: falls back to all-reduce here
+        assert red3.comm_dtype is torch.bfloat16
+        vals = (1.2345, 2.3456)
+        for step in range(2):
+            red3.begin_step()
+            for p in m3.parameters():
+                p.grad.fill_(vals[rank])
+            for layer in (2, 2, 1, 0):
+                m3._grad_hook(layer)
+            red3.finish_backward()
+            want16 = (torch.tensor(vals[0]).to(torch.bfloat16) + torch.tensor(vals[1]).to(torch.bfloat16)).float()
+            for n, p in m3.named_parameters():
+                assert p.grad.dtype == torch.float32 and torch.all(p.grad == want16), (n, p.grad.flatten()[:2], want16)
+        assert red3._wire is not None and red3._wire.dtype == torch.bfloat16
         # a changed use count must be loud
         red.begin_step()
         m._grad_hook(2)
