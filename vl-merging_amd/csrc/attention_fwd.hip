@@ -25,6 +25,12 @@
 #ifndef ATT_FWD_WAVES
 #define ATT_FWD_WAVES 3
 #endif
+// Row sums: 1 = on the matrix pipe (one MFMA per 16 keys against an all-ones operand: the sum of the bf16-ROUNDED weights
+// that also enter P V, so every output row is an exact convex combination), 0 = fp32 adds on the vector pipe.  Same
+// speed (three waves per SIMD either way); 1 keeps the numerics the parity tolerances were measured with.
+#ifndef ATT_FWD_MFMA_ROWSUM_OFF
+#define ATT_FWD_MFMA_ROWSUM 1
+#endif
 #ifdef ATT_DIAG_STAMPS  // diagnostic builds only (tools/scratch/attn_bench.hip): s_memtime inside the tile loop
 __device__ unsigned long long att_stamps[8 * 64];
 #ifndef ATT_STAMP_BLOCK
