@@ -120,7 +120,8 @@ typedef struct {
 int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                   int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream);
 /* Which kernel serves ta = tb = 0 calls: 0 the 128x128 tile always, 1 by shape (default; VLM_GEMM_BIG in the environment),
- * 2 the 256x256 tile whenever the call is legal for it, -1 back to the environment.  Tests and benchmarks only. */
+ * 2 the 256x256 tile whenever the call is legal for it, 3 by shape with the last partial round of tiles handed to the
+ * 128x128 kernel as a second launch over the remaining rows, -1 back to the environment.  Tests and benchmarks only. */
 int vlm_gemm_set_big_tile_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------------

@@ -510,3 +510,37 @@ def test_gemm_big_tile_wgrad(ops, L, big_tile, M, N, K, accumulate):
     ops.gemm(A, B, c2[:M], ta=True, tb=True, alpha=0.01, accumulate=accumulate)
     if N % 256 == 0:  # N % 256 == 128 stays on the atomic split-K kernel, which is not required to be deterministic
         assert torch.equal(c2, got[2])
+
+
+@pytest.mark.parametrize("M,N,K", [(54296, 768, 768), (54296, 2304, 768), (54296, 768, 3072)])
+def test_gemm_tail_split_every_operand_offset(ops, L, big_tile, M, N, K):
+    """Big-tile mode 3 (the tail split, an option) at the 4B-pass shapes: whole rounds of 256x256 tiles on the big kernel, the remaining ROWS on the
+    128x128 kernel (639 tiles = 2.5 rounds -> 43 520 + 10 776 rows).  Every per-row operand of the second call is an
+    offset of the first call's: A, C, in-place fp32 residual, row scale, saved pre-activation (output and GELU' input)."""
+    L.check(big_tile.vlm_gemm_set_big_tile_mode(3), "mode")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    B = bf(torch.randn(N, K, device="cuda", generator=gen))
+    alpha = 1.0 / math.sqrt(K)
+    ref = (A.float() @ B.float().t()) * alpha
+    bias = torch.randn(N, device="cuda", generator=gen)
+    gamma = torch.randn(N, device="cuda", generator=gen) * 0.5
+    rs = (torch.rand(M, device="cuda", generator=gen) > 0.3).float() / 0.7
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    x = torch.full((M + 3, N), 7.0, device="cuda")
+    x[:M] = res
+    y = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, x[:M], bias=bias, col_scale=gamma, row_scale=rs, residual=x[:M], aux=y[:M], alpha=alpha)  # in place
+    assert_close(x[:M], res + rs[:, None] * gamma[None] * (ref + bias), 1e-3, 5e-3, "residual stream")
+    assert_close(y[:M], ref + bias, 1e-2, 2e-2, "branch copy")
+    assert float((x[M:] - 7.0).abs().max()) == 0.0 and float((y[M:].float() - 7.0).abs().max()) == 0.0
+    hpre = bf(torch.randn(M, N, device="cuda", generator=gen))
+    o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(A, B, o[:M], act=L.ACT_GELU_BWD, aux=hpre, alpha=alpha)
+    hh = hpre.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward(ref)
+    assert_close(o[:M], hh.grad, 1e-2, 2e-2, "gelu backward")
+    assert float((o[M:].float() - 7.0).abs().max()) == 0.0
+    # the rows on either side of the split (43 520 for N = 768, 50 944 for N = 2304) come from different kernels
+    cut = {768: 43520, 2304: 50944}[N]
+    assert_close(o[cut - 4:cut + 4], hh.grad[cut - 4:cut + 4], 1e-2, 2e-2, "rows around the split")

@@ -1276,7 +1276,7 @@ static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStr
   return 1;
 }
 
-// VLM_GEMM_BIG: 0 = never, 1 = by shape (default), 2 = whenever the kernel is legal (tests); vlm_gemm_set_big_tile_mode
+// VLM_GEMM_BIG: 0 = never, 1 = by shape (default), 2 = whenever the kernel is legal (tests), 3 = by shape with the tail split; vlm_gemm_set_big_tile_mode
 // overrides the environment (tests compare the two kernels in one process), -1 returns to it
 static std::atomic<int> g_big_mode{-1};  // -1: follow the environment
 static int gemm_big_mode() {
@@ -1290,7 +1290,7 @@ static int gemm_big_mode() {
   return env_mode;
 }
 extern "C" int vlm_gemm_set_big_tile_mode(int mode) {
-  if (mode < -1 || mode > 2) return VLM_ERR_ARG;
+  if (mode < -1 || mode > 3) return VLM_ERR_ARG;
   g_big_mode.store(mode, std::memory_order_relaxed);
   return VLM_OK;
 }
@@ -1341,8 +1341,16 @@ static int dispatch_stage(const gemm_params_t& p, hipStream_t s) {
   return launch_gemm<TA, TB, OUT_F32, false, false, false>(p, s);
 }
 
+static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                         int c_is_f32, const vlm_epilogue_t* epi, void* stream, bool allow_big);
+
 extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                              void* C, int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream) {
+  return gemm_dispatch(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, epi, stream, true);
+}
+
+static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                         int c_is_f32, const vlm_epilogue_t* epi, void* stream, bool allow_big) {
   if (M < 0 || N < 0 || K < 0 || !C) return VLM_ERR_ARG;
   if (M == 0 || N == 0) return VLM_OK;
   if (!A || !B || !epi) return VLM_ERR_ARG;
@@ -1425,7 +1433,7 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
       return launch_gemm<true, true, true, false, false, true>(p, s);
     }
   }
-  if (!ta && !tb && (K % (4 * BIG_BK)) == 0 && gemm_big_mode() > 0) {
+  if (allow_big && !ta && !tb && (K % (4 * BIG_BK)) == 0 && gemm_big_mode() > 0) {
     const long big_tiles = (long)((M + BIG_BM - 1) / BIG_BM) * ((N + BIG_BN - 1) / BIG_BN);
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;
@@ -1435,6 +1443,37 @@ extern "C" int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A,
     const bool ws_ok = (N % BIG_BN) == 0 && p.epi.reserved == 1 && off32 && !epi->accumulate;  // no column bound in the epilogue
     // measured (tools/bench_gemm.py, M = 13 574 and 54 296): ahead of the 128x128 kernel from half a round of tiles up
     if (ws_ok && (gemm_big_mode() >= 2 || 2 * big_tiles >= cus)) {
+      // Tail split (OFF by default; VLM_GEMM_TAIL_SPLIT=1 or big-tile mode 3): one workgroup per CU means whole ROUNDS of
+      // `cus` tiles; 639 tiles (M = 54 296, N = 768) are 2.5 rounds and the last half round idles half the chip for a full
+      // tile time.  With the split the whole rounds run on this kernel and the remaining ROWS go to the 128x128 kernel (two
+      // workgroups per CU, shorter tiles: 10 776 rows x 768 = 510 tiles = one round of it).  Standalone, plain bf16 outputs:
+      // proj forward 82.7 -> 76.3 us, fc2 forward 269.5 -> 245.6 us (-8 / -9 %).  In the training step, where these calls
+      // carry the fp32 residual-stream epilogue, the 128x128 part costs 41 us per call: kernel time -0.4 %, step rate
+      // -0.4 % (522 more launches per 6 steps) in two A/B pairs on one box -- not adopted.
+      static const int tail_split_env = [] {
+        const char* e = getenv("VLM_GEMM_TAIL_SPLIT");
+        return e ? atoi(e) : 0;
+      }();
+      const bool tail_split = (tail_split_env && gemm_big_mode() == 1) || gemm_big_mode() == 3;
+      const long full = big_tiles / cus, rem = big_tiles - full * cus, tn = (N + BIG_BN - 1) / BIG_BN;
+      const long rows_big = (full * cus / tn) * BIG_BM;
+      if (tail_split && full >= 1 && rem > 0 && rem * 10 <= (long)cus * 6 && !epi->col_sum &&
+          rows_big > 0 && rows_big < M) {
+        gemm_params_t p1 = p;
+        p1.M = (int)rows_big;
+        const int rc = launch_gemm_big_variant(p1, c_is_f32 != 0, s);
+        if (rc <= 0) {
+          if (rc < 0) return rc;
+          vlm_epilogue_t e2 = *epi;
+          const size_t r0 = (size_t)rows_big;
+          if (e2.residual) e2.residual += r0 * e2.ld_res;
+          if (e2.aux) e2.aux = reinterpret_cast<unsigned char*>(e2.aux) + r0 * e2.ld_aux * 2;
+          if (e2.row_scale) e2.row_scale += r0;
+          return gemm_dispatch(0, 0, M - (int)rows_big, N, K, reinterpret_cast<const unsigned char*>(A) + r0 * lda * 2, lda, B, ldb,
+                               reinterpret_cast<unsigned char*>(C) + r0 * ldc * (c_is_f32 ? 4 : 2), ldc, c_is_f32, &e2, stream,
+                               /*allow_big=*/false);
+        }
+      }
       const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, s);
       if (rc <= 0) return rc;
     }
