@@ -544,3 +544,19 @@ def test_gemm_tail_split_every_operand_offset(ops, L, big_tile, M, N, K):
     # the rows on either side of the split (43 520 for N = 768, 50 944 for N = 2304) come from different kernels
     cut = {768: 43520, 2304: 50944}[N]
     assert_close(o[cut - 4:cut + 4], hh.grad[cut - 4:cut + 4], 1e-2, 2e-2, "rows around the split")
+
+
+def test_embedding_bwd_matches_torch(ops):
+    """vlm_embedding_bwd against torch's embedding backward (padding index skipped, repeated ids summed, accumulation)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    V, D, n = 1000, 768, 4400
+    ids = torch.randint(0, V, (n,), device="cuda", generator=gen)
+    ids[::7] = 0          # padding tokens
+    ids[1::5] = 17        # a heavily repeated id
+    gy = torch.randn(n, D, device="cuda", generator=gen)
+    w = torch.zeros(V, D, device="cuda", requires_grad=True)
+    torch.nn.functional.embedding(ids, w, padding_idx=0).backward(gy)
+    got = torch.full((V, D), 0.25, device="cuda")
+    ops.embedding_bwd(gy, ids, got, padding_idx=0)
+    assert_close(got - 0.25, w.grad, 1e-5, 1e-4, "embedding backward")
+    assert float((got[0] - 0.25).abs().max()) == 0.0  # the padding row receives nothing

@@ -40,13 +40,14 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-ev = prof.key_averages()
+ev = prof.key_averages(group_by_input_shape=True)
+ev = [e for e in ev if e.key.startswith("aten::")]
 rows = sorted(ev, key=lambda e: -e.self_device_time_total)
 tot = sum(e.self_device_time_total for e in ev)
 print("total device time %.2f ms over 2 steps" % (tot / 1e3))
 for e in rows[:45]:
-    print("%-64s n=%5d  dev %8.1f us  (%.2f%%)" % (e.key[:64], e.count, e.self_device_time_total, 100.0 * e.self_device_time_total / tot))
+    print("%-28s n=%4d  dev %8.1f us  %s" % (e.key[:28], e.count, e.self_device_time_total, str(e.input_shapes)[:110]))

@@ -102,6 +102,8 @@ SIGNATURES = {
     "vlm_potrf_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlm_trsm_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
+    "vlm_embedding_bwd": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int,
+                                  ctypes.c_int64, c_void_p]),
     "vlm_bias_dense_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vlm_bias_dense": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p]),

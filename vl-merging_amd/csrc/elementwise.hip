@@ -138,6 +138,35 @@ extern "C" int vlm_cast_f32_bf16(const float* src, void* dst, uint64_t n, void* 
   return VLM_OK;
 }
 
+// Backward of the word-embedding gather (BertEmbeddings.word_embeddings, vilt_module.py:63 / :1090: nn.Embedding with
+// padding_idx = 0): dW[ids[t], :] += gy[t, :] for every token t whose id is not the padding index.  torch's
+// embedding_dense_backward sorts the ids and builds a dense [vocab, D] gradient that autograd then adds to .grad (0.5 ms per
+// step for 4 400 tokens); here one wave per token adds its row straight into the flat gradient buffer (float atomics on
+// 256-B segments: the full-rate shape).
+__global__ __launch_bounds__(EW_THREADS) void embedding_bwd_kernel(const float* __restrict__ gy, int ld, const int64_t* __restrict__ ids,
+                                                                   int64_t n, int D, int64_t pad, float* __restrict__ dW, int ld_w) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t t = (int64_t)blockIdx.x * (EW_THREADS / 64) + wave; t < n; t += (int64_t)gridDim.x * (EW_THREADS / 64)) {
+    const int64_t id = ids[t];
+    if (id == pad) continue;  // wave-uniform
+    const float* src = gy + t * ld;
+    float* dst = dW + id * ld_w;
+    for (int c = lane; c < D; c += 64) atomicAdd(dst + c, src[c]);
+  }
+}
+
+extern "C" int vlm_embedding_bwd(const float* gy, int ld, const int64_t* ids, int64_t n, int D, int64_t padding_idx, float* dW,
+                                 int ld_w, int64_t vocab, void* stream) {
+  if (n == 0 || D == 0) return VLM_OK;
+  if (!gy || !ids || !dW || n < 0 || D < 0 || ld < D || ld_w < D || vocab <= 0) return VLM_ERR_ARG;
+  int64_t blocks = (n + (EW_THREADS / 64) - 1) / (EW_THREADS / 64);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, gy, ld, ids, n, D,
+                     padding_idx, dW, ld_w);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
 // DropPath row scales (timm drop_path as used at vision_transformer.py:586,:603): per-sample bernoulli(keep)/keep
 // expanded to the segment-major token rows of a pass; u holds one uniform [0,1) draw per sample.
 __global__ __launch_bounds__(EW_THREADS) void droppath_rows_kernel(const float* __restrict__ u, float keep, float inv_keep,

@@ -244,6 +244,7 @@ class _TableT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         acc = ctx.holder.pop("dbias_t", None)
+        ctx.holder.pop("routed", None)
         if acc is None:
             return g.t(), None
         return (acc + g).t(), None
@@ -575,8 +576,10 @@ class _BlockFn(torch.autograd.Function):
         if ctx.hook is not None:
             ctx.hook(plan.layer)
         dbias = None
-        if bias_t is not None and ctx.needs_input_grad[1]:
-            # the real gradient sits in relpos.holder["dbias_t"]; autograd only needs a defined tensor to route
+        if bias_t is not None and ctx.needs_input_grad[1] and rp is not None and not rp.holder.get("routed"):
+            # the real gradient sits in relpos.holder["dbias_t"]; autograd only needs ONE defined tensor per table handle to
+            # reach _TableT.backward (a zero from every block evaluation cost 22 [144, R] additions per step)
+            rp.holder["routed"] = True
             dbias = torch.zeros((), device=dev, dtype=F32).expand_as(bias_t)
         return dx, dbias, None, None, None, None
 
@@ -678,6 +681,35 @@ class _LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, eps, out_f32=False):
     return _LayerNormFn.apply(x, weight, bias, eps, out_f32)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding gather (BertEmbeddings.word_embeddings, vilt_module.py:63) whose backward adds the token rows straight
+    into the flat gradient buffer instead of torch's sort + dense [vocab, D] gradient + accumulate."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.weight, ctx.padding_idx = weight, padding_idx
+        return torch.nn.functional.embedding(ids, weight.detach())
+
+    @staticmethod
+    def backward(ctx, gy):
+        (ids,) = ctx.saved_tensors
+        w = ctx.weight
+        if w.requires_grad:
+            touch(w)
+            g2 = gy.reshape(-1, gy.shape[-1])
+            if g2.dtype != F32 or g2.stride(1) != 1:
+                g2 = g2.float().contiguous()
+            ops.embedding_bwd(g2, ids.reshape(-1).contiguous(), w.grad, -1 if ctx.padding_idx is None else ctx.padding_idx)
+        return None, None, None
+
+
+def embedding(ids, weight, padding_idx=None):
+    if getattr(weight, "_vlm_flat", None) is None or not weight.is_cuda:
+        return torch.nn.functional.embedding(ids, weight, padding_idx=padding_idx)  # not flattened (CPU construction)
+    return _EmbeddingFn.apply(ids, weight, padding_idx)
 
 
 class _PatchEmbedFn(torch.autograd.Function):

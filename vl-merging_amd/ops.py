@@ -179,6 +179,16 @@ def layerscale_bwd(dx, y, gamma, row_scale, dy, dgamma=None, dbias=None, fold=No
     return dy
 
 
+def embedding_bwd(gy, ids, dW, padding_idx=-1):
+    """dW[ids[t]] += gy[t] (fp32) for ids[t] != padding_idx: backward of an nn.Embedding gather into the flat gradient."""
+    L.require_cuda(gy, ids, dW)
+    n, D = gy.shape
+    assert gy.dtype == F32 and dW.dtype == F32 and ids.dtype == torch.int64 and ids.numel() == n and gy.stride(1) == 1
+    L.check(L.get_lib().vlm_embedding_bwd(L.ptr(gy), _ld(gy), L.ptr(ids), n, D, int(padding_idx), L.ptr(dW), _ld(dW),
+                                          dW.shape[0], L.stream_ptr()), "vlm_embedding_bwd")
+    return dW
+
+
 def colsum(a, out):
     """out[n] += sum_m a[m,n]  (a bf16)."""
     L.require_cuda(a, out)

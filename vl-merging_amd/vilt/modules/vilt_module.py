@@ -38,7 +38,8 @@ class BertEmbeddings(nn.Module):
         self.register_buffer("position_ids", torch.arange(max_position_embeddings).expand((1, -1)).clone())
 
     def forward(self, input_ids):
-        emb = self.word_embeddings(input_ids) + self.token_type_embeddings.weight[0]
+        we = self.word_embeddings
+        emb = engine.embedding(input_ids, we.weight, we.padding_idx) + self.token_type_embeddings.weight[0]
         emb = engine.layer_norm(emb, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, out_f32=True)
         return self.dropout(emb)
 
