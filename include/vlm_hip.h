@@ -83,6 +83,9 @@ int vlm_merge_run(const void* workspace, void* stream);
  *   act = NONE/GELU : if aux != NULL, aux[m,n] = bf16(v) (pre-activation / pre-LayerScale branch output)
  *         GELU      : v = gelu_erf(v)               (vision_transformer.py:292, exact erf GELU)
  *         GELU_BWD  : v = v * gelu_erf'(aux[m,n])   (aux is an INPUT: the saved pre-activation)
+ *         GELU_DERIV: aux[m,n] = bf16(gelu_erf'(v)); v = gelu_erf(v)   (aux REQUIRED: the forward pass saves the derivative --
+ *                     one erf / exp evaluation serves both -- so that the backward epilogue is a multiplication)
+ *         MUL_AUX   : v = v * aux[m,n]              (aux is an INPUT: the derivative GELU_DERIV saved)
  *   out = residual[m,n] + row_scale[m] * col_scale[n] * v     (each factor optional)
  *   C   = out  (bf16 or f32)  or  C += out (f32, accumulate != 0)
  *   col_sum[n] += sum_m C[m,n] (optional, fp32 atomics, value before the bf16 rounding): the bias gradient of the
@@ -93,6 +96,8 @@ int vlm_merge_run(const void* workspace, void* stream);
 #define VLM_ACT_NONE 0
 #define VLM_ACT_GELU 1
 #define VLM_ACT_GELU_BWD 2
+#define VLM_ACT_GELU_DERIV 3
+#define VLM_ACT_MUL_AUX 4
 
 typedef struct {
   const float* bias;       /* f32 [N] or NULL */

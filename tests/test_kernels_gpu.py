@@ -560,3 +560,38 @@ def test_embedding_bwd_matches_torch(ops):
     ops.embedding_bwd(gy, ids, got, padding_idx=0)
     assert_close(got - 0.25, w.grad, 1e-5, 1e-4, "embedding backward")
     assert float((got[0] - 0.25).abs().max()) == 0.0  # the padding row receives nothing
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(13574, 3072, 768, 1), (13574, 3072, 768, 0), (880, 3072, 768, 1), (333, 1000, 128, 1)])
+def test_gemm_gelu_saved_derivative(ops, L, big_tile, M, N, K, mode):
+    """VLM_ACT_GELU_DERIV / VLM_ACT_MUL_AUX: the forward epilogue returns gelu(v) and saves bf16(gelu'(v)); the backward
+    epilogue multiplies by it.  Same outputs as ACT_GELU, and the same dh as ACT_GELU_BWD on the saved pre-activation up to
+    the bf16 rounding of either saved tensor -- on both kernels (mode 1: by shape, 0: 128x128 always) and a ragged N."""
+    L.check(big_tile.vlm_gemm_set_big_tile_mode(mode), "mode")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    B = bf(torch.randn(N, K, device="cuda", generator=gen))
+    bias = torch.randn(N, device="cuda", generator=gen) * 0.1
+    alpha = 2.0 / math.sqrt(K)
+    ref = (A.float() @ B.float().t()) * alpha + bias
+    Np = (N + 7) // 8 * 8
+    a0 = torch.empty(M, Np, device="cuda", dtype=torch.bfloat16)[:, :N]
+    h0 = torch.empty(M, Np, device="cuda", dtype=torch.bfloat16)[:, :N]
+    a1 = torch.empty(M, Np, device="cuda", dtype=torch.bfloat16)[:, :N]
+    d1 = torch.empty(M, Np, device="cuda", dtype=torch.bfloat16)[:, :N]
+    ops.gemm(A, B, a0, bias=bias, act=L.ACT_GELU, aux=h0, alpha=alpha)
+    ops.gemm(A, B, a1, bias=bias, act=L.ACT_GELU_DERIV, aux=d1, alpha=alpha)
+    assert torch.equal(a0, a1)                                   # the same gelu, bit for bit
+    x = ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(torch.ones_like(x))
+    assert_close(d1, x.grad, 1e-2, 1e-2, "saved gelu'")            # bf16 of the exact derivative
+    # backward: dh = (dY W) * gelu'  -- from the saved derivative and from the saved pre-activation
+    if N % 8 == 0:
+        dy = bf(torch.randn(M, K, device="cuda", generator=gen))   # reuse shapes: "dY" [M,K] x "W^T" [N,K]
+        o_old = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        o_new = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm(dy, B, o_old, act=L.ACT_GELU_BWD, aux=h0, alpha=alpha)
+        ops.gemm(dy, B, o_new, act=L.ACT_MUL_AUX, aux=d1, alpha=alpha)
+        want = (dy.float() @ B.float().t()) * alpha * x.grad
+        assert_close(o_new, want, 1e-2, 2e-2, "dh from the saved derivative")
+        assert_close(o_old, want, 1e-2, 2e-2, "dh from the saved pre-activation")

@@ -46,7 +46,7 @@ class AttnColsum(ctypes.Structure):
     _fields_ = [("dq", c_void_p * 2), ("dv", c_void_p * 2)]
 
 
-ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_DERIV, ACT_MUL_AUX = 0, 1, 2, 3, 4
 ATTN_JOINT, ATTN_SEPARATE = 0, 1
 
 

@@ -55,6 +55,18 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
   return fmaf(x * 0.39894228040143267794f, ez2, cdf);
 }
+// gelu(x) and gelu'(x) from ONE erf / exp evaluation (VLM_ACT_GELU_DERIV: the forward epilogue saves the derivative, so the
+// backward epilogue is a multiplication instead of 1 rcp + 1 exp + ~14 VALU operations per element)
+__device__ __forceinline__ float gelu_erf_both(float x, float& deriv) {
+  float ez2;
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
+  deriv = fmaf(x * 0.39894228040143267794f, ez2, cdf);
+  return x * cdf;
+}
+// factor of the two backward activations: the saved derivative itself, or gelu' of the saved pre-activation
+__device__ __forceinline__ float act_bwd_factor(int act, float saved) {
+  return act == VLM_ACT_MUL_AUX ? saved : gelu_erf_grad(saved);
+}
 
 // ---- global -> register -> LDS staging (kept for K-strided operands, where it measured faster than LDS-DMA) ------
 template <bool KSTRIDED>
@@ -187,7 +199,7 @@ __device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4
     //     dwordx4 stores and every aux / residual / bias read is 16 B wide;
     // (2) the residual may alias C (in-place residual stream): all epilogue inputs of a 16-row block are fetched
     //     before anything is stored, instead of 16 dependent load->store round trips.
-    const bool has_res = e.residual != nullptr, bwd = e.act == VLM_ACT_GELU_BWD, accum = OUT_F32 && e.accumulate;
+    const bool has_res = e.residual != nullptr, bwd = e.act == VLM_ACT_GELU_BWD || e.act == VLM_ACT_MUL_AUX, accum = OUT_F32 && e.accumulate;
     const int g = lane >> 4;
     const int nl = nw0 + (g & 1) * 16 + (g >> 1) * 8;  // + 32*jp
     float bia[2][8], gam[2][8], csum[2][8];
@@ -250,7 +262,16 @@ __device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4
           for (int r = 0; r < 8; ++r) v[r] += bia[jp][r];
           if (bwd) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)hx[ii][jp][r]);
+            for (int r = 0; r < 8; ++r) v[r] *= act_bwd_factor(e.act, (float)hx[ii][jp][r]);
+          } else if (e.act == VLM_ACT_GELU_DERIV) {
+            bf16x8 h;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              float dg;
+              v[r] = gelu_erf_both(v[r], dg);
+              h[r] = (bf16_t)dg;
+            }
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(e.aux) + m * e.ld_aux + n) = h;
           } else {
             if (e.aux) {
               bf16x8 h;
@@ -345,10 +366,19 @@ __device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += b[r];
         }
-        if (e.act == VLM_ACT_GELU_BWD) {
+        if (e.act == VLM_ACT_GELU_BWD || e.act == VLM_ACT_MUL_AUX) {
           const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)h[r]);
+          for (int r = 0; r < 4; ++r) v[r] *= act_bwd_factor(e.act, (float)h[r]);
+        } else if (e.act == VLM_ACT_GELU_DERIV) {
+          bf16x4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float dg;
+            v[r] = gelu_erf_both(v[r], dg);
+            h[r] = (bf16_t)dg;
+          }
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(e.aux) + (size_t)m * e.ld_aux + n) = h;
         } else {
           if (e.aux) {
             bf16x4 h;
@@ -401,8 +431,12 @@ __device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
           float x = v[r];
           if (e.bias) x += e.bias[n + r];
-          if (e.act == VLM_ACT_GELU_BWD) {
-            x *= gelu_erf_grad((float)reinterpret_cast<const bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r]);
+          if (e.act == VLM_ACT_GELU_BWD || e.act == VLM_ACT_MUL_AUX) {
+            x *= act_bwd_factor(e.act, (float)reinterpret_cast<const bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r]);
+          } else if (e.act == VLM_ACT_GELU_DERIV) {
+            float dg;
+            x = gelu_erf_both(x, dg);
+            reinterpret_cast<bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r] = (bf16_t)dg;
           } else {
             if (e.aux) reinterpret_cast<bf16_t*>(e.aux)[(size_t)m * e.ld_aux + n + r] = (bf16_t)x;
             if (e.act == VLM_ACT_GELU) x = gelu_erf(x);
@@ -793,8 +827,22 @@ struct big_epilogue_t {
         v[4 + r] = hi[r] * e.alpha + bia[4 + r];
       }
       if (bwd) {
+        if (e.act == VLM_ACT_MUL_AUX) {  // the forward pass saved gelu' itself (wave-uniform branch)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)in.hx[t][r]);
+          for (int r = 0; r < 8; ++r) v[r] *= (float)in.hx[t][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)in.hx[t][r]);
+        }
+      } else if (AUX == 1 && e.act == VLM_ACT_GELU_DERIV) {
+        bf16x8 h;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float dg;
+          v[r] = gelu_erf_both(v[r], dg);
+          h[r] = (bf16_t)dg;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), r_aux, (m * (uint32_t)e.ld_aux + n) * 2, 0, EPIL_AUX_STORE_AUX);
       } else {
         if (AUX == 1) {
           bf16x8 h;
@@ -1262,7 +1310,7 @@ static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
 static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStream_t s) {
   const vlm_epilogue_t& e = p.epi;
   const bool res = e.residual != nullptr;
-  const int aux = e.aux ? (e.act == VLM_ACT_GELU_BWD ? 2 : 1) : 0;
+  const int aux = e.aux ? ((e.act == VLM_ACT_GELU_BWD || e.act == VLM_ACT_MUL_AUX) ? 2 : 1) : 0;
   if (e.row_scale && !res) return 1;
   if (!c_is_f32 && !res) {
     if (aux == 0) return launch_gemm_big<false, false, 0>(p, s);
@@ -1360,7 +1408,8 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
   if ((!ta || !tb) && (K % GEMM_BK)) return VLM_ERR_UNSUPPORTED;
   if (((ldc & 3) == 0) && ((uintptr_t)C & 15)) return VLM_ERR_ARG;
   if (epi->accumulate && !c_is_f32) return VLM_ERR_ARG;
-  if (epi->act == VLM_ACT_GELU_BWD && !epi->aux) return VLM_ERR_ARG;
+  if ((epi->act == VLM_ACT_GELU_BWD || epi->act == VLM_ACT_MUL_AUX || epi->act == VLM_ACT_GELU_DERIV) && !epi->aux) return VLM_ERR_ARG;
+  if (epi->act < VLM_ACT_NONE || epi->act > VLM_ACT_MUL_AUX) return VLM_ERR_ARG;
   if (epi->col_sum_ws && (!epi->col_sum || (N % GEMM_BN) != 0 || ta)) return VLM_ERR_ARG;
   const uint64_t a_bytes = (uint64_t)(ta ? K : M) * lda * 2, b_bytes = (uint64_t)(tb ? K : N) * ldb * 2;
   if (a_bytes >= (1ull << 31) || b_bytes >= (1ull << 31)) return VLM_ERR_UNSUPPORTED;

@@ -388,6 +388,7 @@ class GramCapture:
 # through the GELU-backward GEMM epilogue + fold workspace
 _DEFER_FOLD = os.environ.get("VLM_DEFER_FOLD", "1") != "0"
 _DENSE_BIAS = True  # the attention kernels always read the dense table (round 2: bias enters through the matrix pipe)
+_SAVE_DERIV = os.environ.get("VLM_GELU_SAVE_DERIV", "1") != "0"  # fc1 saves gelu'(h) instead of h for the backward pass
 _FUSE_MODE = int(os.environ.get("VLM_FUSE_BIAS_GRADS", "2"))
 _FUSE_BIAS_GRADS = _FUSE_MODE != 0
 _FUSE_FC1_BIAS = _FUSE_MODE in (1, 2)  # through the fold workspace (mode 0: separate colsum launch)
@@ -470,7 +471,10 @@ class _BlockFn(torch.autograd.Function):
         y2 = torch.empty(M, D, device=dev, dtype=BF16)
         for r0, r1, e in plan.ranges:
             ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
-            ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b, act=L.ACT_GELU, aux=h[r0:r1])
+            # h = gelu'(pre-activation) (VLM_GELU_SAVE_DERIV, default): the forward epilogue has erf and exp in hand anyway,
+            # and the fc2-dgrad epilogue of the backward pass becomes a multiplication
+            ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b, act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU,
+                     aux=h[r0:r1])
             ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
                      row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
         if pc.gram is not None:
@@ -529,7 +533,8 @@ class _BlockFn(torch.autograd.Function):
             # fc1 bias gradient = column sums of dh: per-tile sums from the epilogue that produces dh, folded with the
             # block's other column partials (no atomics, no second pass over dh); without a fold batch: colsum kernel
             fuse_b1 = _FUSE_FC1_BIAS and fold is not None
-            _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_GELU_BWD, aux=h[rr], col_sum=e.fc1b.grad if fuse_b1 else None,
+            _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_MUL_AUX if _SAVE_DERIV else L.ACT_GELU_BWD, aux=h[rr],
+                   col_sum=e.fc1b.grad if fuse_b1 else None,
                    col_sum_fold=fold if fuse_b1 else None)
             if not fuse_b1:
                 ops.colsum(dh[rr], e.fc1b.grad)
