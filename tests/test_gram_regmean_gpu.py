@@ -196,3 +196,32 @@ def test_engine_grams_feed_regmean_like_reference_grams(mods, golden_dir):
             assert err <= 2e-2 * scale, (k, err, scale)
             n += 1
     assert n == 48
+
+
+def test_regmean_non_positive_definite_gram_falls_back_like_the_reference(pkg):
+    """scaling_for_non_diag = 1 with a Gram sum that has no Cholesky factor (numerically indefinite: a Gram of few capture
+    batches).  The reference's torch.inverse (LU) still returns a result (vilt_module.py:432); the device path must not
+    abort the merge: it warns and uses a general float64 inverse -- same W* as num @ inverse(den) in numpy float64."""
+    import warnings
+    rm = importlib.import_module("vl_merging_amd.regmean")
+    g = torch.Generator().manual_seed(5)
+    D, O = 128, 96
+    A = torch.randn(D, D, generator=g, dtype=torch.float64)
+    spd = A @ A.t() / D + 0.5 * torch.eye(D, dtype=torch.float64)
+    evals, evecs = torch.linalg.eigh(spd)
+    evals[0] = -0.05                                   # one slightly negative eigenvalue: invertible, not positive definite
+    den = (evecs * evals) @ evecs.t()
+    den = 0.5 * (den + den.t())
+    num = torch.randn(O, D, generator=g, dtype=torch.float64)
+    want = num.numpy() @ np.linalg.inv(den.numpy())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = rm._solve(num.cuda().contiguous(), den.cuda().contiguous(), "test.weight")
+    assert any("not positive definite" in str(x.message) for x in w)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-8, atol=1e-9)
+    # a positive definite sum takes the Cholesky path silently and agrees too
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        got2 = rm._solve(num.cuda().contiguous(), spd.cuda().contiguous(), "test.weight")
+    assert not w2
+    np.testing.assert_allclose(got2.cpu().numpy(), num.numpy() @ np.linalg.inv(spd.numpy()), rtol=1e-8, atol=1e-9)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace stats + three separate PMC passes over the SAME bench command, condensed into
 # gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: tools/profile_round.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

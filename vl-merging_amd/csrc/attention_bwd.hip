@@ -784,6 +784,12 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
     bp.dv_colsum[sgm] = colsum ? colsum->dv[sgm] : nullptr;
   }
 
+  // every argument is validated BEFORE the first launch (a rejected call leaves the stream untouched)
+  if ((size_t)p.total_rows * p.ld_qkv * 2 >= (1ull << 32) || (size_t)p.total_rows * ld_dout * 2 >= (1ull << 32)) return VLM_ERR_UNSUPPORTED;
+  if (p.bias_t && (!p.dense || !p.dense_t)) return VLM_ERR_ARG;  // biased attention runs on the dense tables (vlm_bias_dense)
+  if (p.dense && p.dense_tiles != att_dense_layout(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode).tiles) return VLM_ERR_ARG;
+  if (ws_floats < (size_t)p.H * p.total_rows) return VLM_ERR_WORKSPACE;  // delta[h][row]
+  if (p.bias_t && dbias_t && ((size_t)p.R * 4 > 16 * ATT_TILE_BYTES || !p.idx_t)) return VLM_ERR_UNSUPPORTED;  // the histogram lives in the tile LDS
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;
   int dg = (p.total_rows + 3) / 4;
@@ -792,9 +798,6 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
                      ld_dout, p.total_rows, p.H, delta_ws);
   VLM_CHECK_LAUNCH();
 
-  if ((size_t)p.total_rows * p.ld_qkv * 2 >= (1ull << 32) || (size_t)p.total_rows * ld_dout * 2 >= (1ull << 32)) return VLM_ERR_UNSUPPORTED;
-  if (p.bias_t && (!p.dense || !p.dense_t)) return VLM_ERR_ARG;  // biased attention runs on the dense tables (vlm_bias_dense)
-  if (p.dense && p.dense_tiles != att_dense_layout(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode).tiles) return VLM_ERR_ARG;
   const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
   dim3 grid(att_grid_size(nt, p.seq.B, p.H)), block(ATT_THREADS);
   if (p.bias_t) {
@@ -803,7 +806,6 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, s, bp);
     if (dbias_t) {
       VLM_CHECK_LAUNCH();
-      if ((size_t)p.R * 4 > 16 * ATT_TILE_BYTES || !p.idx_t) return VLM_ERR_UNSUPPORTED;  // the histogram lives in the tile LDS
       // work items: every (128-key tile, 128-query tile of its span) pair x heads x sample groups; the samples are cut
       // into groups until the grid has ~3 items per CU (the per-item histogram is the price of every extra group)
       int pairs, groups;

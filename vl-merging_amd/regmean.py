@@ -20,6 +20,25 @@ def scale_gram(G, alpha):
     return alpha * G + (1 - alpha) * torch.diag_embed(torch.diag(G))
 
 
+def _solve(num, den, what):
+    """W* = num @ inverse(den) (:432-434), float64, on the device.  The sum of a*G + (1-a)*diag(G) over SPD Gram matrices is
+    SPD, so the product path is a blocked Cholesky factorisation + two triangular solves.  A Gram sum that is rank-deficient
+    or numerically indefinite (few capture batches: fewer rows than columns for fc2, scaling_for_non_diag = 1) has no
+    Cholesky factor, while the reference's LU-based torch.inverse still returns a result: that case falls back, loudly, to a
+    general float64 inverse on the device (torch.linalg.inv = hipSOLVER) followed by the MFMA-f64 product."""
+    keep = den.clone()  # cholesky_ works in place
+    try:
+        return ops.solve_spd_right_(num, ops.cholesky_(den))
+    except L.VlmError as e:
+        if "positive definite" not in str(e):
+            raise
+        import warnings
+        warnings.warn("regmean: the Gram sum of %s is not positive definite (%s); using a general inverse like the "
+                      "reference's torch.inverse" % (what, e))
+        inv = torch.linalg.inv(keep).contiguous()
+        return ops.gemm_f64(num, inv, torch.empty_like(num))
+
+
 def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None):
     out = M._passthrough(state_dict)
     if gram_matrices is None:
@@ -62,8 +81,7 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
             elif num is None:
                 out[dst] = 0  # the reference's untouched accumulator (no modality had a gram; does not occur in practice)
             else:
-                # W* = num @ inverse(den) (:432-434), as a Cholesky solve; stays float64 in the returned dict
-                out[dst] = ops.solve_spd_right_(num, ops.cholesky_(den))
+                out[dst] = _solve(num, den, dst)
     if plan.jobs:
         plan.run()
     if plan_out is not None:
