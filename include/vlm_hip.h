@@ -150,7 +150,7 @@ int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, i
                       const float* gamma, int M, int D, const float* dres, int lddres, float* dx, int lddx,
                       float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes, int* deferred_blocks,
                       void* stream);
-#define VLM_MAX_FOLD_JOBS 8
+#define VLM_MAX_FOLD_JOBS 16
 typedef struct {
   const float* partials; /* workspace written by a deferred row kernel: [nblocks][2][D] */
   int32_t nblocks;

@@ -184,6 +184,53 @@ class _Side:
         return False
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# modality experts on two streams: in an all_moe block the text rows (B*40) and the image rows (B*577) go through DIFFERENT
+# weights, so each expert's chain (LayerNorm -> GEMM ...) is an independent sequence of launches.  The text GEMMs are small
+# (M = 3 520: 168-504 tiles of 128x128 on 512 slots) and ran at a third of the image GEMMs' rate, 9.6 % of the all_moe step for
+# 6.5 % of its rows; issued on a second HIP stream they fill the CUs the image expert's last partial round of tiles leaves
+# idle.  Fork / join per phase (VLM_EXPERT_STREAMS=0 switches it off).
+_EXPERTS = {"stream": None, "enabled": os.environ.get("VLM_EXPERT_STREAMS", "1") != "0"}
+
+
+class _ExpertStreams:
+    def __init__(self, ranges):
+        self.side = None
+        self.small = -1
+        if _EXPERTS["enabled"] and len(ranges) > 1:
+            if _EXPERTS["stream"] is None:
+                _EXPERTS["stream"] = torch.cuda.Stream()
+            self.side = _EXPERTS["stream"]
+            sizes = [r1 - r0 for r0, r1, _ in ranges]
+            self.small = sizes.index(min(sizes))  # the smallest row range (text) goes to the side stream
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+        return self
+
+    def on(self, idx):
+        if self.side is not None and idx == self.small:
+            return torch.cuda.stream(self.side)
+        return _NULL_CTX
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        return False
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 def wT16(p):
     """Transposed bf16 shadow [in, out] of a weight, or None when the model keeps none for it."""
     return getattr(p, "_vlm_bf16_t", None)
@@ -448,9 +495,11 @@ class _BlockFn(torch.autograd.Function):
         qkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
         rs1 = pc.drop_path_rows(plan.drop_prob, training, dev)
         rs2 = pc.drop_path_rows(plan.drop_prob, training, dev)
-        for r0, r1, e in plan.ranges:
-            ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, ln1[r0:r1], st1[r0:r1])
-            ops.gemm(ln1[r0:r1], w16(e.qkvw), qkv[r0:r1], bias=_qkv_bias(e))
+        with _ExpertStreams(plan.ranges) as es:
+            for idx, (r0, r1, e) in enumerate(plan.ranges):
+                with es.on(idx):
+                    ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, ln1[r0:r1], st1[r0:r1])
+                    ops.gemm(ln1[r0:r1], w16(e.qkvw), qkv[r0:r1], bias=_qkv_bias(e))
         o = torch.empty(M, D, device=dev, dtype=BF16)
         lse = torch.empty(H, M, device=dev, dtype=F32)
         rp = pc.relpos
@@ -460,23 +509,24 @@ class _BlockFn(torch.autograd.Function):
                           mode=plan.mode, bias_dense=rp.dense_for(pc.seq, plan.mode) if rp is not None else None)
         x1 = torch.empty(M, D, device=dev, dtype=F32)
         y1 = torch.empty(M, D, device=dev, dtype=BF16)
-        for r0, r1, e in plan.ranges:
-            ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
-                     row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
         ln2 = torch.empty(M, D, device=dev, dtype=BF16)
         st2 = torch.empty(M, 2, device=dev, dtype=F32)
         h = torch.empty(M, Fdim, device=dev, dtype=BF16)
         a = torch.empty(M, Fdim, device=dev, dtype=BF16)
         x2 = torch.empty(M, D, device=dev, dtype=F32)
         y2 = torch.empty(M, D, device=dev, dtype=BF16)
-        for r0, r1, e in plan.ranges:
-            ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
-            # h = gelu'(pre-activation) (VLM_GELU_SAVE_DERIV, default): the forward epilogue has erf and exp in hand anyway,
-            # and the fc2-dgrad epilogue of the backward pass becomes a multiplication
-            ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b, act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU,
-                     aux=h[r0:r1])
-            ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
-                     row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
+        with _ExpertStreams(plan.ranges) as es:  # each expert's proj -> LayerNorm -> fc1 -> fc2 chain is independent
+            for idx, (r0, r1, e) in enumerate(plan.ranges):
+                with es.on(idx):
+                    ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
+                             row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
+                    ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
+                    # h = gelu'(pre-activation) (VLM_GELU_SAVE_DERIV, default): the forward epilogue has erf and exp in
+                    # hand anyway, and the fc2-dgrad epilogue of the backward pass becomes a multiplication
+                    ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b,
+                             act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h[r0:r1])
+                    ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
+                             row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
         if pc.gram is not None:
             # Gram cache: the LayerNorm outputs enter in fp32 (re-computed here, capture runs are not timed), like the
             # fp32 activations the reference's hooks see; the attention output and the GELU output exist only as the bf16
@@ -524,35 +574,34 @@ class _BlockFn(torch.autograd.Function):
         dx1 = torch.empty(M, D, device=dev, dtype=F32)
         # column partials (dgamma / dbeta / dbias) of the block's four row kernels are folded by ONE launch at the end
         fold = ops.FoldBatch(dev, D) if _DEFER_FOLD else None
-        # ---- FFN branch ----
-        for r0, r1, e in plan.ranges:
-            rr = slice(r0, r1)
-            ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad,
-                               fold=fold)
-            # fc1 bias gradient = column sums of dh, taken in the epilogue that produces dh (no second pass over it)
-            # fc1 bias gradient = column sums of dh: per-tile sums from the epilogue that produces dh, folded with the
-            # block's other column partials (no atomics, no second pass over dh); without a fold batch: colsum kernel
-            fuse_b1 = _FUSE_FC1_BIAS and fold is not None
-            _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_MUL_AUX if _SAVE_DERIV else L.ACT_GELU_BWD, aux=h[rr],
-                   col_sum=e.fc1b.grad if fuse_b1 else None,
-                   col_sum_fold=fold if fuse_b1 else None)
-            if not fuse_b1:
-                ops.colsum(dh[rr], e.fc1b.grad)
-            with _Side(dy2, a, dh, ln2):
-                ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
-                ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
-            _dgrad(dh[rr], e.fc1w, dln[rr])
-            ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
-                              dbeta=e.n2b.grad, fold=fold)
-        # ---- attention branch ----
+        if fold is not None and _EXPERTS["enabled"] and len(plan.ranges) > 1:
+            fold.multi_stream = True  # the experts' row kernels run on two streams: fold only after the join
+        # ---- FFN branch, then the attention branch up to the attention core: one independent chain per expert ----
         do = torch.empty(M, D, device=dev, dtype=BF16)
-        for r0, r1, e in plan.ranges:
-            rr = slice(r0, r1)
-            ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad,
-                               fold=fold)
-            _dgrad(dy1[rr], e.projw, do[rr])
-            with _Side(dy1, o):
-                ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
+        fuse_b1 = _FUSE_FC1_BIAS and fold is not None
+        with _ExpertStreams(plan.ranges) as es:
+            for idx, (r0, r1, e) in enumerate(plan.ranges):
+                rr = slice(r0, r1)
+                with es.on(idx):
+                    ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad,
+                                       e.fc2b.grad, fold=fold)
+                    # fc1 bias gradient = column sums of dh: per-tile sums from the epilogue that produces dh, folded with
+                    # the block's other column partials (no atomics, no second pass over dh); without a fold batch: colsum
+                    _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_MUL_AUX if _SAVE_DERIV else L.ACT_GELU_BWD, aux=h[rr],
+                           col_sum=e.fc1b.grad if fuse_b1 else None, col_sum_fold=fold if fuse_b1 else None)
+                    if not fuse_b1:
+                        ops.colsum(dh[rr], e.fc1b.grad)
+                    with _Side(dy2, a, dh, ln2):
+                        ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
+                        ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
+                    _dgrad(dh[rr], e.fc1w, dln[rr])
+                    ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
+                                      dbeta=e.n2b.grad, fold=fold)
+                    ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad,
+                                       e.projb.grad, fold=fold)
+                    _dgrad(dy1[rr], e.projw, do[rr])
+                    with _Side(dy1, o):
+                        ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
         dln1 = torch.empty(M, D, device=dev, dtype=BF16)
         rp = pc.relpos
@@ -566,16 +615,18 @@ class _BlockFn(torch.autograd.Function):
                           dq_colsum=qb_grads, dv_colsum=vb_grads,
                           bias_dense=rp.dense_for(pc.seq, plan.mode) if rp is not None else None)
         dx = torch.empty(M, D, device=dev, dtype=F32)
-        for r0, r1, e in plan.ranges:
-            rr = slice(r0, r1)
-            if e.qb is not None and not fused_qv:
-                ops.colsum(dqkv[rr, :D], e.qb.grad)
-                ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
-            with _Side(dqkv, ln1):
-                ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
-            _dgrad(dqkv[rr], e.qkvw, dln1[rr])
-            ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad, dbeta=e.n1b.grad,
-                              fold=fold)
+        with _ExpertStreams(plan.ranges) as es:
+            for idx, (r0, r1, e) in enumerate(plan.ranges):
+                rr = slice(r0, r1)
+                with es.on(idx):
+                    if e.qb is not None and not fused_qv:
+                        ops.colsum(dqkv[rr, :D], e.qb.grad)
+                        ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
+                    with _Side(dqkv, ln1):
+                        ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
+                    _dgrad(dqkv[rr], e.qkvw, dln1[rr])
+                    ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad,
+                                      dbeta=e.n1b.grad, fold=fold)
         if fold is not None:
             fold.flush()
         if ctx.hook is not None:

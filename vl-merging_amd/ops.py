@@ -117,7 +117,7 @@ class FoldBatch:
     """Deferred column-sum folds of several row kernels (vlm_colreduce_batch): each deferred call writes its
     per-workgroup partials to its own region of one scratch tensor; flush() folds them all in ONE launch."""
 
-    MAX = 8
+    MAX = 16  # VLM_MAX_FOLD_JOBS: an all_moe block's backward parks 10 (two experts x five row kernels / epilogues)
 
     def __init__(self, device, D=1024):
         self.region = 1536 * 2 * max(D, 1024)
@@ -127,9 +127,13 @@ class FoldBatch:
             ws = _ROW_WS[key] = torch.empty(self.MAX * self.region, device=device, dtype=F32)
         self.ws = ws
         self.jobs = []
+        self.multi_stream = False  # set by a caller whose row kernels run on more than one stream between two flushes
 
     def next_region(self):
         if len(self.jobs) >= self.MAX:
+            if self.multi_stream:
+                raise L.VlmError("FoldBatch overflow while its producers run on several streams (a mid-way fold would "
+                                 "read partials of launches the folding stream is not ordered behind)")
             self.flush()
         i = len(self.jobs)
         return self.ws[i * self.region:(i + 1) * self.region]
