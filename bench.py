@@ -99,13 +99,13 @@ GEMM_HELPERS = ("splitk_reduce_kernel",)  # second launch of a wgrad call: its b
 
 def pmc_traffic(kernels, helpers=()):
     """HBM-side bytes per launch of a kernel (or, launch-weighted, of a family of kernels that serve the same call) from the
-    committed rocprofv3 --pmc passes over this same bench command (profiles/r02_pmc_traffic.json, made by
+    committed rocprofv3 --pmc passes over this same bench command (profiles/r03_pmc_traffic.json, made by
     tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950).
     Counters cannot be read from inside the timed process; None if the file is absent."""
     if isinstance(kernels, str):
         kernels = (kernels,)
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # the newest committed PMC passes
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # the newest committed PMC passes
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]
@@ -472,7 +472,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(GEMM_KERNELS, GEMM_HELPERS),
                                "traffic_unit": "HBM-side bytes per vlm_gemm_bf16 call, launch-weighted over the kernels "
-                                               "that serve it (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
+                                               "that serve it (rocprofv3 PMC, profiles/r03_pmc_traffic.json)",
                                "kernel": "vlm_gemm_bf16: " + " / ".join(GEMM_KERNELS),
                                "note": "peak = nominal dense bf16; a loop of nothing but independent MFMAs reaches 1515 "
                                        "TFLOP/s on this chip (clock drops to 1.45 GHz: DESIGN.md 4.1)",

@@ -32,7 +32,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 4
+#define VLM_ABI_VERSION 5
 int vlm_abi_version(void);
 /* Number of compute units of the current device (grid sizing), or negative error. */
 int vlm_device_cus(void);
