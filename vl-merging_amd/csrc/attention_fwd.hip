@@ -25,6 +25,9 @@
 #ifndef ATT_FWD_WAVES
 #define ATT_FWD_WAVES 3
 #endif
+#ifndef ATT_FWD_STAGES
+#define ATT_FWD_STAGES 2
+#endif
 // Row sums: 1 = on the matrix pipe (one MFMA per 16 keys against an all-ones operand: the sum of the bf16-ROUNDED weights
 // that also enter P V, so every output row is an exact convex combination), 0 = fp32 adds on the vector pipe.  Same
 // speed (three waves per SIMD either way); 1 keeps the numerics the parity tolerances were measured with.
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   __shared__ __attribute__((aligned(16))) unsigned char ldsK0[ATT_TILE_BYTES], ldsK1[ATT_TILE_BYTES];  // [64 keys][128 B] row image
   __shared__ __attribute__((aligned(16))) unsigned char ldsV0[ATT_TILE_BYTES], ldsV1[ATT_TILE_BYTES];  // transposed-read image
   __shared__ float kmask0[64], kmask1[64];
+#if ATT_FWD_STAGES == 3  // K / V two tiles ahead (49 KB per workgroup: three workgroups still fit a CU)
+  __shared__ __attribute__((aligned(16))) unsigned char ldsK2[ATT_TILE_BYTES], ldsV2[ATT_TILE_BYTES];
+  __shared__ float kmask2[64];
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
@@ -159,7 +166,19 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   att_bias_t bw;  // ONE set: the next tile's rows are requested as soon as this tile's selection MFMAs have been issued
   if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);  // issued BEFORE the DMA: vmcnt retires in order
   stage(0, ldsK0, ldsV0, kmask0);
+#if ATT_FWD_STAGES == 3
+  // publish with `keep` younger vector-memory operations still in flight (0, 4 or 8: the next tile's bias rows and / or the
+  // LDS-DMA pieces of the tile after next); one asm statement each (see ATT_PUBLISH_KEEP4)
+  auto publish_keep = [&](int keep) {
+    if (keep >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  if (ntiles > 1) stage(1, ldsK1, ldsV1, kmask1);
+  publish_keep(ntiles > 1 ? 4 : 0);
+#else
   ATT_PUBLISH();
+#endif
 
   // one streamed tile; `bw` = this tile's bias rows (complete since the last publish), `bn` receives the next tile's
   [[maybe_unused]] int slot = 0;
@@ -167,9 +186,9 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
                   unsigned char* nv, float* nm_) {
     const int kp0 = sp.s_lo + t * ATT_BK;
     ATT_STAMP(slot++);
-    if (t + 1 < ntiles) {
+    if (t + (ATT_FWD_STAGES - 1) < ntiles) {  // nk / nv / nm_: the stage of tile t + 1 (two stages) or t + 2 (three)
 #ifndef ATT_DIAG_NODMA
-      stage(t + 1, nk, nv, nm_);
+      stage(t + (ATT_FWD_STAGES - 1), nk, nv, nm_);
 #endif
     }
 
@@ -271,15 +290,25 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
     }
 #if defined(ATT_DIAG_NOBIASLOAD) || defined(ATT_DIAG_NODMA)
     ATT_PUBLISH();
+#elif ATT_FWD_STAGES == 3
+    publish_keep((HAS_BIAS && t + 1 < ntiles ? 4 : 0) + (t + 2 < ntiles ? 4 : 0));  // tile t + 1 is complete, younger ops fly on
 #else
     if (HAS_BIAS && t + 1 < ntiles) ATT_PUBLISH_KEEP4();
     else ATT_PUBLISH();
 #endif
   };
+#if ATT_FWD_STAGES == 3
+  for (int t = 0; t < ntiles; t += 3) {  // three tiles per trip: the LDS stages are distinct objects, selected at compile time
+    tile(t, ldsK0, ldsV0, kmask0, ldsK2, ldsV2, kmask2);
+    if (t + 1 < ntiles) tile(t + 1, ldsK1, ldsV1, kmask1, ldsK0, ldsV0, kmask0);
+    if (t + 2 < ntiles) tile(t + 2, ldsK2, ldsV2, kmask2, ldsK1, ldsV1, kmask1);
+  }
+#else
   for (int t = 0; t < ntiles; t += 2) {  // two tiles per trip: the LDS stages are distinct objects, selected at compile time
     tile(t, ldsK0, ldsV0, kmask0, ldsK1, ldsV1, kmask1);
     if (t + 1 < ntiles) tile(t + 1, ldsK1, ldsV1, kmask1, ldsK0, ldsV0, kmask0);
   }
+#endif
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
 #ifdef ATT_FWD_MFMA_ROWSUM
