@@ -224,3 +224,18 @@ def test_bias_dense_tables(ops, L, ci, sep):
                     want = torch.where(ok[None], full[:, q.clamp(0, NP - 1), k.clamp(0, NP - 1)], torch.full((), -30000.0, device="cuda"))
                     assert torch.allclose(tile, want, rtol=1e-3, atol=1e-3), (k_major, sb, st)
             first += nsb * nst
+
+
+def test_eight_wave_bias_gradient_kernel_still_agrees():
+    """attn_bwd_dbias16_kernel is what runs by default; VLM_ATT_DB16=0 (parsed once per process) selects the 8-wave kernel it
+    replaced, kept for A/B runs: the biased backward cases must pass with it too."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("VLM_ATT_DB16") == "0":
+        pytest.skip("already the 8-wave run")
+    env = dict(os.environ, VLM_ATT_DB16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_attention_bwd and True"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -5,6 +5,7 @@
 #include "../../vl-merging_amd/csrc/attention_fwd.hip"
 #include "../../vl-merging_amd/csrc/attention_bwd.hip"
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <cstdlib>
 #include <vector>
@@ -68,6 +69,16 @@ int main(int argc, char** argv) {
   const double nn = mode ? (double)n0 * n0 + (double)n1 * n1 : (double)(n0 + n1) * (n0 + n1);
   const double fl = 4.0 * B * H * 64 * nn * (what ? 2.5 : 1.0);
   printf("%s B=%d mode=%d bias=%d: %.1f us  %.0f TFLOP/s\n", what ? "bwd" : "fwd", B, mode, with_bias, us, fl / us / 1e6);
+  if (what == 1 && with_bias && with_dbias) {  // checksum of one pass's bias-table gradient (compare VLM_ATT_DB16=0 / 1 runs)
+    CK(hipMemset(dbias, 0, hb.size() * 4));
+    run();
+    CK(hipDeviceSynchronize());
+    std::vector<float> g(hb.size());
+    CK(hipMemcpy(g.data(), dbias, g.size() * 4, hipMemcpyDeviceToHost));
+    double sum = 0, sabs = 0, w = 0;
+    for (size_t i = 0; i < g.size(); ++i) { sum += g[i]; sabs += fabs(g[i]); w += g[i] * (double)((i * 2654435761u) % 1000); }
+    printf("dbias checksum: sum %.6e abs %.6e weighted %.6e  [%g %g %g %g]\n", sum, sabs, w, g[12 * R + 5], g[13 * R + 700], g[20 * R + 1500], g[23 * R + 2200]);
+  }
 #ifdef ATT_DIAG_STAMPS
   {
     unsigned long long st[8 * 64];

@@ -12,11 +12,13 @@
 // bias gradient whose (slow) LDS atomics are amortised over the batch.
 #include "vlm_common.h"
 #include "attention_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------- delta
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int ld_o,
                                                          const bf16_t* __restrict__ d_o, int ld_do, int rows, int H,
-                                                         float* __restrict__ delta) {
+                                                         float* __restrict__ delta, const float* __restrict__ lse,
+                                                         float* __restrict__ nstat, float inv_c1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = H * 64;
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -29,7 +31,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       s += __shfl_xor(s, 4, 64);
-      if ((lane & 7) == 0) delta[(size_t)(c >> 6) * rows + row] = s;
+      if ((lane & 7) == 0) {
+        const size_t at = (size_t)(c >> 6) * rows + row;
+        delta[at] = s;
+        if (nstat) {  // C operands of attn_bwd_dbias16_kernel: -lse / c1 (scores stay unscaled there) and -delta
+          nstat[at] = -lse[at] * inv_c1;
+          nstat[(size_t)H * rows + at] = -s;
+        }
+      }
     }
   }
 }
@@ -44,6 +53,7 @@ struct attn_bwd_params_t {
   int ld_dqkv;
   float* dbias_t;         // [n_cols, R] accumulate
   float* dbias_part;      // [items][R] per-workgroup histograms (two-stage reduction) or NULL (global atomics)
+  const float* nstat;     // [2][H][rows]: -lse / c1 and -delta (attn_delta_kernel) or NULL
   float* dq_colsum[2];    // per segment (0 text rows, 1 image rows): [H*64] += column sums of dQ (q_bias grad) or NULL
   float* dv_colsum[2];    // same for dV (v_bias gradient)
 };
@@ -716,6 +726,243 @@ __global__ __launch_bounds__(ATT_DB_THREADS, 2) void attn_bwd_dbias_kernel(const
   }
 }
 
+// ---- the same work item with SIXTEEN waves (four per SIMD) ---------------------------------------------------------------
+// The 8-wave kernel above spends 3.2 us per sample where its MFMAs need 0.6 and its LDS traffic 1.0: two waves per SIMD with
+// 240 registers each cannot cover the LDS -> MFMA -> exp chain of a sample, and the global -> VGPR -> LDS staging adds a
+// vmcnt(0) wait and eight ds_write_b128 per thread to it.  Here wave (kw = wave & 3, qw = wave >> 2) owns 32 keys x 32
+// queries (16 accumulator registers), the four operand tiles of the next sample arrive by LDS-DMA (no staging registers: four
+// 1-KiB pieces per wave and sample, the row-image swizzle on the source side) and nothing is converted on the vector pipe:
+// K stays unscaled, the C operand of the score product is -lse / c1 (attn_delta_kernel writes it), the bias enters through
+// selection MFMAs whose "one" is 1 / c1 split into an fp16 head and tail (products of fp16 values are exact in the fp32
+// accumulator), and P = exp2(c1 * e).  <= 128 VGPRs.
+#define ATT_DB16_THREADS 1024
+__global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(const attn_bwd_params_t bp, int n_groups) {
+  const attn_params_t& p = bp.f;
+  constexpr int STAGE = 8 * ATT_TILE_BYTES + 1024;  // K, V (128 keys), Q, dO (128 queries) row images + (-lse / c1 | -delta)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  float* hist = reinterpret_cast<float*>(smem);  // aliases the tiles: only used after the sample loop
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kw = wave & 3, qw = wave >> 2;
+  const int r = lane & 31, hh = lane >> 5;
+  const att_pos_t ps = att_pos(p.seq);
+  const int D = p.H * 64;
+  // ---- work item (same order and slots as attn_bwd_dbias_kernel) ------------------------------------------------------------
+  const int nkt = att_num_tiles(ps.n0, ps.n1, ps.pos1, p.mode);
+  int pairs = 0;
+  for (int k = 0; k < nkt; ++k) {
+    const att_span_t s_ = att_span(ps, p.mode, k);
+    pairs += (s_.s_hi - s_.s_lo + ATT_BQ - 1) / ATT_BQ;
+  }
+  const int total = pairs * p.H * n_groups, per = (total + 7) >> 3;
+  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || logical >= total) return;
+  int item = logical % pairs;
+  const int pair_id = item;
+  const int grp = (logical / pairs) % n_groups;
+  const int h = logical / (pairs * n_groups);
+  const int part_slot = (pair_id * p.H + h) * n_groups + grp;
+  int kt = 0;
+  att_span_t sp = att_span(ps, p.mode, 0);
+  for (;; ++kt) {
+    sp = att_span(ps, p.mode, kt);
+    const int nq = (sp.s_hi - sp.s_lo + ATT_BQ - 1) / ATT_BQ;
+    if (item < nq) break;
+    item -= nq;
+    if (kt + 1 >= nkt) return;
+  }
+  const int qp0 = sp.s_lo + item * ATT_BQ;
+  const int b_lo = (int)((long)ps.B * grp / n_groups), b_hi = (int)((long)ps.B * (grp + 1) / n_groups);
+  if (b_lo >= b_hi) return;
+
+  const int kp = sp.p0 + kw * 32 + r;  // this lane's key position
+  const bool kvalid = kp < sp.s_hi && (kp < ps.n0 || kp >= ps.pos1);
+  const uint8_t* keepk = kp < ps.n0 ? p.keep0 : p.keep1;
+  const int keep_at = kp < ps.n0 ? kp : kp - ps.pos1, keep_n = kp < ps.n0 ? ps.n0 : ps.n1;
+  const bool wave_keep = __any(kvalid && keepk != nullptr);
+
+  // selection fragments scaled by 1 / c1 = head + tail (fp16 each)
+  const float c1 = p.scale * ATT_LOG2E, inv = 1.0f / c1;
+  const _Float16 inv_hi = (_Float16)inv, inv_lo = (_Float16)(inv - (float)inv_hi);
+  f16x8 sh0, sh1, sl0, sl1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool m0 = r == 16 * hh + e, m1 = r == 16 * hh + 8 + e;
+    sh0[e] = m0 ? inv_hi : (_Float16)0.f;
+    sl0[e] = m0 ? inv_lo : (_Float16)0.f;
+    sh1[e] = m1 ? inv_hi : (_Float16)0.f;
+    sl1[e] = m1 ? inv_lo : (_Float16)0.f;
+  }
+  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(p.dense_t + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048), 0, (uint32_t)p.dense_tiles * 4096u, 0x00020000);
+  att_bias_t bw;  // this wave's 32-query block (the same for every sample): bw.w[qw & 1]
+  att_bias_load_half(bw, qw & 1, rbias, att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + kw, lane), (qp0 - sp.s_lo) / ATT_BK + (qw >> 1));
+  const u32x4 bw0 = bw.w[qw & 1][0], bw1 = bw.w[qw & 1][1];
+
+  // ---- LDS-DMA staging: wave w moves piece w (rows 8w .. 8w+7) of each of the four 128-row tiles ----------------------------
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv), 0, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(bp.d_o), 0, (uint32_t)((size_t)p.total_rows * bp.ld_do * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(bp.nstat), 0, (uint32_t)((size_t)2 * p.H * p.total_rows * 4), 0x00020000);
+  const int srow = wave * 8 + (lane >> 3);
+  const uint32_t schunk = (uint32_t)(((lane & 7) ^ (srow & 7)) * 16);  // source-side swizzle of the row image
+  // position -> (valid, first row of its segment for sample 0, rows per sample) is per-lane constant; the sample adds b * n
+  auto seg_of = [&](int pos, int lim, bool& ok, int& row0, int& stride) {
+    const bool txt = pos < ps.n0, img = pos >= ps.pos1 && pos < ps.NP;
+    ok = (txt || img) && pos < lim;
+    row0 = txt ? ps.base0 + pos : ps.base1 + (pos - ps.pos1);
+    stride = txt ? ps.n0 : ps.n1;
+  };
+  bool k_ok, q_ok, s_ok;
+  int k_row0, k_str, q_row0, q_str, s_row0, s_str;
+  seg_of(sp.p0 + srow, sp.s_hi, k_ok, k_row0, k_str);
+  seg_of(qp0 + srow, sp.s_hi, q_ok, q_row0, q_str);
+  seg_of(qp0 + (wave & 1) * 64 + lane, sp.s_hi, s_ok, s_row0, s_str);  // waves 0..3: one half of one statistic
+  const uint32_t colK = (uint32_t)(D + h * 64) * 2, colV = (uint32_t)(2 * D + h * 64) * 2, colQ = (uint32_t)(h * 64) * 2;
+  const uint32_t stat_base = (uint32_t)(((wave >> 1) * p.H + h) * p.total_rows);
+  auto dma = [&](int b, int stage) {
+    unsigned char* base = smem + stage * STAGE + wave * 1024;
+    const uint32_t ko = k_ok ? (uint32_t)(k_row0 + b * k_str) * (uint32_t)p.ld_qkv * 2 + schunk : 0xFFFFF000u;
+    const uint32_t qo = q_ok ? (uint32_t)(q_row0 + b * q_str) * (uint32_t)p.ld_qkv * 2 + schunk : 0xFFFFF000u;
+    const uint32_t oo = q_ok ? (uint32_t)(q_row0 + b * q_str) * (uint32_t)bp.ld_do * 2 + schunk : 0xFFFFF000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base), 16, ko, colK, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base + 2 * ATT_TILE_BYTES), 16, ko, colV, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base + 4 * ATT_TILE_BYTES), 16, qo, colQ, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (att_lds_void*)(base + 6 * ATT_TILE_BYTES), 16, oo, colQ, 0, 0);
+    if (wave < 4) {  // -lse / c1 (waves 0, 1) and -delta (waves 2, 3) of the tile's 128 queries; absent queries read 0 (the table masks them)
+      const uint32_t so = s_ok ? (stat_base + (uint32_t)(s_row0 + b * s_str)) * 4 : 0xFFFFF000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rst, (att_lds_void*)(smem + stage * STAGE + 8 * ATT_TILE_BYTES + wave * 256), 4, so, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  dma(b_lo, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n s_barrier" ::: "memory");
+  for (int b = b_lo; b < b_hi; ++b) {
+    const int cur = (b - b_lo) & 1;
+#ifndef ATT_DB16_NODMA
+    if (b + 1 < b_hi) dma(b + 1, cur ^ 1);  // that stage was last read in the previous trip (barrier below)
+#endif
+    const unsigned char* ldsK = smem + cur * STAGE;
+    const unsigned char* ldsV = ldsK + 2 * ATT_TILE_BYTES;
+    const unsigned char* ldsQ = ldsK + 4 * ATT_TILE_BYTES;
+    const unsigned char* ldsO = ldsK + 6 * ATT_TILE_BYTES;
+    const float* qstat = reinterpret_cast<const float*>(ldsK + 8 * ATT_TILE_BYTES);
+    float kmaskv = kvalid ? 0.f : -INFINITY;
+    if (wave_keep && kvalid && keepk && keepk[(size_t)b * keep_n + keep_at] == 0) kmaskv = -INFINITY;
+    const bool wave_masked = __any(kmaskv != 0.f);
+    const int q0 = qw * 32;
+    f32x16 e, dp;
+#ifdef ATT_DB16_NOMATH
+    acc[0] += qstat[q0 + lane] + kmaskv;
+    if (false) {
+#else
+    {
+#endif
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qstat + q0 + 8 * g4 + 4 * hh);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(qstat + 128 + q0 + 8 * g4 + 4 * hh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
+    }
+    if (wave_masked) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) e[i] += kmaskv;
+    }
+    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh0, __builtin_bit_cast(f16x8, bw0), e, 0, 0, 0);
+    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh1, __builtin_bit_cast(f16x8, bw1), e, 0, 0, 0);
+    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl0, __builtin_bit_cast(f16x8, bw0), e, 0, 0, 0);
+    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl1, __builtin_bit_cast(f16x8, bw1), e, 0, 0, 0);
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      const bf16x8 qa = att_k_rowfrag(ldsQ, q0 + r, 2 * ss + hh), ka = att_k_rowfrag(ldsK, kw * 32 + r, 2 * ss + hh);
+      const bf16x8 oa = att_k_rowfrag(ldsO, q0 + r, 2 * ss + hh), va = att_k_rowfrag(ldsV, kw * 32 + r, 2 * ss + hh);
+      e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, ka, e, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, va, dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fmaf(att_exp2(e[i] * c1), dp[i], acc[i]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n s_barrier" ::: "memory");  // stage cur ^ 1 is published, stage cur is free
+  }
+
+  // ---- histogram of the batch-summed dS (in the LDS that held the tiles) ---------------------------------------------------
+  // 64-bit FIXED-POINT bins: ds_add_f32 costs ~110-150 cycles per wave instruction on this chip whatever the address pattern
+  // (47 of this kernel's 346 us at 88 samples), ds_add_u64 runs at the LDS array's rate -- and integer sums do not depend on
+  // the order the waves arrive in.  The step is 2^-48 of the item's largest |sum of dS| (a bin receives at most 2^14 addends).
+#ifdef ATT_DB16_NOTAIL
+  if (acc[0] == 12345.f) hist[tid] = acc[1] + acc[7];
+  return;
+#endif
+  unsigned long long* hist64 = reinterpret_cast<unsigned long long*>(smem);
+  unsigned* smax = reinterpret_cast<unsigned*>(hist64 + p.R);
+  for (int i = tid; i < p.R; i += ATT_DB16_THREADS) hist64[i] = 0ull;
+  if (tid == 0) *smax = 0u;
+  __syncthreads();
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(acc[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) atomicMax(smax, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  }
+  __syncthreads();
+  int ex;
+  (void)frexpf(__uint_as_float(*smax), &ex);  // largest |value| < 2^ex
+  if (ex < -60) ex = -60;                     // (2^(48 - ex) must stay a finite float)
+  const float FIX = ldexpf(1.0f, 48 - ex), UNFIX = ldexpf(1.0f, ex - 48);
+  {
+    // byte offsets (4 x relative-position index) of this lane's 16 (query, key) pairs through the [query][key] orientation:
+    // the 32 lanes of a half read 64 consecutive bytes of one row
+    const bool kin = kp < p.ld_idx;
+    const int qpos0 = qp0 + qw * 32;
+    uint32_t ids[16];
+    bool same = true;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int qq = qpos0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+      ids[j] = (kin && qq < p.idx_rows) ? (uint32_t)(unsigned short)p.idx[(size_t)qq * p.ld_idx + kp] : 0u;
+      same = same && ids[j] == ids[0];
+    }
+    const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
+    same = same && ids[0] == first;
+    if (__all(same)) {  // text -> image pairs share ONE table row (vilt_module.py:180-181): reduce in registers
+      float tsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tsum += acc[j];
+      tsum = wave_sum(tsum);
+      if (lane == 0) atomicAdd(hist64 + (first >> 2), (unsigned long long)(long long)(tsum * FIX));
+    } else {
+#ifndef ATT_DB16_NOHIST
+#pragma unroll
+      for (int j = 0; j < 16; ++j)  // ids are byte offsets of 4-byte entries: 2 * ids addresses the 8-byte bin
+        atomicAdd(reinterpret_cast<unsigned long long*>(smem + 2 * ids[j]), (unsigned long long)(long long)(acc[j] * FIX));
+#else
+      hist[tid] = acc[0] + acc[5] + (float)ids[3] + (float)ids[9];
+#endif
+    }
+  }
+  __syncthreads();
+  if (bp.dbias_part) {
+    float* g = bp.dbias_part + (size_t)part_slot * p.R;
+    for (int i = tid; i < p.R; i += ATT_DB16_THREADS) g[i] = (float)(long long)hist64[i] * UNFIX;
+  } else {
+    float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
+    for (int i = tid; i < p.R; i += ATT_DB16_THREADS) {
+      const long long v = (long long)hist64[i];
+      if (v != 0) atomicAdd(g + i, (float)v * UNFIX);
+    }
+  }
+}
+
 // dbias_t[head_row0 + h][i] += sum over the work items of head h (item = (pair * H + h) * groups + grp) of part[item][i]
 __global__ __launch_bounds__(256) void attn_dbias_fold_kernel(const float* __restrict__ part, int R, int H, int groups, int pairs,
                                                               float* __restrict__ dbias_t, int head_row0) {
@@ -725,6 +972,15 @@ __global__ __launch_bounds__(256) void attn_dbias_fold_kernel(const float* __res
   for (int pr = 0; pr < pairs; ++pr)
     for (int g = 0; g < groups; ++g) sum += part[((size_t)(pr * H + h) * groups + g) * R + i];
   dbias_t[(size_t)(head_row0 + h) * R + i] += sum;
+}
+
+// VLM_ATT_DB16=0 selects the 8-wave bias-gradient kernel (A/B runs); parsed once
+static bool att_db16_enabled() {
+  static const bool on = []() {
+    const char* e = getenv("VLM_ATT_DB16");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 // work items of the bias-gradient kernel for this geometry: (key tile, query tile) pairs and sample groups
@@ -739,16 +995,38 @@ static void att_dbias_items(const attn_params_t& p, int& pairs, int& groups) {
   }
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;
-  groups = pairs > 0 ? (3 * cus + pairs * p.H - 1) / (pairs * p.H) : 1;  // ~3 items per CU
-  if (groups > p.seq.B) groups = p.seq.B;
-  if (groups > 8) groups = 8;
-  if (groups < 1) groups = 1;
+  if (!att_db16_enabled() || pairs <= 0) {
+    groups = pairs > 0 ? (3 * cus + pairs * p.H - 1) / (pairs * p.H) : 1;  // ~3 items per CU
+    if (groups > p.seq.B) groups = p.seq.B;
+    if (groups > 8) groups = 8;
+    if (groups < 1) groups = 1;
+    return;
+  }
+  // 16-wave kernel: an item costs its samples (2.2 us each) plus the histogram tail (10 us); the CUs finish within half an
+  // item of each other.  (Harness sweep, 300 (pair, head) items per group: 88 samples 330 / 294 / 282 / 297 / 298 us for 1..5
+  // groups, 66: 253 / 226 / 218 / 229 / 243, 22: 108 / 104 / 113 / 127 / 131 -- the model picks 3, 3, 2.)
+  static const int forced = []() {  // VLM_ATT_DB_GROUPS=n overrides the model (experiments); parsed once
+    const char* e = getenv("VLM_ATT_DB_GROUPS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) {
+    groups = forced < p.seq.B ? forced : p.seq.B;
+    return;
+  }
+  groups = 1;
+  float best = 1e30f;
+  for (int g = 1; g <= 8 && g <= p.seq.B; ++g) {
+    const float item = 2.2f * (float)p.seq.B / (float)g + 10.0f;
+    const float t = ((float)pairs * p.H * g / (float)cus + 0.5f) * item;
+    if (t < best) { best = t; groups = g; }
+  }
 }
 
 extern "C" size_t vlm_attention_bwd_ws_floats(const vlm_attn_desc_t* d, int with_dbias) {
   attn_params_t p;
   if (att_fill_params(d, p) != VLM_OK) return 0;
   size_t n = (size_t)p.H * p.total_rows;  // delta
+  if (p.bias_t) n *= 3;                    // + (-lse / c1 | -delta) for the 16-wave bias-gradient kernel
   if (with_dbias && p.bias_t) {
     int pairs, groups;
     att_dbias_items(p, pairs, groups);
@@ -765,6 +1043,7 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   if (rc != VLM_OK) return rc;
   if (!out || !d_out || !lse || !delta_ws || !dqkv) return VLM_ERR_ARG;
   bp.dbias_part = nullptr;
+  bp.nstat = nullptr;
   if ((ld_out & 7) || (ld_dout & 7) || (ld_dqkv & 3) || ((uintptr_t)out & 15) || ((uintptr_t)d_out & 15))
     return VLM_ERR_ARG;
   if (bp.f.bias_t && (!bp.f.idx || (bp.f.ld_idx & 3))) return VLM_ERR_ARG;
@@ -794,8 +1073,12 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   if (cus <= 0) cus = 256;
   int dg = (p.total_rows + 3) / 4;
   if (dg > cus * 8) dg = cus * 8;
+  // the 16-wave bias-gradient kernel needs its C operands from the delta launch: workspace = delta | nstat | histograms
+  const size_t hr = (size_t)p.H * p.total_rows;
+  const bool db16 = p.bias_t && dbias_t && ws_floats >= 3 * hr && att_db16_enabled();
+  bp.nstat = db16 ? delta_ws + hr : nullptr;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(dg), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(out), ld_out, bp.d_o,
-                     ld_dout, p.total_rows, p.H, delta_ws);
+                     ld_dout, p.total_rows, p.H, delta_ws, lse, db16 ? delta_ws + hr : nullptr, 1.0f / (p.scale * ATT_LOG2E));
   VLM_CHECK_LAUNCH();
 
   const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
@@ -810,9 +1093,10 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
       // into groups until the grid has ~3 items per CU (the per-item histogram is the price of every extra group)
       int pairs, groups;
       att_dbias_items(p, pairs, groups);
-      const size_t items = (size_t)pairs * p.H * groups, need = (size_t)p.H * p.total_rows + items * p.R;
-      bp.dbias_part = ws_floats >= need ? delta_ws + (size_t)p.H * p.total_rows : nullptr;
-      hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3((unsigned)((items + 7) / 8 * 8)), dim3(ATT_DB_THREADS), 0, s, bp, groups);
+      const size_t items = (size_t)pairs * p.H * groups, need = 3 * hr + items * p.R;
+      bp.dbias_part = ws_floats >= need ? delta_ws + 3 * hr : nullptr;
+      if (db16) hipLaunchKernelGGL(attn_bwd_dbias16_kernel, dim3((unsigned)((items + 7) / 8 * 8)), dim3(ATT_DB16_THREADS), 0, s, bp, groups);
+      else hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3((unsigned)((items + 7) / 8 * 8)), dim3(ATT_DB_THREADS), 0, s, bp, groups);
       if (bp.dbias_part) {
         VLM_CHECK_LAUNCH();
         hipLaunchKernelGGL(attn_dbias_fold_kernel, dim3((p.R + 255) / 256, p.H), dim3(256), 0, s, bp.dbias_part, p.R, p.H, groups,
