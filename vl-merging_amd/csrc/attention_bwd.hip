@@ -13,6 +13,9 @@
 #include "vlm_common.h"
 #include "attention_common.h"
 #include <stdlib.h>
+#ifndef ATT_STAMP  // (defined by attention_fwd.hip in diagnostic harness builds)
+#define ATT_STAMP(slot) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------------- delta
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int ld_o,
@@ -118,7 +121,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
       const_cast<_Float16*>(HAS_BIAS ? p.dense + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048 : nullptr), 0,
       HAS_BIAS ? (uint32_t)p.dense_tiles * 4096u : 0, 0x00020000);
   const uint32_t bvoff = att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + wave, lane);
-  const att_rows2_t ro = att_rows2_init(p.ld_qkv, tid);
 
   f32x16 o[2];
 #pragma unroll
@@ -128,19 +130,49 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
     return (p.keep0 != nullptr && kp0 < ps.n0) || (p.keep1 != nullptr && kp0 + ATT_BK > ps.pos1) ||
            (!HAS_BIAS && (kp0 < ps.pos1 || kp0 + ATT_BK > sp.s_hi));
   };
+  // Staging: every trip issues the SAME vector-memory operations in the same order, none under a branch (4 tile pieces,
+  // 2 keep bytes, 4 bias operands) so that the compiler's vmcnt waits stay counted -- see attn_bwd_dkv_kernel.  A segment
+  // without a keep mask reads through a zero-length descriptor; a trip past the last tile points every row out of range.
+  const __amdgpu_buffer_rsrc_t rkeep0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.keep0 ? p.keep0 : reinterpret_cast<const uint8_t*>(p.qkv)), 0, p.keep0 ? (uint32_t)(ps.B * ps.n0) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rkeep1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.keep1 ? p.keep1 : reinterpret_cast<const uint8_t*>(p.qkv)), 0, p.keep1 ? (uint32_t)(ps.B * ps.n1) : 0u, 0x00020000);
   u32x4 rk[2], rv[2];
-  float rmask = 0.f;
+  uint32_t rkeep[2] = {0u, 0u};
+  const uint32_t chunk2 = (uint32_t)(tid & 7) * 16;
   auto load = [&](int t) {
     const int kp0 = sp.s_lo + t * ATT_BK;
-    att_rows2_load(rk, rkv, ro, ps, b, kp0, sp.s_hi, p.ld_qkv, D + h * 64, tid);
-    att_rows2_load(rv, rkv, ro, ps, b, kp0, sp.s_hi, p.ld_qkv, 2 * D + h * 64, tid);
-    if (tile_masked(kp0) && tid < 64) rmask = att_key_mask(ps, b, kp0 + tid, sp.s_hi, p.keep0, p.keep1);
+    const int lim = t < ntiles ? sp.s_hi : 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pp = kp0 + ((tid + 256 * u) >> 3);
+      const bool txt = pp < ps.n0, img = pp >= ps.pos1 && pp < ps.NP;
+      const bool ok = (txt || img) && pp < lim;
+      const uint32_t row = (uint32_t)(txt ? ps.base0 + b * ps.n0 + pp : ps.base1 + b * ps.n1 + (pp - ps.pos1));
+      const uint32_t ok_ = ok ? (row * (uint32_t)p.ld_qkv + (uint32_t)(D + h * 64)) * 2 + chunk2 : 0xFFFFFFF0u;
+      const uint32_t ov_ = ok ? (row * (uint32_t)p.ld_qkv + (uint32_t)(2 * D + h * 64)) * 2 + chunk2 : 0xFFFFFFF0u;
+      rk[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ok_, 0, 0));
+      rv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rkv, ov_, 0, 0));
+    }
+    {  // keep bytes of key position kp0 + lane (text / image segment): RAW, looked at in store()
+      const int pp = kp0 + lane;
+      const bool txt = pp < ps.n0 && pp < lim, img = pp >= ps.pos1 && pp < ps.NP && pp < lim;
+      rkeep[0] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rkeep0, txt ? (uint32_t)(b * ps.n0 + pp) : 0xFFFFFFF0u, 0, 0);
+      rkeep[1] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rkeep1, img ? (uint32_t)(b * ps.n1 + (pp - ps.pos1)) : 0xFFFFFFF0u, 0, 0);
+    }
   };
   auto store = [&](int t, int buf) {
     att_tile_store_rows(rk, ldsK + buf * ATT_TILE_BYTES, tid);
     att_tile_store_tr(rk, ldsKt + buf * ATT_TILE_BYTES, tid);
     att_tile_store_rows(rv, ldsV + buf * ATT_TILE_BYTES, tid);
-    if (tile_masked(sp.s_lo + t * ATT_BK) && tid < 64) kmask[buf * 64 + tid] = rmask;
+    if (wave == 0) {  // additive key mask of the tile: 0 keep, -inf drop
+      const int pp = sp.s_lo + t * ATT_BK + lane;
+      const bool txt = pp < ps.n0, img = pp >= ps.pos1 && pp < ps.NP;
+      bool ok = (txt || img) && pp < sp.s_hi;
+      if (txt && p.keep0) ok = ok && rkeep[0] != 0;
+      if (img && p.keep1) ok = ok && rkeep[1] != 0;
+      kmask[buf * 64 + lane] = ok ? 0.f : -INFINITY;
+    }
   };
   att_bias_t bw;
   if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);
@@ -151,7 +183,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const int kp0 = sp.s_lo + t * ATT_BK;
-    if (t + 1 < ntiles) load(t + 1);
+    load(t + 1);
     const unsigned char* lk = ldsK + cur * ATT_TILE_BYTES;
     const unsigned char* lkt = ldsKt + cur * ATT_TILE_BYTES;
     const unsigned char* lv = ldsV + cur * ATT_TILE_BYTES;
@@ -203,8 +235,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         }
       }
     }
-    if (HAS_BIAS && t + 1 < ntiles) att_bias_load(bw, rbias, bvoff, t + 1);  // same registers, consumed next trip
-    if (t + 1 < ntiles) store(t + 1, cur ^ 1);
+    if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, t + 1);  // same registers, consumed next trip (past the last tile: unused)
+    store(t + 1, cur ^ 1);
     __syncthreads();
   }
 #pragma unroll
@@ -315,24 +347,43 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       const_cast<_Float16*>(HAS_BIAS ? p.dense_t + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048 : nullptr), 0,
       HAS_BIAS ? (uint32_t)p.dense_tiles * 4096u : 0, 0x00020000);
   const uint32_t bvoff = att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + wave, lane);
-  const att_rows2_t roq = att_rows2_init(p.ld_qkv, tid), roo = att_rows2_init(bp.ld_do, tid);
 
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
 
+  // ---- staging of the streamed tiles ------------------------------------------------------------------------------------
+  // Every trip of the tile loop issues the SAME vector-memory operations in the same order, none of them under a branch:
+  // 4 tile pieces, 1 statistic, 4 bias operands.  vmcnt is one in-order counter; where a path may or may not have issued
+  // a load (round 2: a plain / ragged tile branch, the statistics of waves 0-1 only, "if there is a next tile") the compiler
+  // has to assume it has not, and its wait for the OLDER bias operands at the first MFMA of a tile then also drained the
+  // tile loads issued a few cycles before: 2 000 of a tile's 7 400 cycles (s_memtime stamps, tools/scratch/attn_bench.hip).
+  // A trip past the last tile points every row out of range (zero fill, no traffic).
   u32x4 rq_[2], ro_[2];
   float rstat = 0.f;
+  bool rstat_ok = false;
+  const uint32_t chunk2 = (uint32_t)(tid & 7) * 16;
   auto load = [&](int t) {
     const int qp0 = sp.s_lo + t * ATT_BK;
-    att_rows2_load(rq_, rq, roq, ps, b, qp0, sp.s_hi, p.ld_qkv, h * 64, tid);
-    att_rows2_load(ro_, rdo, roo, ps, b, qp0, sp.s_hi, bp.ld_do, h * 64, tid);
-    if (tid < 128) {  // threads 0..63: -lse, 64..127: -delta of the tile's 64 query positions
-      const int qq = qp0 + (tid & 63);
-      const int row = qq < sp.s_hi ? att_row_of(ps, b, qq) : -1;
-      const float* src = tid < 64 ? bp.lse : bp.delta;
-      const float v = row >= 0 ? -src[(size_t)h * p.total_rows + row] : 0.f;
-      rstat = row >= 0 ? v : (tid < 64 ? -INFINITY : 0.f);  // absent queries: P = exp2(-inf) = 0
+    const int lim = t < ntiles ? sp.s_hi : 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pp = qp0 + ((tid + 256 * u) >> 3);
+      const bool txt = pp < ps.n0, img = pp >= ps.pos1 && pp < ps.NP;
+      const bool ok = (txt || img) && pp < lim;
+      const uint32_t row = (uint32_t)(txt ? ps.base0 + b * ps.n0 + pp : ps.base1 + b * ps.n1 + (pp - ps.pos1));
+      const uint32_t oq = ok ? (row * (uint32_t)p.ld_qkv + (uint32_t)h * 64) * 2 + chunk2 : 0xFFFFFFF0u;
+      const uint32_t oo = ok ? (row * (uint32_t)bp.ld_do + (uint32_t)h * 64) * 2 + chunk2 : 0xFFFFFFF0u;
+      rq_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, oq, 0, 0));
+      ro_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, oo, 0, 0));
+    }
+    {  // waves 0 / 2: lse, waves 1 / 3: delta of the tile's 64 query positions (waves 0 and 1 publish them).  RAW values: anything
+       // computed from them here would make the compiler wait for this load, and with it for the tile loads above
+      const int qq = qp0 + lane;
+      const int row = qq < lim ? att_row_of(ps, b, qq) : -1;
+      const float* src = (wave & 1) ? bp.delta : bp.lse;  // wave-uniform (a per-lane select loaded the POINTER through memory)
+      rstat = src[(size_t)h * p.total_rows + (row >= 0 ? row : 0)];
+      rstat_ok = row >= 0;
     }
   };
   auto store = [&](int buf) {
@@ -340,7 +391,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
     att_tile_store_tr(rq_, ldsQt + buf * ATT_TILE_BYTES, tid);
     att_tile_store_rows(ro_, ldsO + buf * ATT_TILE_BYTES, tid);
     att_tile_store_tr(ro_, ldsOt + buf * ATT_TILE_BYTES, tid);
-    if (tid < 128) qstat[buf * 128 + tid] = rstat;
+    if (wave < 2) qstat[buf * 128 + tid] = rstat_ok ? -rstat : (wave == 0 ? -INFINITY : 0.f);  // absent queries: P = exp2(-inf) = 0
   };
   att_bias_t bw;
   if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);
@@ -348,9 +399,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   store(0);
   __syncthreads();
 
+  int slot = 0;
+  (void)slot;
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) load(t + 1);
+    load(t + 1);
+    ATT_STAMP(slot++);  // next tile's loads issued
     const unsigned char* lq = ldsQ + cur * ATT_TILE_BYTES;
     const unsigned char* lqt = ldsQt + cur * ATT_TILE_BYTES;
     const unsigned char* lo = ldsO + cur * ATT_TILE_BYTES;
@@ -393,11 +447,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ss], vf[ss], dp, 0, 0, 0);   // dP[q][key]
 #endif
       }
+      ATT_STAMP(slot++);  // score / dP chains issued
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         e[i] = att_exp2(e[i]);  // P
         dp[i] *= e[i];          // dS (natural units)
       }
+      ATT_STAMP(slot++);  // exponentials issued
 #ifdef ATT_DIAG_HIST
       {
         const int base = 1300 + ((t * 2 + qb) * 29) % 1200;
@@ -428,10 +484,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, qb_, dk[db], 0, 0, 0);
         }
       }
+      ATT_STAMP(slot++);  // dV / dK products issued
     }
-    if (HAS_BIAS && t + 1 < ntiles) att_bias_load(bw, rbias, bvoff, t + 1);
-    if (t + 1 < ntiles) store(cur ^ 1);
+    if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, t + 1);  // (past the last tile: unused)
+    store(cur ^ 1);
+    ATT_STAMP(slot++);  // next tile stored to LDS
     __syncthreads();
+    ATT_STAMP(slot++);  // barrier passed
   }
 
 #ifdef ATT_DIAG_HIST
