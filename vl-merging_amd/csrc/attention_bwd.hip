@@ -363,19 +363,23 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   float rstat = 0.f;
   bool rstat_ok = false;
   const uint32_t chunk2 = (uint32_t)(tid & 7) * 16;
-  auto load = [&](int t) {
+  auto row_ok = [&](int pp, int lim, uint32_t& row) {
+    const bool txt = pp < ps.n0, img = pp >= ps.pos1 && pp < ps.NP;
+    row = (uint32_t)(txt ? ps.base0 + b * ps.n0 + pp : ps.base1 + b * ps.n1 + (pp - ps.pos1));
+    return (txt || img) && pp < lim;
+  };
+  // (Requesting dO after the first 32-query block and writing Q to LDS there -- half the burst behind the barrier, the two
+  // register sets never live together, 222 VGPRs -- measured the same: 700 / 706 vs 706 / 698 us.  So did issuing the exponentials of
+  // the score chain between the MFMAs of the dP chain: the wave's dependent chain, not a pipe, sets the time.)
+  auto load_q = [&](int t) {
     const int qp0 = sp.s_lo + t * ATT_BK;
     const int lim = t < ntiles ? sp.s_hi : 0;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int pp = qp0 + ((tid + 256 * u) >> 3);
-      const bool txt = pp < ps.n0, img = pp >= ps.pos1 && pp < ps.NP;
-      const bool ok = (txt || img) && pp < lim;
-      const uint32_t row = (uint32_t)(txt ? ps.base0 + b * ps.n0 + pp : ps.base1 + b * ps.n1 + (pp - ps.pos1));
-      const uint32_t oq = ok ? (row * (uint32_t)p.ld_qkv + (uint32_t)h * 64) * 2 + chunk2 : 0xFFFFFFF0u;
-      const uint32_t oo = ok ? (row * (uint32_t)bp.ld_do + (uint32_t)h * 64) * 2 + chunk2 : 0xFFFFFFF0u;
-      rq_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, oq, 0, 0));
-      ro_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, oo, 0, 0));
+      uint32_t row;
+      const bool ok = row_ok(qp0 + ((tid + 256 * u) >> 3), lim, row);
+      rq_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rq, ok ? (row * (uint32_t)p.ld_qkv + (uint32_t)h * 64) * 2 + chunk2 : 0xFFFFFFF0u, 0, 0));
     }
     {  // waves 0 / 2: lse, waves 1 / 3: delta of the tile's 64 query positions (waves 0 and 1 publish them).  RAW values: anything
        // computed from them here would make the compiler wait for this load, and with it for the tile loads above
@@ -386,13 +390,28 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       rstat_ok = row >= 0;
     }
   };
-  auto store = [&](int buf) {
+  auto load_o = [&](int t) {
+    const int qp0 = sp.s_lo + t * ATT_BK;
+    const int lim = t < ntiles ? sp.s_hi : 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint32_t row;
+      const bool ok = row_ok(qp0 + ((tid + 256 * u) >> 3), lim, row);
+      ro_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rdo, ok ? (row * (uint32_t)bp.ld_do + (uint32_t)h * 64) * 2 + chunk2 : 0xFFFFFFF0u, 0, 0));
+    }
+  };
+  auto store_q = [&](int buf) {
     att_tile_store_rows(rq_, ldsQ + buf * ATT_TILE_BYTES, tid);
     att_tile_store_tr(rq_, ldsQt + buf * ATT_TILE_BYTES, tid);
-    att_tile_store_rows(ro_, ldsO + buf * ATT_TILE_BYTES, tid);
-    att_tile_store_tr(ro_, ldsOt + buf * ATT_TILE_BYTES, tid);
     if (wave < 2) qstat[buf * 128 + tid] = rstat_ok ? -rstat : (wave == 0 ? -INFINITY : 0.f);  // absent queries: P = exp2(-inf) = 0
   };
+  auto store_o = [&](int buf) {
+    att_tile_store_rows(ro_, ldsO + buf * ATT_TILE_BYTES, tid);
+    att_tile_store_tr(ro_, ldsOt + buf * ATT_TILE_BYTES, tid);
+  };
+  auto load = [&](int t) { load_q(t); load_o(t); };
+  auto store = [&](int buf) { store_q(buf); store_o(buf); };
   att_bias_t bw;
   if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);
   load(0);
@@ -403,7 +422,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   (void)slot;
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
+#ifndef ATT_DKV_NOLOAD
     load(t + 1);
+#endif
     ATT_STAMP(slot++);  // next tile's loads issued
     const unsigned char* lq = ldsQ + cur * ATT_TILE_BYTES;
     const unsigned char* lqt = ldsQt + cur * ATT_TILE_BYTES;
@@ -435,7 +456,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] += kmaskv;
       }
+#ifndef ATT_DKV_NOBIAS
       if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[qb], e);
+#endif
+#ifdef ATT_DKV_NOC
+      if (false)
+#endif
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
 #ifndef ATT_DKV_PREFETCH
@@ -450,7 +476,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       ATT_STAMP(slot++);  // score / dP chains issued
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+#ifndef ATT_DKV_NOEXP
         e[i] = att_exp2(e[i]);  // P
+#endif
         dp[i] *= e[i];          // dS (natural units)
       }
       ATT_STAMP(slot++);  // exponentials issued
@@ -476,6 +504,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
           pf[j] = (bf16_t)e[8 * s2 + j];
           df[j] = (bf16_t)dp[8 * s2 + j];
         }
+#ifdef ATT_DKV_NOD
+        dv[0][s2] += (float)pf[0] + (float)df[3];
+        if (false)
+#endif
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16x8 ob = att_tr_frag(lot, qb * 32 + 16 * s2, db, lane);
@@ -486,10 +518,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       }
       ATT_STAMP(slot++);  // dV / dK products issued
     }
+#ifndef ATT_DKV_NOBIAS
     if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, t + 1);  // (past the last tile: unused)
+#endif
+#ifndef ATT_DKV_NOSTORE
     store(cur ^ 1);
+#endif
     ATT_STAMP(slot++);  // next tile stored to LDS
+#ifndef ATT_DKV_NOBAR
     __syncthreads();
+#endif
     ATT_STAMP(slot++);  // barrier passed
   }
 
@@ -498,6 +536,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   if (diag_hist[tid] == 12345.f) dk[0][0] += 1.f;  // keep the histogram alive
 #endif
   // ---- store dK, dV: accumulator rows = keys (registers), column = d (lane & 31) ---------------------------------------
+  // (2-byte stores, 64-byte segments per half wave.  Through a wave-private LDS transpose and 16-byte row stores instead:
+  // no difference, 714 vs 717 us for the backward pass at 88 samples -- what the stores cost, 16 us, is their traffic.)
   {
     const int kp0w = sp.p0 + wave * 32;
 #pragma unroll
@@ -505,7 +545,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       const int kl = (i & 3) + 8 * (i >> 2) + 4 * hh;
       const int kpi = kp0w + kl;
       const int row = kpi < sp.s_hi ? att_row_of(ps, b, kpi) : -1;
+#ifdef ATT_DKV_NOEPI
+      if (row == 123456789) {
+#else
       if (row >= 0) {
+#endif
         bf16_t* dst = bp.dqkv + (size_t)row * bp.ld_dqkv + D + h * 64 + r;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
