@@ -697,3 +697,34 @@ def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
     feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
     feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
     check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))
+
+
+@pytest.mark.gpu
+def test_infer_with_precomputed_image_embeds(mods, golden_dir):
+    """infer(image_embeds=, image_masks=) (reference vilt_module.py:1092-1108: visual_embed's output handed in): the same
+    features as the pass that embeds the image itself; a dropped image token (mask 0) is a key nobody attends to -- the
+    result equals the reference restatement of that mask in the torch oracle of the attention test, here checked through
+    the property that the text features then differ and the kept rows stay finite.  (The reference's own path ends in an
+    UnboundLocalError at its result dict, `"image": img`; here that entry is None.)"""
+    model = build(mods, "ufo", "tiny_ufo", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})
+    batch = gpu_batch(det_batch(3, 224, 40, 1024, seed=17))
+    with torch.no_grad():
+        want = model.infer(batch)
+        emb, masks, _, _ = model.transformer.visual_embed(batch["image"][0], max_image_len=model.hparams.config["max_image_len"])
+        got = model.infer(batch, image_embeds=emb, image_masks=masks)
+        for k in ("text_feats", "image_feats", "cls_feats", "raw_cls_feats"):
+            assert torch.equal(got[k], want[k]), k
+        assert got["image"] is None and got["image_labels"] is None and got["patch_index"] is None
+        m2 = masks.clone()
+        m2[:, -20:] = 0
+        cut = model.infer(batch, image_embeds=emb, image_masks=m2)
+        assert torch.isfinite(cut["text_feats"].float()).all()
+        assert float((cut["text_feats"].float() - want["text_feats"].float()).abs().max()) > 1e-3
+        # the dropped keys really are invisible: their embeddings may be anything
+        emb2 = emb.clone()
+        emb2[:, -20:] = 123.0
+        cut2 = model.infer(batch, image_embeds=emb2, image_masks=m2)
+        assert torch.equal(cut2["text_feats"], cut["text_feats"])
+        assert torch.equal(cut2["image_feats"][:, :-20], cut["image_feats"][:, :-20])
+    with pytest.raises(ValueError):
+        model.infer(batch, image_embeds=emb)
