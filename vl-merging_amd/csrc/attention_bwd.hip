@@ -929,15 +929,16 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   const uint32_t stat_base = (uint32_t)(((wave >> 1) * p.H + h) * p.total_rows);
   auto dma = [&](int b, int stage) {
     unsigned char* base = smem + stage * STAGE + wave * 1024;
-    const uint32_t ko = k_ok ? (uint32_t)(k_row0 + b * k_str) * (uint32_t)p.ld_qkv * 2 + schunk : 0xFFFFF000u;
-    const uint32_t qo = q_ok ? (uint32_t)(q_row0 + b * q_str) * (uint32_t)p.ld_qkv * 2 + schunk : 0xFFFFF000u;
-    const uint32_t oo = q_ok ? (uint32_t)(q_row0 + b * q_str) * (uint32_t)bp.ld_do * 2 + schunk : 0xFFFFF000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base), 16, ko, colK, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base + 2 * ATT_TILE_BYTES), 16, ko, colV, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base + 4 * ATT_TILE_BYTES), 16, qo, colQ, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (att_lds_void*)(base + 6 * ATT_TILE_BYTES), 16, oo, colQ, 0, 0);
+    // (the whole offset rides in the VECTOR operand: an absent row's 0xFFFFFFF0 is then out of range whatever else is added)
+    const uint32_t kb = (uint32_t)(k_row0 + b * k_str) * (uint32_t)p.ld_qkv * 2 + schunk;
+    const uint32_t qb2 = (uint32_t)(q_row0 + b * q_str) * (uint32_t)p.ld_qkv * 2 + schunk;
+    const uint32_t ob = (uint32_t)(q_row0 + b * q_str) * (uint32_t)bp.ld_do * 2 + schunk;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base), 16, k_ok ? kb + colK : 0xFFFFFFF0u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base + 2 * ATT_TILE_BYTES), 16, k_ok ? kb + colV : 0xFFFFFFF0u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (att_lds_void*)(base + 4 * ATT_TILE_BYTES), 16, q_ok ? qb2 + colQ : 0xFFFFFFF0u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (att_lds_void*)(base + 6 * ATT_TILE_BYTES), 16, q_ok ? ob + colQ : 0xFFFFFFF0u, 0, 0, 0);
     if (wave < 4) {  // -lse / c1 (waves 0, 1) and -delta (waves 2, 3) of the tile's 128 queries; absent queries read 0 (the table masks them)
-      const uint32_t so = s_ok ? (stat_base + (uint32_t)(s_row0 + b * s_str)) * 4 : 0xFFFFF000u;
+      const uint32_t so = s_ok ? (stat_base + (uint32_t)(s_row0 + b * s_str)) * 4 : 0xFFFFFFF0u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rst, (att_lds_void*)(smem + stage * STAGE + 8 * ATT_TILE_BYTES + wave * 256), 4, so, 0, 0, 0);
     }
   };

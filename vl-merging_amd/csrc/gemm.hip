@@ -1503,7 +1503,8 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
         const char* e = getenv("VLM_GEMM_TAIL_SPLIT");
         return e ? atoi(e) : 0;
       }();
-      const bool tail_split = (tail_split_env && gemm_big_mode() == 1) || gemm_big_mode() == 3;
+      const bool plain_out = !epi->residual && !c_is_f32;  // VLM_GEMM_TAIL_SPLIT=2: only calls without the fp32 residual epilogue
+      const bool tail_split = ((tail_split_env == 1 || (tail_split_env == 2 && plain_out)) && gemm_big_mode() == 1) || gemm_big_mode() == 3;
       const long full = big_tiles / cus, rem = big_tiles - full * cus, tn = (N + BIG_BN - 1) / BIG_BN;
       const long rows_big = (full * cus / tn) * BIG_BM;
       if (tail_split && full >= 1 && rem > 0 && rem * 10 <= (long)cus * 6 && !epi->col_sum &&
