@@ -302,10 +302,11 @@ typedef struct {
   float* dv[2];
 } vlm_attn_colsum_t;
 
-/* delta_ws: f32 scratch of ws_floats elements: at least H * total_rows (rowsum(dO*O)); with
- * vlm_attention_bwd_ws_floats(d, 1) elements the bias-table gradient's per-workgroup histograms are summed by a second
- * small launch instead of contended global atomics.  dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED.  colsum may
- * be NULL. */
+/* delta_ws: f32 scratch of ws_floats elements: at least H * total_rows (rowsum(dO*O)).  With a bias table,
+ * vlm_attention_bwd_ws_floats(d, 0) = 3 * H * total_rows also holds the C operands (-lse / (scale log2 e), -delta) of the
+ * 16-wave bias-table-gradient kernel (a smaller scratch selects the 8-wave kernel it replaced), and with
+ * vlm_attention_bwd_ws_floats(d, 1) elements the per-workgroup histograms are summed by a second small launch instead of
+ * global atomics (order-independent result).  dbias_t (f32 [n_cols, R], may be NULL) is ACCUMULATED.  colsum may be NULL. */
 size_t vlm_attention_bwd_ws_floats(const vlm_attn_desc_t* d, int with_dbias);
 int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out_bf16, int ld_out, const void* dout_bf16, int ld_dout,
                       const float* lse, float* delta_ws, size_t ws_floats, void* dqkv_bf16, int ld_dqkv, float* dbias_t,
