@@ -1,12 +1,12 @@
-// Fused attention backward: recompute-based (flash style), four launches per (layer, pass):
-//   1. delta[h][row] = sum_d dO*O
-//   2. dQ kernel  (query-stationary, same structure as the forward; lane <-> query)
+// Fused attention backward: recompute-based (flash style), three launches per (layer, pass):
+//   1. dQ kernel  (query-stationary, same structure as the forward; lane <-> query); its prologue also computes
+//        delta[h][row] = sum_d dO*O for its rows and publishes it for the kernels below
 //        S^T = K Q^T -> P^T = exp2(S2 - lse2) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - delta) ;
 //        dQ^T[d][q] += K^T . dS^T      (A = K^T by ds_read_b64_tr_b16, B = dS^T accumulator regs as bf16)
-//   3. dK/dV kernel (key-stationary; lane <-> key)
+//   2. dK/dV kernel (key-stationary; lane <-> key)
 //        S = Q K^T -> P ; dP = dO V^T ; dS = P o (dP - delta) ;
 //        dV[key][d] += P^T dO ,  dK[key][d] += scale * dS^T Q      (A = accumulator regs, B = dO / Q tr-read)
-//   4. dBias kernel (only when the bias table needs a gradient): batch-summed dS -> LDS histogram -> global atomics
+//   3. dBias kernel (only when the bias table needs a gradient): batch-summed dS -> LDS histogram -> global atomics
 // This is what autograd derives for reference vision_transformer.py:346-358 + F.embedding in get_rel_pos_bias
 // (vilt_module.py:1061-1064); the extra MFMA products (9 instead of 5) buy a deterministic dQ without atomics and a
 // bias gradient whose (slow) LDS atomics are amortised over the batch.
@@ -17,46 +17,20 @@
 #define ATT_STAMP(slot) do { } while (0)
 #endif
 
-// ------------------------------------------------------------------------------------------------------- delta
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int ld_o,
-                                                         const bf16_t* __restrict__ d_o, int ld_do, int rows, int H,
-                                                         float* __restrict__ delta, const float* __restrict__ lse,
-                                                         float* __restrict__ nstat, float inv_c1) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int D = H * 64;
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    for (int c = lane * 8; c < D; c += 512) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + (size_t)row * ld_o + c);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(d_o + (size_t)row * ld_do + c);
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)b[j];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if ((lane & 7) == 0) {
-        const size_t at = (size_t)(c >> 6) * rows + row;
-        delta[at] = s;
-        if (nstat) {  // C operands of attn_bwd_dbias16_kernel: -lse / c1 (scores stay unscaled there) and -delta
-          nstat[at] = -lse[at] * inv_c1;
-          nstat[(size_t)H * rows + at] = -s;
-        }
-      }
-    }
-  }
-}
-
 struct attn_bwd_params_t {
   attn_params_t f;        // forward description (qkv, bias, index, ranges)
   const bf16_t* d_o;      // [rows, H*64]
   int ld_do;
   const float* lse;       // [H, rows] log2 domain
-  const float* delta;     // [H, rows]
+  const bf16_t* o;        // [rows, H*64] forward output
+  int ld_o;
+  float* delta;           // [H, rows] rowsum(dO * O): written by the dQ kernel (every row belongs to one of its tiles), read by dK/dV
+  float inv_c1;           // 1 / (scale log2 e)
   bf16_t* dqkv;           // [rows, 3*H*64]
   int ld_dqkv;
   float* dbias_t;         // [n_cols, R] accumulate
   float* dbias_part;      // [items][R] per-workgroup histograms (two-stage reduction) or NULL (global atomics)
-  const float* nstat;     // [2][H][rows]: -lse / c1 and -delta (attn_delta_kernel) or NULL
+  float* nstat;           // [2][H][rows]: -lse / c1 and -delta for the 16-wave bias-gradient kernel (written by the dQ kernel) or NULL
   float* dq_colsum[2];    // per segment (0 text rows, 1 image rows): [H*64] += column sums of dQ (q_bias grad) or NULL
   float* dv_colsum[2];    // same for dV (v_bias gradient)
 };
@@ -107,8 +81,29 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
   }
   f32x16 neglse, negdel;
   {
-    const float l2 = qvalid ? -bp.lse[(size_t)h * p.total_rows + qrow] : -INFINITY;  // invalid rows: P = 0
-    const float dl = qvalid ? -bp.delta[(size_t)h * p.total_rows + qrow] : 0.f;
+    // delta = rowsum(dO * O) of this lane's query, from the dO fragments already in registers and the matching 32 values of O
+    // (the two lane halves hold complementary 8-column groups of the head): no separate pass over O and dO, and the value
+    // is published for the dK/dV and bias-gradient kernels that follow on the stream
+    const bf16_t* optr = bp.o + qrow * bp.ld_o + h * 64 + 8 * hh;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(optr + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += (float)raw[j] * (float)dof[s][j];
+    }
+    part += att_other_half(part);
+    const size_t at = (size_t)h * p.total_rows + qrow;
+    const float lse2 = qvalid ? bp.lse[at] : INFINITY;
+    if (qvalid && hh == 0) {
+      bp.delta[at] = part;
+      if (bp.nstat) {  // C operands of attn_bwd_dbias16_kernel: -lse / c1 (its scores stay unscaled) and -delta
+        bp.nstat[at] = -lse2 * bp.inv_c1;
+        bp.nstat[(size_t)p.H * p.total_rows + at] = -part;
+      }
+    }
+    const float l2 = -lse2;                  // invalid rows: -inf, P = 0
+    const float dl = qvalid ? -part : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { neglse[i] = l2; negdel[i] = dl; }
   }
@@ -835,7 +830,7 @@ __global__ __launch_bounds__(ATT_DB_THREADS, 2) void attn_bwd_dbias_kernel(const
 // vmcnt(0) wait and eight ds_write_b128 per thread to it.  Here wave (kw = wave & 3, qw = wave >> 2) owns 32 keys x 32
 // queries (16 accumulator registers), the four operand tiles of the next sample arrive by LDS-DMA (no staging registers: four
 // 1-KiB pieces per wave and sample, the row-image swizzle on the source side) and nothing is converted on the vector pipe:
-// K stays unscaled, the C operand of the score product is -lse / c1 (attn_delta_kernel writes it), the bias enters through
+// K stays unscaled, the C operand of the score product is -lse / c1 (the dQ kernel writes it), the bias enters through
 // selection MFMAs whose "one" is 1 / c1 split into an fp16 head and tail (products of fp16 values are exact in the fp32
 // accumulator), and P = exp2(c1 * e).  <= 128 VGPRs.
 #define ATT_DB16_THREADS 1024
@@ -1173,17 +1168,13 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   if (p.dense && p.dense_tiles != att_dense_layout(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode).tiles) return VLM_ERR_ARG;
   if (ws_floats < (size_t)p.H * p.total_rows) return VLM_ERR_WORKSPACE;  // delta[h][row]
   if (p.bias_t && dbias_t && ((size_t)p.R * 4 > 16 * ATT_TILE_BYTES || !p.idx_t)) return VLM_ERR_UNSUPPORTED;  // the histogram lives in the tile LDS
-  int cus = vlm_device_cus();
-  if (cus <= 0) cus = 256;
-  int dg = (p.total_rows + 3) / 4;
-  if (dg > cus * 8) dg = cus * 8;
-  // the 16-wave bias-gradient kernel needs its C operands from the delta launch: workspace = delta | nstat | histograms
+  // the 16-wave bias-gradient kernel takes its C operands from the dQ launch: workspace = delta | nstat | histograms
   const size_t hr = (size_t)p.H * p.total_rows;
   const bool db16 = p.bias_t && dbias_t && ws_floats >= 3 * hr && att_db16_enabled();
   bp.nstat = db16 ? delta_ws + hr : nullptr;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(dg), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(out), ld_out, bp.d_o,
-                     ld_dout, p.total_rows, p.H, delta_ws, lse, db16 ? delta_ws + hr : nullptr, 1.0f / (p.scale * ATT_LOG2E));
-  VLM_CHECK_LAUNCH();
+  bp.o = reinterpret_cast<const bf16_t*>(out);
+  bp.ld_o = ld_out;
+  bp.inv_c1 = 1.0f / (p.scale * ATT_LOG2E);
 
   const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
   dim3 grid(att_grid_size(nt, p.seq.B, p.H)), block(ATT_THREADS);
