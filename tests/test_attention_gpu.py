@@ -239,3 +239,31 @@ def test_eight_wave_bias_gradient_kernel_still_agrees():
                         "test_attention_bwd and True"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("k", [14, -24])
+def test_bias_gradient_fixed_point_histogram_follows_the_magnitude(ops, L, k):
+    """attn_bwd_dbias16_kernel sums dS in 64-bit fixed-point LDS bins whose step is 2^-48 of the work item's largest value:
+    scaling dO by 2^k (exact in bf16 and in every product on the way) must scale the bias-table gradient by 2^k -- no
+    overflow at large gradients, no underflow to zero at tiny ones (a fixed step would fail one of the two)."""
+    c = build_case(seed=4242, **CASES[-1])
+    seq = ops.Seq(c["B"], c["n0"], c["n1"])
+    rows, H, D = seq.rows, c["H"], c["D"]
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    dout = torch.randn(rows, D, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(H, rows, device="cuda")
+    bias_t = c["table"].t().contiguous()
+    kw = dict(bias_t=bias_t, head_row0=H, rel_index=c["idx"] * 4, rel_index_t=make_idx_t(c), keep0=c["keep0"], mode=L.ATTN_JOINT)
+    ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
+    res = []
+    for scale in (1.0, 2.0 ** k):
+        dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
+        dbias_t = torch.zeros_like(bias_t)
+        ops.attention_bwd(c["qkv"], out, (dout.float() * scale).to(torch.bfloat16), lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
+        torch.cuda.synchronize()
+        res.append(dbias_t[H:2 * H].double() / scale)
+    ref, got = res
+    assert float(ref.abs().max()) > 0
+    # the items' sums reach the table through float atomics in arrival order: last-bit differences only
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
