@@ -39,6 +39,8 @@ def main():
         ("fc1 bias+gelu+aux", lambda: ops.gemm(x768, w_fc1, o3072b, bias=bias3072, act=L.ACT_GELU, aux=aux), 3072, 768),
         ("fc2 dgrad plain", lambda: ops.gemm(x768, w_fc2, o3072b, False, True), 3072, 768),
         ("fc2 dgrad gelu_bwd", lambda: ops.gemm(x768, w_fc2, o3072b, False, True, act=L.ACT_GELU_BWD, aux=aux), 3072, 768),
+        ("fc1 bias+gelu+deriv", lambda: ops.gemm(x768, w_fc1, o3072b, bias=bias3072, act=L.ACT_GELU_DERIV, aux=aux), 3072, 768),
+        ("fc2 dgrad mul_aux", lambda: ops.gemm(x768, w_fc2, o3072b, False, True, act=L.ACT_MUL_AUX, aux=aux), 3072, 768),
     ]
     for name, fn, n, k in cases:
         us = timeit(fn)
