@@ -5,6 +5,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = re.sub(r"<.*", "<...>", name)
     name = name.replace("void ", "").replace("at::native::", "")
