@@ -9,8 +9,9 @@
  *   - return 0 on success, a negative VLM_ERR_* otherwise; nothing throws across the boundary;
  *   - process-wide state is limited to (1) diagnostic switches read ONCE from the environment at first use (VLM_GEMM_BIG,
  *     VLM_GEMM_BIGT, VLM_GEMM_STAGE, VLM_GEMM_SPLITK, VLM_GEMM_SPLITK_SLOTS, VLM_GEMM_GROUP_M, VLM_GEMM_BIG_GROUP_M,
- *     VLM_MERGE_VARIANT: thread-safe function-local statics, immutable afterwards) and (2) the test hook
- *     vlm_gemm_set_big_tile_mode (one atomic int).  Neither changes results beyond the fp32 summation order of a GEMM.
+ *     VLM_GEMM_TAIL_SPLIT, VLM_ATT_DB16, VLM_ATT_DB_GROUPS, VLM_MERGE_VARIANT: thread-safe function-local statics,
+ *     immutable afterwards) and (2) the test hook vlm_gemm_set_big_tile_mode (one atomic int).  None changes results
+ *     beyond the fp32 summation order of a GEMM or of the bias-table gradient.
  *
  * Token layout ("segment-major"): a pass over B samples with n0 text and n1 image tokens per sample keeps
  * activations as a [rows, D] matrix whose rows are  base0 + b*n0 + t  (t < n0)  and  base1 + b*n1 + (t-n0).
