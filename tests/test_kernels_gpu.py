@@ -136,6 +136,22 @@ def test_gemm_wgrad_splitk(ops):
     assert_close(out2, 0.5 * ref[:, :264], 1e-3, 2e-3 * math.sqrt(K), "split-K ragged")
 
 
+def test_gemm_dgrad_splitk_long_reduction(ops):
+    """The MLM decoder's dgrad shape: [880 x 30 528] . [30 528 x 768] -- 42 output tiles, a reduction of 30 528: with
+    accumulate=True into fp32 the library cuts K over one round of workgroups (ta = 0, tb = 1 split-K)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(23)
+    M, N, K = 880, 768, 30528
+    a = bf(torch.randn(M, K, device="cuda", generator=gen) * 0.1)
+    w = bf(torch.randn(K, N, device="cuda", generator=gen) * 0.1)
+    ref = a.float() @ w.float()
+    out = torch.full((M, N), -1.0, device="cuda")
+    ops.gemm(a, w, out, False, True, accumulate=True)
+    assert_close(out, ref - 1.0, 1e-3, 2e-5 * math.sqrt(K), "split-K dgrad")
+    out_b = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)   # the unsplit path of the same product
+    ops.gemm(a, w, out_b, False, True)
+    assert_close(out_b.float(), ref, 1e-2, 1e-2, "unsplit dgrad")
+
+
 def test_gemm_epilogues(ops, L):
     gen = torch.Generator(device="cuda"); gen.manual_seed(11)
     M, N, K = 617 * 2, 768, 768

@@ -1460,7 +1460,9 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
     const int rc = launch_gemm_bigT(p, epi, s);
     if (rc <= 0) return rc;
   }
-  if (gemm_splitk_enabled() && ta && tb && plain_acc && ntile < 512 && nk >= 32) {
+  // (ta = 0: a dgrad whose reduction is long and whose output is small -- the MLM decoder's, [880 x 30 522] . [30 522 x 768]: 42
+  // tiles on 256 CUs took 475 us)
+  if (gemm_splitk_enabled() && tb && plain_acc && ntile < 512 && nk >= 32) {
     int cus = vlm_device_cus();
     if (cus <= 0) cus = 256;
     // Slices so that the launch is ONE round of the 2 x CUs resident workgroups, never a little more: measured at
@@ -1479,7 +1481,8 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
       p.ksteps_per_split = (nk + splits - 1) / splits;
       p.splits = (nk + p.ksteps_per_split - 1) / p.ksteps_per_split;
       if (!group_m) p.group_m = p.tiles_n >= 12 ? 1 : 4;  // split-K (timed): co-resident blocks already share tiles across K slices
-      return launch_gemm<true, true, true, false, false, true>(p, s);
+      if (ta) return launch_gemm<true, true, true, false, false, true>(p, s);
+      return launch_gemm<false, true, true, false, false, true>(p, s);
     }
   }
   if (allow_big && !ta && !tb && (K % (4 * BIG_BK)) == 0 && gemm_big_mode() > 0) {

@@ -690,13 +690,17 @@ class _LinearFn(torch.autograd.Function):
             ops.gemm(dy[:, :N], x2, weight.grad, ta=True, tb=True, accumulate=True)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, device=x2.device, dtype=BF16)
-            if Np == N:
-                ops.gemm(dy, w16(weight), dx, tb=True)
+            # ragged N (vocab 30522): the reduction runs over the zero-padded Np columns of dy; the weight rows
+            # past N are whatever follows in the flat buffer (finite), multiplied by those zeros
+            wpad = w16(weight) if Np == N else torch.as_strided(w16(weight), (Np, K), (K, 1))
+            if Np >= 8192 and ((M + 127) // 128) * ((K + 127) // 128) <= 128:
+                # a long reduction into a small output (the MLM decoder: 42 tiles of 128 x 128 for 256 CUs, 475 us): the
+                # library's split-K path accumulates fp32 slices, one round of workgroups instead of a sixth of one
+                dx32 = torch.zeros(M, K, device=x2.device, dtype=F32)
+                ops.gemm(dy, wpad, dx32, tb=True, accumulate=True)
+                dx = dx32.to(BF16)
             else:
-                # ragged N (vocab 30522): the reduction runs over the zero-padded Np columns of dy; the weight rows
-                # past N are whatever follows in the flat buffer (finite), multiplied by those zeros
-                wpad = torch.as_strided(w16(weight), (Np, K), (K, 1))
+                dx = torch.empty(M, K, device=x2.device, dtype=BF16)
                 ops.gemm(dy, wpad, dx, tb=True)
             dx = dx.view(ctx.shape)
         return dx, None, None, None
