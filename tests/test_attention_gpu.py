@@ -266,4 +266,4 @@ def test_bias_gradient_fixed_point_histogram_follows_the_magnitude(ops, L, k):
     ref, got = res
     assert float(ref.abs().max()) > 0
     # the items' sums reach the table through float atomics in arrival order: last-bit differences only
-    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())  # (75 fp32 additions per bin, any order: <= 4.5e-6)
