@@ -80,6 +80,8 @@ def reference(c, layer, mode_sep, qkv=None):
     keep = torch.ones(B, N, dtype=torch.bool, device="cuda")
     if c["keep0"] is not None:
         keep[:, :n0] = c["keep0"].bool()
+    if c.get("keep1") is not None:
+        keep[:, n0:] = c["keep1"].bool()
     s = s.masked_fill(~keep[:, None, None, :], float("-inf"))
     if mode_sep:
         blk = torch.zeros(N, N, dtype=torch.bool, device="cuda")
@@ -267,3 +269,45 @@ def test_bias_gradient_fixed_point_histogram_follows_the_magnitude(ops, L, k):
     assert float(ref.abs().max()) > 0
     # the items' sums reach the table through float atomics in arrival order: last-bit differences only
     assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())  # (75 fp32 additions per bin, any order: <= 4.5e-6)
+
+
+@pytest.mark.parametrize("sep", [False, True])
+def test_attention_with_an_image_keep_mask(ops, L, sep):
+    """keep1 (dropped IMAGE tokens: infer(image_embeds=, image_masks=), vilt_module.py:1092-1108) through the forward kernel
+    and the three backward kernels, against the same fp32 restatement; the last image tokens of every sample and a few in
+    the middle are dropped."""
+    c = build_case(seed=777 + sep, **CASES[0])
+    B, n0, n1, H, D = c["B"], c["n0"], c["n1"], c["H"], c["D"]
+    keep1 = torch.ones(B, n1, dtype=torch.uint8, device="cuda")
+    keep1[:, -37:] = 0
+    keep1[0, 50:53] = 0
+    c["keep1"] = keep1
+    seq = ops.Seq(B, n0, n1)
+    rows, layer = seq.rows, 1
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    dout = torch.randn(rows, D, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(H, rows, device="cuda")
+    bias_t = c["table"].t().contiguous()
+    kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=c["idx"] * 4, rel_index_t=make_idx_t(c), keep0=c["keep0"], keep1=keep1,
+              mode=L.ATTN_SEPARATE if sep else L.ATTN_JOINT)
+    ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
+    dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
+    dbias_t = torch.zeros_like(bias_t)
+    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
+    torch.cuda.synchronize()
+    q32 = c["qkv"].float().requires_grad_(True)
+    tab = c["table"].clone().requires_grad_(True)
+    cc = dict(c); cc["table"] = tab
+    ref_o, _, _ = reference(cc, layer, sep, qkv=q32)
+    vmax = float(c["qkv"].float().abs().max())
+    assert bool(((out.float() - ref_o).abs() <= 2e-2 * vmax + 1e-2 * ref_o.abs()).all())
+    (ref_o * dout.float()).sum().backward()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        a, b = dqkv[:, sl].float(), q32.grad[:, sl]
+        assert bool(((a - b).abs() <= 3e-2 * float(b.abs().max()) + 3e-2 * b.abs()).all()), name
+    # dropped image keys receive no gradient at all
+    img = dqkv[B * n0:].view(B, n1, 3 * D)
+    assert float(img[:, -37:, D:].abs().max()) == 0.0
+    a, b = dbias_t[layer * H:(layer + 1) * H], tab.grad.t()[layer * H:(layer + 1) * H]
+    assert bool(((a - b).abs() <= 2e-2 * float(b.abs().max()) + 2e-2 * b.abs()).all())
