@@ -49,5 +49,10 @@ ev = [e for e in ev if e.key.startswith("aten::")]
 rows = sorted(ev, key=lambda e: -e.self_device_time_total)
 tot = sum(e.self_device_time_total for e in ev)
 print("total device time %.2f ms over 2 steps" % (tot / 1e3))
+import os
+flt = os.environ.get("VLM_PROFILE_FILTER")
+if flt:
+    import re as _re
+    rows = [e for e in rows if _re.search(flt, e.key)]
 for e in rows[:45]:
     print("%-28s n=%4d  dev %8.1f us  %s" % (e.key[:28], e.count, e.self_device_time_total, str(e.input_shapes)[:110]))
