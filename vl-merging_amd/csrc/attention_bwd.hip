@@ -838,7 +838,6 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   const attn_params_t& p = bp.f;
   constexpr int STAGE = 8 * ATT_TILE_BYTES + 1024;  // K, V (128 keys), Q, dO (128 queries) row images + (-lse / c1 | -delta)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
-  float* hist = reinterpret_cast<float*>(smem);  // aliases the tiles: only used after the sample loop
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -997,7 +996,7 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   // (47 of this kernel's 346 us at 88 samples), ds_add_u64 runs at the LDS array's rate -- and integer sums do not depend on
   // the order the waves arrive in.  The step is 2^-48 of the item's largest |sum of dS| (a bin receives at most 2^14 addends).
 #ifdef ATT_DB16_NOTAIL
-  if (acc[0] == 12345.f) hist[tid] = acc[1] + acc[7];
+  if (acc[0] == 12345.f) reinterpret_cast<float*>(smem)[tid] = acc[1] + acc[7];
   return;
 #endif
   unsigned long long* hist64 = reinterpret_cast<unsigned long long*>(smem);
@@ -1045,7 +1044,7 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
       for (int j = 0; j < 16; ++j)  // ids are byte offsets of 4-byte entries: 2 * ids addresses the 8-byte bin
         atomicAdd(reinterpret_cast<unsigned long long*>(smem + 2 * ids[j]), (unsigned long long)(long long)(acc[j] * FIX));
 #else
-      hist[tid] = acc[0] + acc[5] + (float)ids[3] + (float)ids[9];
+      reinterpret_cast<float*>(smem)[tid] = acc[0] + acc[5] + (float)ids[3] + (float)ids[9];
 #endif
     }
   }
