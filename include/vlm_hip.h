@@ -33,7 +33,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 5
+#define VLM_ABI_VERSION 6
 int vlm_abi_version(void);
 /* Number of compute units of the current device (grid sizing), or negative error. */
 int vlm_device_cus(void);
@@ -125,6 +125,27 @@ typedef struct {
 
 int vlm_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                   int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream);
+/* Grouped form of the ta = tb = 0 call (K9): row ranges of ONE activation matrix go through DIFFERENT weights -- the
+ * modality experts of an all_moe block act on the text rows and on the image rows of the segment-major token matrix
+ * (modules/vision_transformer.py:607-681: x[:, :max_text_len] through mlp['l'] / attn['l'], the rest through ['v'], then
+ * torch.cat) -- in one launch: the groups' 256-row tiles form one grid, so the small expert's tiles fill the large one's
+ * rounds instead of under-filling a launch of their own.  A, C, residual, aux and row_scale are the WHOLE matrices
+ * (a group's rows are [row0, row0 + rows) of each); bias, col_sum and col_sum_ws come per group (col_sum_ws rows are
+ * counted from the group's row0) and must be NULL in `epi`, as must splitk_ws; accumulate is not supported.  Groups are
+ * ascending and disjoint; empty groups are allowed.  Shapes the 256x256 kernel does not serve run as one vlm_gemm_bf16
+ * call per group on the same stream: same results either way. */
+#define VLM_GEMM_MAX_GROUPS 4
+typedef struct {
+  int32_t row0, rows;
+  const void* B;        /* bf16 [N][ldb]: this group's weight (nn.Linear layout) */
+  int32_t ldb;
+  int32_t reserved;
+  const float* bias;    /* f32 [N] or NULL */
+  float* col_sum;       /* f32 [N] or NULL */
+  float* col_sum_ws;    /* as vlm_epilogue_t.col_sum_ws: f32 [rows/128][2][N] */
+} vlm_gemm_group_t;
+int vlm_gemm_bf16_grouped(int n_groups, const vlm_gemm_group_t* groups, int N, int K, const void* A, int lda, void* C,
+                          int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream);
 /* Which kernel serves ta = tb = 0 calls: 0 the 128x128 tile always, 1 by shape (default; VLM_GEMM_BIG in the environment),
  * 2 the 256x256 tile whenever the call is legal for it, 3 by shape with the last partial round of tiles handed to the
  * 128x128 kernel as a second launch over the remaining rows, -1 back to the environment.  Tests and benchmarks only. */

@@ -611,3 +611,123 @@ def test_gemm_gelu_saved_derivative(ops, L, big_tile, M, N, K, mode):
         want = (dy.float() @ B.float().t()) * alpha * x.grad
         assert_close(o_new, want, 1e-2, 2e-2, "dh from the saved derivative")
         assert_close(o_old, want, 1e-2, 2e-2, "dh from the saved pre-activation")
+
+
+@pytest.mark.parametrize("rows,N,K", [((3520, 50776 // 8), 768, 768),      # text + image expert rows (image cut for test time)
+                                       ((880, 12694), 2304, 768),           # the 22-sample unimodal pair pass
+                                       ((256 * 2 + 9, 256 * 3 + 130), 256, 128),
+                                       ((40, 577), 512, 256),               # one sample: both groups ragged, one tile each
+                                       ((0, 700), 768, 128), ((700, 0), 768, 128),  # an empty expert on either side
+                                       ((300, 200, 100, 450), 256, 256),    # four groups
+                                       ((333, 444), 192, 192)])             # N % 256 != 0: served as one plain call per group
+def test_gemm_grouped_every_epilogue_variant(ops, L, big_tile, rows, N, K):
+    """vlm_gemm_bf16_grouped (the experts of an all_moe block in one launch, vision_transformer.py:607-681) against
+    (a) fp32 matmul of the bf16 operands per group and (b) one vlm_gemm_bf16 call per group: every epilogue variant a block
+    uses, rows of the NEXT group and guard rows behind the last one untouched by a group's ragged last tile."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(sum(rows) + N + K)
+    M = sum(rows)
+    bounds, r = [], 0
+    for n in rows:
+        bounds.append((r, r + n)); r += n
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    Ws = [bf(torch.randn(N, K, device="cuda", generator=gen)) for _ in rows]
+    biases = [torch.randn(N, device="cuda", generator=gen) for _ in rows]
+    alpha = 1.0 / math.sqrt(K)
+    ref = torch.cat([(A[r0:r1].float() @ W.float().t()) * alpha + b for (r0, r1), W, b in zip(bounds, Ws, biases)])
+    gamma = torch.randn(N, device="cuda", generator=gen) * 0.5
+    rs = (torch.rand(M, device="cuda", generator=gen) > 0.3).float() / 0.7
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    hpre = bf(torch.randn(M, N, device="cuda", generator=gen))
+
+    def groups(with_bias=True, col_sums=None):
+        return [(r0, r1, W, b if with_bias else None, col_sums[i] if col_sums else None)
+                for i, ((r0, r1), W, b) in enumerate(zip(bounds, Ws, biases))]
+
+    def run(grouped):
+        def call(a, out, with_bias=True, col_sums=None, **kw):
+            if grouped:
+                return ops.gemm_grouped(a, groups(with_bias, col_sums), out, alpha=alpha, **kw)
+            for i, (r0, r1, W, b, cs) in enumerate(groups(with_bias, col_sums)):
+                if r1 > r0:
+                    sl = {k: (v[r0:r1] if k in ("aux", "row_scale", "residual") and v is not None else v) for k, v in kw.items()}
+                    ops.gemm(a[r0:r1], W, out[r0:r1], bias=b, col_sum=cs, alpha=alpha, **sl)
+        r = {}
+        o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        call(A, o[:M])
+        r["bf16+bias"] = o
+        o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        h = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        call(A, o[:M], act=L.ACT_GELU_DERIV, aux=h[:M])
+        r["gelu"], r["gelu'"] = o, h
+        o = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        css = [torch.full((N,), 0.25 * (i + 1), device="cuda") for i in range(len(rows))]
+        call(A, o[:M], with_bias=False, col_sums=css, act=L.ACT_MUL_AUX, aux=hpre)
+        r["mul_aux"], r["col_sums"] = o, css
+        x = torch.full((M + 3, N), 7.0, device="cuda")
+        x[:M] = res
+        y = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        call(A, x[:M], col_scale=gamma, row_scale=rs, residual=x[:M], aux=y[:M])  # in place
+        r["residual stream"], r["branch"] = x, y
+        return r
+
+    g, s = run(True), run(False)
+    pre = ref.clone().requires_grad_(True)
+    act = torch.nn.functional.gelu(pre)
+    dact = torch.autograd.grad(act.sum(), pre)[0]
+    nob = ref - torch.cat([b[None].expand(r1 - r0, N) for (r0, r1), b in zip(bounds, biases)])
+    want = {"bf16+bias": ref, "gelu": act.detach(), "gelu'": dact, "mul_aux": nob * hpre.float(),
+            "residual stream": res + rs[:, None] * gamma[None] * ref, "branch": ref}
+    for k, w in want.items():
+        tol = (1e-2, 2e-2) if g[k].dtype == torch.bfloat16 else (1e-3, 5e-3)
+        assert_close(g[k][:M], w, tol[0], tol[1], "grouped " + k)
+        assert float((g[k][M:].float() - 7.0).abs().max()) == 0.0, "rows behind M were written: " + k
+        assert_close(g[k][:M], s[k][:M].float(), tol[0], tol[1], "grouped vs per-group " + k)
+    for i, (r0, r1) in enumerate(bounds):
+        wcs = (nob[r0:r1] * hpre[r0:r1].float()).sum(0) + 0.25 * (i + 1)
+        assert_close(g["col_sums"][i], wcs, 2e-3, 3e-2, "grouped col_sum of group %d" % i)
+        assert_close(g["col_sums"][i], s["col_sums"][i], 1e-3, 1e-2, "col_sum grouped vs per-group %d" % i)
+
+
+def test_gemm_grouped_col_sum_fold_and_group_isolation(ops, L, big_tile):
+    """Column sums of a grouped call through the fold workspace (a region per group, rows counted from the group's first
+    row), and the row bound between groups: a group's ragged last tile must neither read its operands from nor write into
+    the next group's rows (checked with a poisoned second group)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    N, K = 512, 256
+    bounds = [(0, 256 + 128 + 50), (256 + 128 + 50, 256 + 128 + 50 + 256 * 2 + 128 + 7)]
+    M = bounds[-1][1]
+    A = bf(torch.randn(M, K, device="cuda", generator=gen))
+    Ws = [bf(torch.randn(N, K, device="cuda", generator=gen)) for _ in bounds]
+    h = bf(torch.randn(M, N, device="cuda", generator=gen))
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    fold = ops.FoldBatch(A.device, N)
+    got = [torch.full((N,), 1.5, device="cuda"), torch.full((N,), -2.0, device="cuda")]
+    ops.gemm_grouped(A, [(r0, r1, W, None, cs) for (r0, r1), W, cs in zip(bounds, Ws, got)], out, act=L.ACT_MUL_AUX, aux=h,
+                     alpha=0.1, col_sum_fold=fold)
+    assert [j[1] for j in fold.jobs] == [(r1 - r0) // 128 for r0, r1 in bounds]
+    fold.flush()
+    for (r0, r1), W, cs, base in zip(bounds, Ws, got, (1.5, -2.0)):
+        w = (A[r0:r1].float() @ W.float().t()) * 0.1 * h[r0:r1].float()
+        assert_close(out[r0:r1], w, 1e-2, 2e-2, "grouped mul_aux rows %d:%d" % (r0, r1))
+        assert_close(cs, w.sum(0) + base, 2e-3, 2e-2, "grouped col_sum through the fold workspace")
+    # NaN in group 1's operand rows and weight: group 0's outputs and column sums must not see them
+    A2 = A.clone(); A2[bounds[1][0]:] = float("nan")
+    out2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    cs0 = torch.zeros(N, device="cuda")
+    ops.gemm_grouped(A2, [(bounds[0][0], bounds[0][1], Ws[0], None, cs0), (bounds[1][0], bounds[1][1], Ws[1] * float("nan"), None, None)],
+                     out2, act=L.ACT_MUL_AUX, aux=h, alpha=0.1)
+    assert torch.isfinite(out2[:bounds[0][1]].float()).all() and torch.isfinite(cs0).all()
+    assert torch.equal(out2[:bounds[0][1]], out[:bounds[0][1]])
+
+
+def test_gemm_grouped_argument_errors(ops, L):
+    A = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    W = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(L.VlmError):
+        ops.gemm_grouped(A, [(32, 64, W, None, None), (0, 32, W, None, None)], out)  # not ascending
+    with pytest.raises(L.VlmError):
+        ops.gemm_grouped(A, [(0, 40, W, None, None), (32, 64, W, None, None)], out)  # overlapping
+    with pytest.raises(L.VlmError):
+        ops.gemm_grouped(A, [(0, 16, W, None, None)] * 5, out)                       # too many groups
+    ops.gemm_grouped(A, [(0, 64, W, None, None)], out)

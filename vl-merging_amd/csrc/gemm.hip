@@ -156,6 +156,16 @@ __device__ __forceinline__ bf16x8 frag_load(const unsigned char* lds, int xblk /
   }
 }
 
+// One row range of a grouped call (vlm_gemm_bf16_grouped): its own weight, bias and column-sum targets; M tiles are counted
+// per group (tile0 = index of its first 256-row tile in the launch's tile grid).
+struct gemm_group_t {
+  const void* B;
+  const float* bias;
+  float* col_sum;
+  float* col_sum_ws;
+  int ldb, row0, row_end, tile0;
+};
+
 struct gemm_params_t {
   const void* A;
   const void* B;
@@ -166,6 +176,8 @@ struct gemm_params_t {
   int tiles_m, tiles_n;
   int group_m;  // raster group height in tiles (1 = row-major)
   int splits, ksteps_per_split;  // split-K (wgrad): block -> (tile, K slice), fp32 atomic accumulation
+  int n_groups;                  // 256x256 kernel, GROUPED instantiations only
+  gemm_group_t grp[VLM_GEMM_MAX_GROUPS];
 #ifdef VLM_GEMM_STAMPS
   unsigned long long* stamps;  // diagnostic build only (tools/stamp_gemm.py): 8 u64 per workgroup
 #endif
@@ -935,27 +947,50 @@ struct big_epilogue_t {
     ep.load_inputs(inB, q < 3 ? 2 * q + 3 : 7);                                                                    \
   }
 
-template <bool OUT_F32, bool RES, int AUX>
-__global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gemm_params_t p) {
+// GROUPED (vlm_gemm_bf16_grouped, the modality experts of an all_moe block in ONE launch, vision_transformer.py:607-681): the
+// M tiles of the grid are the concatenation of every group's own 256-row tiles; a workgroup takes the weight, bias,
+// column-sum targets and row bound of the group its tile belongs to (a scalar select over <= 4 groups) and is otherwise
+// the same kernel -- the text expert's 14 row tiles ride in the image expert's rounds instead of a launch of their own.
+template <bool OUT_F32, bool RES, int AUX, bool GROUPED = false>
+__global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gemm_params_t p_in) {
   __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char epl[4 * EPIL_WAVE_BYTES];  // wave-private epilogue transposes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  STAMP(0)
 
   const uint32_t nblk = gridDim.x, bid = blockIdx.x;
   const uint32_t q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   const uint32_t tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   uint32_t tm, tn;
   {
-    const uint32_t gm = (uint32_t)p.group_m, gsz = gm * p.tiles_n, grp = tile / gsz, first = grp * gm;
-    const uint32_t rows = min(gm, (uint32_t)p.tiles_m - first), in = tile - grp * gsz;
+    const uint32_t gm = (uint32_t)p_in.group_m, gsz = gm * p_in.tiles_n, grp = tile / gsz, first = grp * gm;
+    const uint32_t rows = min(gm, (uint32_t)p_in.tiles_m - first), in = tile - grp * gsz;
     tm = first + in % rows;
     tn = in / rows;
   }
-  const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG_BN;
+  gemm_params_t p_grp;  // GROUPED: this workgroup's view of the call (its group's weight, bias, column sums, row bound)
+  uint32_t m0 = tm * BIG_BM, tm_ws = tm;
+  if constexpr (GROUPED) {
+    p_grp = p_in;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < VLM_GEMM_MAX_GROUPS; ++i)
+      if (i < p_in.n_groups && tm >= (uint32_t)p_in.grp[i].tile0) g = i;
+    const gemm_group_t G = p_in.grp[g];
+    tm_ws = tm - (uint32_t)G.tile0;
+    m0 = (uint32_t)G.row0 + tm_ws * BIG_BM;
+    p_grp.M = G.row_end;
+    p_grp.B = G.B;
+    p_grp.ldb = G.ldb;
+    p_grp.epi.bias = G.bias;
+    p_grp.epi.col_sum = G.col_sum;
+    p_grp.epi.col_sum_ws = G.col_sum_ws;
+  }
+  const gemm_params_t& p = GROUPED ? p_grp : p_in;
+  STAMP(0)
+  const uint32_t n0 = tn * BIG_BN;
   const __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb =
@@ -1096,7 +1131,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   // (column sums: a wave covers its 128-row half alone -- workspace slot 2 tm + wm when the half is complete, else
   // atomics); the rest (ragged N, odd leading dimensions) take the generic 64x64 epilogue, column sums by atomics.
   {  // the launcher sends only shapes here whose wave tiles are whole in N and keep the 16-B alignments
-    float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm * 2 + wm) * 2) * p.N : nullptr;
+    float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm_ws * 2 + wm) * 2) * p.N : nullptr;
     BIG_EPILOGUE_LOOP()
     ep.finish(lane, ws_row);
   }
@@ -1287,9 +1322,9 @@ static int launch_gemm_bigT(gemm_params_t p, const vlm_epilogue_t* epi, hipStrea
   return VLM_OK;
 }
 
-template <bool OUT_F32, bool RES, int AUX>
+template <bool OUT_F32, bool RES, int AUX, bool GROUPED = false>
 static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
-  p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;
+  if (!GROUPED) p.tiles_m = (p.M + BIG_BM - 1) / BIG_BM;  // GROUPED: the caller counted every group's own tiles
   p.tiles_n = (p.N + BIG_BN - 1) / BIG_BN;
   static const int group_m = [] {
     const char* e = getenv("VLM_GEMM_BIG_GROUP_M");
@@ -1301,24 +1336,28 @@ static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
 #ifdef VLM_GEMM_STAMPS
   p.stamps = g_stamp_buffer;
 #endif
-  hipLaunchKernelGGL((vlm_gemm_big_kernel<OUT_F32, RES, AUX>), dim3(p.tiles_m * p.tiles_n), dim3(GEMM_THREADS), 0, stream, p);
+  hipLaunchKernelGGL((vlm_gemm_big_kernel<OUT_F32, RES, AUX, GROUPED>), dim3(p.tiles_m * p.tiles_n), dim3(GEMM_THREADS), 0, stream, p);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
 
 // The epilogue variants the 256x256 kernel is built for; anything else runs on the 128x128 kernel (return 1: not offered).
+// GROUPED: the four variants a transformer block's forward and dgrad GEMMs use.
+template <bool GROUPED = false>
 static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStream_t s) {
   const vlm_epilogue_t& e = p.epi;
   const bool res = e.residual != nullptr;
   const int aux = e.aux ? ((e.act == VLM_ACT_GELU_BWD || e.act == VLM_ACT_MUL_AUX) ? 2 : 1) : 0;
   if (e.row_scale && !res) return 1;
   if (!c_is_f32 && !res) {
-    if (aux == 0) return launch_gemm_big<false, false, 0>(p, s);
-    if (aux == 1) return launch_gemm_big<false, false, 1>(p, s);
-    return launch_gemm_big<false, false, 2>(p, s);
+    if (aux == 0) return launch_gemm_big<false, false, 0, GROUPED>(p, s);
+    if (aux == 1) return launch_gemm_big<false, false, 1, GROUPED>(p, s);
+    return launch_gemm_big<false, false, 2, GROUPED>(p, s);
   }
   if (c_is_f32 && aux != 2) {
-    if (res) return aux ? launch_gemm_big<true, true, 1>(p, s) : launch_gemm_big<true, true, 0>(p, s);
+    if (res && aux) return launch_gemm_big<true, true, 1, GROUPED>(p, s);
+    if (GROUPED) return 1;
+    if (res) return launch_gemm_big<true, true, 0>(p, s);
     if (aux == 0) return launch_gemm_big<true, false, 0>(p, s);
   }
   return 1;
@@ -1430,6 +1469,7 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   p.splits = 1;
   p.ksteps_per_split = 0;
+  p.n_groups = 0;
   // 0 = by shape.  Fabric-side fetch per launch at M = 54 296 (rocprofv3 FETCH_SIZE x 2, tools/pmc_gemm.py), group height
   // 1 / 4 / 8 / 16 / 32:  qkv fwd (operands 87 MB) 523 / 485 / 346 / 526 / 906 MB;  fc1 fwd 879 / 623 / 431 / 663 / 1277;
   // fc2 dgrad 1462 / 626 / 460 / 676 / 1143;  fc2 fwd (N = 768, K = 3072, operands 338 MB) 534 / 620 / 851 / 1023 / 1323.
@@ -1514,7 +1554,7 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
           rows_big > 0 && rows_big < M) {
         gemm_params_t p1 = p;
         p1.M = (int)rows_big;
-        const int rc = launch_gemm_big_variant(p1, c_is_f32 != 0, s);
+        const int rc = launch_gemm_big_variant<>(p1, c_is_f32 != 0, s);
         if (rc <= 0) {
           if (rc < 0) return rc;
           vlm_epilogue_t e2 = *epi;
@@ -1527,7 +1567,7 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
                                /*allow_big=*/false);
         }
       }
-      const int rc = launch_gemm_big_variant(p, c_is_f32 != 0, s);
+      const int rc = launch_gemm_big_variant<>(p, c_is_f32 != 0, s);
       if (rc <= 0) return rc;
     }
   }
@@ -1546,3 +1586,75 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
     default: return dispatch_stage<true, true, true>(p, s);
   }
 }
+
+// Grouped call: the row ranges of `groups` (ascending, disjoint) of ONE activation matrix go through different weights
+// (the modality experts of an all_moe block, vision_transformer.py:607-681) in one launch of the 256x256 kernel; shapes the
+// kernel does not serve (ragged N, tiny launches, other epilogue variants) run as one plain call per group on the same stream.
+extern "C" int vlm_gemm_bf16_grouped(int n_groups, const vlm_gemm_group_t* groups, int N, int K, const void* A, int lda, void* C,
+                                     int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream) {
+  if (n_groups < 1 || n_groups > VLM_GEMM_MAX_GROUPS || !groups || N < 0 || K < 0 || !C || !epi) return VLM_ERR_ARG;
+  if (epi->bias || epi->col_sum || epi->col_sum_ws || epi->splitk_ws) return VLM_ERR_ARG;  // per group, in vlm_gemm_group_t
+  int prev_end = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    const vlm_gemm_group_t& G = groups[g];
+    if (G.row0 < prev_end || G.rows < 0 || !G.B || (G.col_sum_ws && !G.col_sum)) return VLM_ERR_ARG;
+    prev_end = G.row0 + G.rows;
+  }
+  const int M_total = prev_end;
+  if (M_total == 0 || N == 0) return VLM_OK;
+  if (!A) return VLM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bool big = gemm_big_mode() > 0 && (K % (4 * BIG_BK)) == 0 && (N % BIG_BN) == 0 && !epi->accumulate && (lda & 7) == 0 &&
+             ((uintptr_t)A & 15) == 0 && ((uintptr_t)C & 15) == 0;
+  {  // the looped epilogue's 16-B vectors and 32-bit descriptor offsets (gemm_dispatch: v8, off32)
+    const bool v4 = ((ldc & 3) == 0) && (!epi->aux || (epi->ld_aux & 3) == 0) && (!epi->residual || (epi->ld_res & 3) == 0);
+    const bool v8 = v4 && (c_is_f32 || (ldc & 7) == 0) && (!epi->aux || ((epi->ld_aux & 7) == 0 && ((uintptr_t)epi->aux & 15) == 0)) &&
+                    (!epi->residual || ((uintptr_t)epi->residual & 15) == 0) && (!epi->col_scale || ((uintptr_t)epi->col_scale & 15) == 0);
+    const bool off32 = (uint64_t)M_total * ldc * 4 < (1ull << 31) && (!epi->residual || (uint64_t)M_total * epi->ld_res * 4 < (1ull << 31)) &&
+                       (!epi->aux || (uint64_t)M_total * epi->ld_aux * 2 < (1ull << 31)) && (uint64_t)M_total * lda * 2 < (1ull << 31);
+    big = big && v8 && off32;
+  }
+  gemm_params_t p;
+  p.A = A; p.B = nullptr; p.C = C;
+  p.M = M_total; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = 0; p.ldc = ldc;
+  p.epi = *epi;
+  p.epi.reserved = 1;
+  p.splits = 1;
+  p.ksteps_per_split = 0;
+  p.n_groups = 0;
+  int tiles = 0;
+  for (int g = 0; g < n_groups && big; ++g) {
+    const vlm_gemm_group_t& G = groups[g];
+    if (G.rows == 0) continue;
+    if ((G.ldb & 7) || ((uintptr_t)G.B & 15) || (uint64_t)N * G.ldb * 2 >= (1ull << 31) || (G.bias && ((uintptr_t)G.bias & 15))) big = false;
+    gemm_group_t& D = p.grp[p.n_groups++];
+    D.B = G.B; D.bias = G.bias; D.col_sum = G.col_sum; D.col_sum_ws = G.col_sum_ws;
+    D.ldb = G.ldb; D.row0 = G.row0; D.row_end = G.row0 + G.rows; D.tile0 = tiles;
+    tiles += (G.rows + BIG_BM - 1) / BIG_BM;
+  }
+  if (big && p.n_groups >= 1) {
+    int cus = vlm_device_cus();
+    if (cus <= 0) cus = 256;
+    p.tiles_m = tiles;
+    if (gemm_big_mode() >= 2 || 2l * tiles * (N / BIG_BN) >= cus) {
+      const int rc = launch_gemm_big_variant<true>(p, c_is_f32 != 0, s);
+      if (rc <= 0) return rc;
+    }
+  }
+  for (int g = 0; g < n_groups; ++g) {  // not offered: one plain call per group
+    const vlm_gemm_group_t& G = groups[g];
+    if (G.rows == 0) continue;
+    vlm_epilogue_t e = *epi;
+    const size_t r0 = (size_t)G.row0;
+    e.bias = G.bias; e.col_sum = G.col_sum; e.col_sum_ws = G.col_sum_ws;
+    if (e.residual) e.residual += r0 * e.ld_res;
+    if (e.aux) e.aux = reinterpret_cast<unsigned char*>(e.aux) + r0 * e.ld_aux * 2;
+    if (e.row_scale) e.row_scale += r0;
+    const int rc = gemm_dispatch(0, 0, G.rows, N, K, reinterpret_cast<const unsigned char*>(A) + r0 * lda * 2, lda, G.B, G.ldb,
+                                 reinterpret_cast<unsigned char*>(C) + r0 * ldc * (c_is_f32 ? 4 : 2), ldc, c_is_f32, &e, stream, true);
+    if (rc) return rc;
+  }
+  return VLM_OK;
+}
+

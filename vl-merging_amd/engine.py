@@ -193,11 +193,23 @@ class _Side:
 _EXPERTS = {"stream": None, "enabled": os.environ.get("VLM_EXPERT_STREAMS", "1") != "0"}
 
 
+# Grouped GEMM (default): the experts' forward and dgrad GEMMs of a block are ONE launch each over both row
+# ranges (ops.gemm_grouped): the text expert's 14 row tiles ride in the image expert's rounds of 256x256 tiles instead of
+# under-filling launches of their own on the 128x128 kernel (9.6 % of the all_moe step for 6.5 % of its rows).  The two-stream
+# schedule above is then off (every GEMM is a join).  VLM_GROUPED_GEMM=0: back to one launch chain per expert.
+_GROUPED = os.environ.get("VLM_GROUPED_GEMM", "1") != "0"
+
+
+def _use_grouped(ranges):
+    return _GROUPED and len(ranges) > 1 and all(wT16(getattr(e, n)) is not None for _, _, e in ranges
+                                                for n in ("qkvw", "projw", "fc1w", "fc2w"))
+
+
 class _ExpertStreams:
     def __init__(self, ranges):
         self.side = None
         self.small = -1
-        if _EXPERTS["enabled"] and len(ranges) > 1:
+        if _EXPERTS["enabled"] and len(ranges) > 1 and not _use_grouped(ranges):
             if _EXPERTS["stream"] is None:
                 _EXPERTS["stream"] = torch.cuda.Stream()
             self.side = _EXPERTS["stream"]
@@ -495,11 +507,17 @@ class _BlockFn(torch.autograd.Function):
         qkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
         rs1 = pc.drop_path_rows(plan.drop_prob, training, dev)
         rs2 = pc.drop_path_rows(plan.drop_prob, training, dev)
-        with _ExpertStreams(plan.ranges) as es:
-            for idx, (r0, r1, e) in enumerate(plan.ranges):
-                with es.on(idx):
-                    ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, ln1[r0:r1], st1[r0:r1])
-                    ops.gemm(ln1[r0:r1], w16(e.qkvw), qkv[r0:r1], bias=_qkv_bias(e))
+        grouped = _use_grouped(plan.ranges)
+        if grouped:
+            for r0, r1, e in plan.ranges:
+                ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, ln1[r0:r1], st1[r0:r1])
+            ops.gemm_grouped(ln1, [(r0, r1, w16(e.qkvw), _qkv_bias(e), None) for r0, r1, e in plan.ranges], qkv)
+        else:
+            with _ExpertStreams(plan.ranges) as es:
+                for idx, (r0, r1, e) in enumerate(plan.ranges):
+                    with es.on(idx):
+                        ops.layernorm_fwd(x[r0:r1], e.n1w, e.n1b, plan.eps, ln1[r0:r1], st1[r0:r1])
+                        ops.gemm(ln1[r0:r1], w16(e.qkvw), qkv[r0:r1], bias=_qkv_bias(e))
         o = torch.empty(M, D, device=dev, dtype=BF16)
         lse = torch.empty(H, M, device=dev, dtype=F32)
         rp = pc.relpos
@@ -515,8 +533,18 @@ class _BlockFn(torch.autograd.Function):
         a = torch.empty(M, Fdim, device=dev, dtype=BF16)
         x2 = torch.empty(M, D, device=dev, dtype=F32)
         y2 = torch.empty(M, D, device=dev, dtype=BF16)
-        with _ExpertStreams(plan.ranges) as es:  # each expert's proj -> LayerNorm -> fc1 -> fc2 chain is independent
-            for idx, (r0, r1, e) in enumerate(plan.ranges):
+        if grouped:
+            rg = plan.ranges
+            ops.gemm_grouped(o, [(r0, r1, w16(e.projw), e.projb, None) for r0, r1, e in rg], x1, col_scale=plan.gamma1,
+                             row_scale=rs1, residual=x, aux=y1)
+            for r0, r1, e in rg:
+                ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
+            ops.gemm_grouped(ln2, [(r0, r1, w16(e.fc1w), e.fc1b, None) for r0, r1, e in rg], a,
+                             act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h)
+            ops.gemm_grouped(a, [(r0, r1, w16(e.fc2w), e.fc2b, None) for r0, r1, e in rg], x2, col_scale=plan.gamma2,
+                             row_scale=rs2, residual=x1, aux=y2)
+        with _ExpertStreams(() if grouped else plan.ranges) as es:  # each expert's proj -> LayerNorm -> fc1 -> fc2 chain is independent
+            for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
                 with es.on(idx):
                     ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
                              row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
@@ -574,13 +602,44 @@ class _BlockFn(torch.autograd.Function):
         dx1 = torch.empty(M, D, device=dev, dtype=F32)
         # column partials (dgamma / dbeta / dbias) of the block's four row kernels are folded by ONE launch at the end
         fold = ops.FoldBatch(dev, D) if _DEFER_FOLD else None
-        if fold is not None and _EXPERTS["enabled"] and len(plan.ranges) > 1:
+        grouped = _use_grouped(plan.ranges)
+        if fold is not None and _EXPERTS["enabled"] and len(plan.ranges) > 1 and not grouped:
             fold.multi_stream = True  # the experts' row kernels run on two streams: fold only after the join
         # ---- FFN branch, then the attention branch up to the attention core: one independent chain per expert ----
         do = torch.empty(M, D, device=dev, dtype=BF16)
         fuse_b1 = _FUSE_FC1_BIAS and fold is not None
-        with _ExpertStreams(plan.ranges) as es:
-            for idx, (r0, r1, e) in enumerate(plan.ranges):
+        if grouped:
+            # the same chain with every dgrad as ONE grouped launch over the experts' row ranges; row kernels and wgrads
+            # stay per expert (their parameters and gradient targets differ)
+            rg = plan.ranges
+            act_bwd = L.ACT_MUL_AUX if _SAVE_DERIV else L.ACT_GELU_BWD
+            for r0, r1, e in rg:
+                rr = slice(r0, r1)
+                ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad,
+                                   fold=fold)
+            ops.gemm_grouped(dy2, [(r0, r1, wT16(e.fc2w), None, e.fc1b.grad if fuse_b1 else None) for r0, r1, e in rg], dh,
+                             act=act_bwd, aux=h, col_sum_fold=fold if fuse_b1 else None)
+            for r0, r1, e in rg:
+                rr = slice(r0, r1)
+                if not fuse_b1:
+                    ops.colsum(dh[rr], e.fc1b.grad)
+                with _Side(dy2, a, dh, ln2):
+                    ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
+                    ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
+            ops.gemm_grouped(dh, [(r0, r1, wT16(e.fc1w), None, None) for r0, r1, e in rg], dln)
+            for r0, r1, e in rg:
+                rr = slice(r0, r1)
+                ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
+                                  dbeta=e.n2b.grad, fold=fold)
+                ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad,
+                                   fold=fold)
+            ops.gemm_grouped(dy1, [(r0, r1, wT16(e.projw), None, None) for r0, r1, e in rg], do)
+            for r0, r1, e in rg:
+                rr = slice(r0, r1)
+                with _Side(dy1, o):
+                    ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
+        with _ExpertStreams(() if grouped else plan.ranges) as es:
+            for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
                 rr = slice(r0, r1)
                 with es.on(idx):
                     ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad,
@@ -615,8 +674,21 @@ class _BlockFn(torch.autograd.Function):
                           dq_colsum=qb_grads, dv_colsum=vb_grads,
                           bias_dense=rp.dense_for(pc.seq, plan.mode) if rp is not None else None)
         dx = torch.empty(M, D, device=dev, dtype=F32)
-        with _ExpertStreams(plan.ranges) as es:
-            for idx, (r0, r1, e) in enumerate(plan.ranges):
+        if grouped:
+            for r0, r1, e in plan.ranges:
+                rr = slice(r0, r1)
+                if e.qb is not None and not fused_qv:
+                    ops.colsum(dqkv[rr, :D], e.qb.grad)
+                    ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
+                with _Side(dqkv, ln1):
+                    ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
+            ops.gemm_grouped(dqkv, [(r0, r1, wT16(e.qkvw), None, None) for r0, r1, e in plan.ranges], dln1)
+            for r0, r1, e in plan.ranges:
+                rr = slice(r0, r1)
+                ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad,
+                                  dbeta=e.n1b.grad, fold=fold)
+        with _ExpertStreams(() if grouped else plan.ranges) as es:
+            for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
                 rr = slice(r0, r1)
                 with es.on(idx):
                     if e.qb is not None and not fused_qv:

@@ -77,6 +77,64 @@ def gemm(a, b, out, ta=False, tb=False, *, bias=None, act=L.ACT_NONE, aux=None, 
     return out
 
 
+def gemm_grouped(a, groups, out, *, act=L.ACT_NONE, aux=None, col_scale=None, row_scale=None, residual=None, alpha=1.0,
+                 col_sum_fold=None):
+    """out[r0:r1] = epilogue(a[r0:r1] @ w_g^T) for every group (r0, r1, w_g [N, K] bf16, bias_g or None, col_sum_g or None) in
+    ONE launch (include/vlm_hip.h vlm_gemm_bf16_grouped): the modality experts of an all_moe block
+    (vision_transformer.py:607-681).  aux / col_scale / row_scale / residual are whole-matrix epilogue inputs as in gemm()."""
+    L.require_cuda(a, out, aux, col_scale, row_scale, residual)
+    if a.dtype != BF16:
+        raise L.VlmError("gemm operands must be bfloat16")
+    if len(groups) < 1 or len(groups) > L.GEMM_MAX_GROUPS:
+        raise L.VlmError("gemm_grouped: 1..%d groups" % L.GEMM_MAX_GROUPS)
+    M, N = out.shape
+    K = a.shape[1]
+    if a.shape[0] != M:
+        raise L.VlmError("gemm_grouped: A rows %s do not match M=%d" % (tuple(a.shape), M))
+    e = L.Epilogue()
+    e.col_scale = col_scale.data_ptr() if col_scale is not None else 0
+    e.row_scale = row_scale.data_ptr() if row_scale is not None else 0
+    e.residual = residual.data_ptr() if residual is not None else 0
+    e.ld_res = _ld(residual) if residual is not None else 0
+    e.aux = aux.data_ptr() if aux is not None else 0
+    e.ld_aux = _ld(aux) if aux is not None else 0
+    e.act = act
+    e.alpha = alpha
+    for t, dt in ((col_scale, F32), (row_scale, F32), (residual, F32), (aux, BF16)):
+        if t is not None and t.dtype != dt:
+            raise L.VlmError("gemm epilogue tensor has dtype %s, expected %s" % (t.dtype, dt))
+    if out.dtype not in (BF16, F32):
+        raise L.VlmError("gemm output must be bf16 or f32")
+    arr = (L.GemmGroup * len(groups))()
+    folds = []
+    prev = 0
+    if col_sum_fold is not None and len(col_sum_fold.jobs) + len(groups) > col_sum_fold.MAX:
+        col_sum_fold.flush()  # never in the middle of this call: its regions are reserved before the launch that fills them
+    for g, (r0, r1, w, bias, col_sum) in zip(arr, groups):
+        L.require_cuda(w, bias, col_sum)
+        if w.dtype != BF16 or tuple(w.shape) != (N, K) or r0 < prev or r1 < r0 or r1 > M:
+            raise L.VlmError("gemm_grouped: group (%d, %d) weight %s for N=%d K=%d M=%d" % (r0, r1, tuple(w.shape), N, K, M))
+        prev = r1
+        for t in (bias, col_sum):
+            if t is not None and (t.dtype != F32 or t.numel() < N or not t.is_contiguous()):
+                raise L.VlmError("gemm_grouped: bias / col_sum must be contiguous f32 vectors of at least N elements")
+        g.row0, g.rows, g.B, g.ldb = r0, r1 - r0, w.data_ptr(), _ld(w)
+        g.bias = bias.data_ptr() if bias is not None else None
+        g.col_sum = col_sum.data_ptr() if col_sum is not None else None
+        rows = r1 - r0
+        if col_sum is not None and col_sum_fold is not None and N % 128 == 0 and rows >= 128:
+            region = col_sum_fold.next_region()
+            if region.numel() >= (rows // 128) * 2 * N:
+                g.col_sum_ws = region.data_ptr()
+                # reserve the region NOW (the next group's next_region() must not hand out the same one)
+                col_sum_fold.add(region, rows // 128, N, col_sum, None)
+                folds.append(region)
+    rc = L.get_lib().vlm_gemm_bf16_grouped(len(groups), arr, N, K, L.ptr(a), _ld(a), L.ptr(out), _ld(out),
+                                           int(out.dtype == F32), ctypes.byref(e), L.stream_ptr())
+    L.check(rc, "vlm_gemm_bf16_grouped")
+    return out
+
+
 _SPLITK_WS = {}
 SPLITK_WS_BYTES = 96 << 20
 
