@@ -28,35 +28,14 @@ import __graft_entry__ as ge  # noqa: E402
 FLOP_PER_SAMPLE_384 = 1835.1e9  # fwd 611.7 GFLOP x 3
 MFMA_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0
+F64_MFMA_PEAK_TFLOPS = 78.6     # the Gram / RegMean leg's roofline (v_mfma_f64_16x16x4_f64)
 
 
-def synthetic_batch(B, image_size, T, vocab, seed, device, mlm_prob=0.25):
-    """SURVEY.md 8(d): image ~ U(-1,1); ids: [CLS]=101, length ~ U{8..40}, ids ~ U{1000..vocab-1}, [SEP]=102, pad 0;
-    25 % of the non-special positions -> [MASK]=103 with the original id as label."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    image = torch.rand(B, 3, image_size, image_size, generator=g) * 2 - 1
-    ids = torch.zeros(B, T, dtype=torch.long)
-    masks = torch.zeros(B, T, dtype=torch.long)
-    ids_mlm = torch.zeros(B, T, dtype=torch.long)
-    labels_mlm = torch.full((B, T), -100, dtype=torch.long)
-    for b in range(B):
-        ln = int(torch.randint(8, T + 1, (1,), generator=g))
-        ids[b, 0] = 101
-        ids[b, 1:ln - 1] = torch.randint(1000, vocab, (ln - 2,), generator=g)
-        ids[b, ln - 1] = 102
-        masks[b, :ln] = 1
-        ids_mlm[b] = ids[b]
-        pick = torch.rand(ln - 2, generator=g) < mlm_prob
-        if not pick.any():
-            pick[0] = True
-        pos = pick.nonzero().squeeze(1) + 1
-        labels_mlm[b, pos] = ids[b, pos]
-        ids_mlm[b, pos] = 103
-    batch = {"image": [image.to(device)], "text_ids": ids.to(device), "text_masks": masks.to(device),
-             "text_labels": torch.full((B, T), -100, dtype=torch.long, device=device),
-             "text_ids_mlm": ids_mlm.to(device), "text_labels_mlm": labels_mlm.to(device)}
-    return {"vl": batch}
+def synthetic_batch(*a, **kw):
+    """The synthetic batch of SURVEY.md 8(d): lives in the package (vl_merging_amd.synthetic) so that run.py does not import the
+    benchmark; kept here as the name the tests and tools call."""
+    ge.import_package()
+    return importlib.import_module("vl_merging_amd.synthetic").synthetic_batch(*a, **kw)
 
 
 class GemmTimer:
@@ -275,6 +254,135 @@ def cpu_baseline():
     return res
 
 
+def secondary_benches(dev, cfgmod, vm, vu, steps=4, warm=2):
+    """The other BASELINE configs on ONE GPU, after the timed region (rank 0, N = 1 only; < 60 s together):
+    configs[2] all_moe B=22 per-GPU step, configs[4] irtr on ufo B=20 per-GPU step, configs[3]'s task-vector merge, RegMean at base
+    size (fp64 MFMA GEMMs + Cholesky solve) and the Gram capture SYRK, the last two against the fp64 MFMA roofline."""
+    import statistics
+    ops = importlib.import_module("vl_merging_amd.ops")
+    M = importlib.import_module("vl_merging_amd.merge")
+    bm = importlib.import_module("vl_merging_amd.bench_merge")
+    rg = importlib.import_module("vl_merging_amd.regmean")
+    out = {}
+
+    def timed_steps(step):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def train_leg(key, names, batch_of, B, **over):
+        try:
+            cfg = cfgmod.make_config(*names, image_size=384, vit="vit_base_patch16_384", per_gpu_batchsize=B, num_gpus=1, **over)
+            torch.manual_seed(0)
+            model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).to(dev)
+            model.train()
+            model.setup_engine()
+            (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"] or 1000)
+            batch = batch_of(synthetic_batch(B, 384, cfg["max_text_len"], cfg["vocab_size"], 1234, dev))
+
+            def step():
+                loss = model.training_step(batch, 0)
+                loss.backward()
+                opt.step()
+                sch["scheduler"].step()
+
+            dt = timed_steps(step)
+            out[key] = {"samples_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B, "steps": steps, "warmup": warm}
+            del model, opt, sch, batch
+        except Exception as e:  # a secondary leg must never take the headline number down with it
+            out[key] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
+    train_leg("all_moe_b22", ("task_mlm_itm_ifm_square_randaug_base_vl", "step200k", "all_moe"), lambda b: b, 22, vl_mlm_prob=0.25)
+    train_leg("irtr_ufo_b20", ("task_finetune_irtr_coco_square_randaug_base_image384", "ufo"), lambda b: b["vl"], 20)
+
+    def ev_median(fn, reps=5, warmup=2):
+        for _ in range(warmup):
+            fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        return statistics.median(ts)
+
+    try:  # task-vector merge (vilt_module.py:640-746): all_moe experts + a central ufo checkpoint -> ufo
+        sd = bm.synthetic_all_moe_blocks()
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        central = {}
+        for k, v in sd.items():
+            dst = k.replace(".v.", ".").replace(".l.", ".").replace(".vl.", ".")
+            if dst not in central:
+                central[dst] = torch.randn(v.shape, device="cuda", generator=gen) * 0.02
+        cfg = dict(vlffn_start_layer_index=10, only_activate_used_experts=False, sum_lambda=0.75, loss_names={})
+        plans = []
+        M.sum_task_vectors(sd, cfg, central_weight=central, plan_out=plans)
+        plan = plans[0]
+        t = ev_median(plan.run, reps=10, warmup=3)
+        nbytes = plan.bytes_read + plan.bytes_written
+        out["task_vector"] = {"GBps": nbytes / t / 1e9, "seconds_median": t, "algorithmic_bytes": nbytes,
+                              "frac_of_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBPS}
+        del central, plans, plan
+    except Exception as e:
+        out["task_vector"] = {"error": repr(e)}
+    try:  # RegMean at base size, device-resident inputs (vilt_module.py:366-531): W.G GEMMs, Cholesky, two triangular solves
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        grams = {}
+        for k, v in sd.items():
+            if k.endswith(".weight") and "norm" not in k and ".vl." not in k:
+                name = k.replace(".qkv.weight", "") if "qkv" in k else k.replace(".weight", "")
+                D = v.shape[1]
+                x = torch.randn(D + 64, D, device="cuda", dtype=torch.float64, generator=gen)
+                grams[name] = x.t() @ x
+        cfg = dict(vlffn_start_layer_index=10, only_activate_used_experts=False, scaling_for_non_diag=0.9,
+                   loss_names={"irtr": 1}, gram_matrices=None)
+        res = rg.regmean(sd, cfg, gram_matrices=grams)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = rg.regmean(sd, cfg, gram_matrices=grams)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = statistics.median(ts)
+        # per merged weight [out, in] of two experts: 2 products W_m G'_m (2 out in^2 each), Cholesky in^3 / 3, two triangular
+        # solves of `out` right-hand sides (out in^2 each)
+        fl = sum(2 * 2.0 * v.shape[0] * v.shape[1] ** 2 + v.shape[1] ** 3 / 3.0 + 2.0 * v.shape[0] * v.shape[1] ** 2
+                 for k, v in res.items() if k.endswith(".weight") and v.dim() == 2 and "norm" not in k and "blocks" in k)
+        out["regmean_base"] = {"seconds": dt, "seconds_min_max": [min(ts), max(ts)], "fp64_flop": fl, "fp64_tflops": fl / dt / 1e12,
+                               "frac_of_fp64_mfma_peak": fl / dt / 1e12 / F64_MFMA_PEAK_TFLOPS, "peak_tflops": F64_MFMA_PEAK_TFLOPS,
+                               "note": "wall time of the whole merge (48 weight solves + HIP averages, ~1000 launches from Python); "
+                                       "the GEMM kernel alone: gram_capture_base"}
+        del grams, res, sd
+    except Exception as e:
+        out["regmean_base"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:  # Gram capture (cache_gram_matrices.py:246-254): G += X^T X in fp64 on the device, X = one hooked input of the 88-sample pass
+        legs = {}
+        for D in (768, 3072):
+            rows = 54296
+            x = torch.randn(rows, D, device=dev).to(torch.bfloat16)
+            g = torch.zeros(D, D, device=dev, dtype=torch.float64)
+            t = ev_median(lambda: ops.gram_accumulate(x, g), reps=5, warmup=1)
+            fl = 2.0 * rows * D * D  # the reference's X^T X (torch.matmul computes the full product; the SYRK does half of it)
+            legs["D%d" % D] = {"seconds_median": t, "rows": rows, "tflops_over_2MD2": fl / t / 1e12,
+                               "frac_of_fp64_mfma_peak": fl / t / 1e12 / F64_MFMA_PEAK_TFLOPS}
+            del x, g
+        out["gram_capture_base"] = dict(legs, peak_tflops=F64_MFMA_PEAK_TFLOPS, kernel="gram_f64_kernel")
+    except Exception as e:
+        out["gram_capture_base"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -358,6 +466,8 @@ def main():
                     help="bracket the GEMM launches of every n-th timed step with HIP events (all 8 steps cost 3 %% of "
                          "the step: 2x1000 event records; every 4th keeps that under 1 %%)")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the attainable-peak probes")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs' legs (all_moe, irtr, task vector, "
+                                                                "RegMean, Gram capture)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -492,6 +602,8 @@ def main():
                             "roofline": {"bound": "hbm", "achieved": m["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                          "frac": m["GBps"] / HBM_PEAK_GBPS,
                                          "traffic": pmc_traffic("vlm_merge_kernel"), "kernel": "vlm_merge_kernel"}}
+        if not args.no_secondary and world == 1 and not force_dist and args.arch == "ufo":
+            out["secondary"] = secondary_benches(dev, cfgmod, vm, vu)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -9,7 +9,7 @@
  *   - return 0 on success, a negative VLM_ERR_* otherwise; nothing throws across the boundary;
  *   - process-wide state is limited to (1) diagnostic switches read ONCE from the environment at first use (VLM_GEMM_BIG,
  *     VLM_GEMM_BIGT, VLM_GEMM_STAGE, VLM_GEMM_SPLITK, VLM_GEMM_SPLITK_SLOTS, VLM_GEMM_GROUP_M, VLM_GEMM_BIG_GROUP_M,
- *     VLM_GEMM_TAIL_SPLIT, VLM_ATT_DB16, VLM_ATT_DB_GROUPS, VLM_MERGE_VARIANT: thread-safe function-local statics,
+ *     VLM_GEMM_TAIL_SPLIT, VLM_ATT_DB_GROUPS, VLM_MERGE_VARIANT: thread-safe function-local statics,
  *     immutable afterwards) and (2) the test hook vlm_gemm_set_big_tile_mode (one atomic int).  None changes results
  *     beyond the fp32 summation order of a GEMM or of the bias-table gradient.
  *
@@ -146,6 +146,21 @@ typedef struct {
 } vlm_gemm_group_t;
 int vlm_gemm_bf16_grouped(int n_groups, const vlm_gemm_group_t* groups, int N, int K, const void* A, int lda, void* C,
                           int ldc, int c_is_f32, const vlm_epilogue_t* epi, void* stream);
+/* Grouped weight gradients (the autograd backward of the grouped call): for every group of TOKEN rows [row0, row0 + rows) of
+ * A = dY [tokens][lda] and B = X [tokens][ldb] (both bf16, token-major: ta = tb = 1 of vlm_gemm_bf16),
+ *   C_g[M,N] (+)= A[rows_g]^T . B[rows_g]      (f32, ldc; accumulate per group)
+ * in one launch of the 256x256 wgrad kernel plus one reduce launch: the K slices of all groups share one round of
+ * workgroups, each group's share following its token count.  splitk_ws as in vlm_epilogue_t (without it, or for shapes the
+ * kernel does not serve: one vlm_gemm_bf16 call per group on the same stream; an empty group leaves C_g unchanged when
+ * accumulating and zeroes it otherwise). */
+typedef struct {
+  int32_t row0, rows;
+  float* C;
+  int32_t accumulate;
+  int32_t reserved;
+} vlm_wgrad_group_t;
+int vlm_gemm_wgrad_grouped(int n_groups, const vlm_wgrad_group_t* groups, int M, int N, const void* A, int lda,
+                           const void* B, int ldb, int ldc, float* splitk_ws, uint64_t splitk_ws_bytes, void* stream);
 /* Which kernel serves ta = tb = 0 calls: 0 the 128x128 tile always, 1 by shape (default; VLM_GEMM_BIG in the environment),
  * 2 the 256x256 tile whenever the call is legal for it, 3 by shape with the last partial round of tiles handed to the
  * 128x128 kernel as a second launch over the remaining rows, -1 back to the environment.  Tests and benchmarks only. */

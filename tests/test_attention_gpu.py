@@ -228,21 +228,6 @@ def test_bias_dense_tables(ops, L, ci, sep):
             first += nsb * nst
 
 
-def test_eight_wave_bias_gradient_kernel_still_agrees():
-    """attn_bwd_dbias16_kernel is what runs by default; VLM_ATT_DB16=0 (parsed once per process) selects the 8-wave kernel it
-    replaced, kept for A/B runs: the biased backward cases must pass with it too."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("VLM_ATT_DB16") == "0":
-        pytest.skip("already the 8-wave run")
-    env = dict(os.environ, VLM_ATT_DB16="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "test_attention_bwd and True"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
-
 @pytest.mark.parametrize("k", [14, -24])
 def test_bias_gradient_fixed_point_histogram_follows_the_magnitude(ops, L, k):
     """attn_bwd_dbias16_kernel sums dS in 64-bit fixed-point LDS bins whose step is 2^-48 of the work item's largest value:

@@ -29,6 +29,14 @@ def test_bench_json_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
     m = d["merge"]
     assert m["roofline"]["bound"] == "hbm" and m["algorithmic_bytes"] == 1077239808 and 0.3 < m["roofline"]["frac"] < 1.0
+    # the other BASELINE configs, measured in the same run (configs[2], [4], [3]'s task-vector / RegMean / Gram legs)
+    sec = d["secondary"]
+    for k in ("all_moe_b22", "irtr_ufo_b20", "task_vector", "regmean_base", "gram_capture_base"):
+        assert k in sec and "error" not in sec[k], (k, sec.get(k))
+    assert sec["all_moe_b22"]["samples_per_s"] > 50 and sec["irtr_ufo_b20"]["samples_per_s"] > 50
+    assert 0.3 < sec["task_vector"]["frac_of_hbm_peak"] < 1.0
+    assert 0.0 < sec["regmean_base"]["frac_of_fp64_mfma_peak"] < 1.0 and sec["regmean_base"]["seconds"] < 10
+    assert all(0.0 < sec["gram_capture_base"][k]["frac_of_fp64_mfma_peak"] < 1.0 for k in ("D768", "D3072"))
 
 
 def _run_bench(argv, env=None, timeout=900):

@@ -731,3 +731,30 @@ def test_gemm_grouped_argument_errors(ops, L):
     with pytest.raises(L.VlmError):
         ops.gemm_grouped(A, [(0, 16, W, None, None)] * 5, out)                       # too many groups
     ops.gemm_grouped(A, [(0, 64, W, None, None)], out)
+
+
+@pytest.mark.parametrize("rows,M,N", [((3520, 6000), 768, 768), ((880, 12694), 2304, 768), ((40, 577), 256, 512),
+                                       ((0, 900), 768, 256), ((900, 0), 768, 256), ((130, 70, 333, 64), 256, 256),
+                                       ((500, 700), 192, 192)])  # N % 256 != 0: one plain call per group
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_wgrad_grouped(ops, L, big_tile, rows, M, N, accumulate):
+    """vlm_gemm_wgrad_grouped: dW_g (+)= dY[rows_g]^T X[rows_g] for the experts of a block in one launch, against fp32 matmul
+    per group and against one wgrad call per group; ragged token counts (not multiples of 32), empty groups."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(sum(rows) + M + N)
+    T = sum(rows)
+    bounds, r = [], 0
+    for n in rows:
+        bounds.append((r, r + n)); r += n
+    dy = bf(torch.randn(T, M, device="cuda", generator=gen))
+    x = bf(torch.randn(T, N, device="cuda", generator=gen))
+    base = [torch.randn(M, N, device="cuda", generator=gen) for _ in rows]
+    got = [b.clone() for b in base]
+    ops.gemm_wgrad_grouped(dy, x, [(r0, r1, g) for (r0, r1), g in zip(bounds, got)], accumulate=accumulate)
+    for (r0, r1), g, b in zip(bounds, got, base):
+        want = dy[r0:r1].float().t() @ x[r0:r1].float() + (b if accumulate else 0)
+        tol = 2e-3 * math.sqrt(max(r1 - r0, 1))
+        assert_close(g, want, 1e-3, tol, "grouped wgrad rows %d:%d" % (r0, r1))
+        if r1 > r0:
+            one = b.clone()
+            ops.gemm(dy[r0:r1], x[r0:r1], one, ta=True, tb=True, accumulate=accumulate)
+            assert_close(g, one, 1e-3, tol, "grouped vs plain wgrad rows %d:%d" % (r0, r1))

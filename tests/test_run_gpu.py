@@ -61,7 +61,7 @@ def test_fit_save_reload_resume(run_mod, pkg, shards, tmp_path):
     r2 = run_mod.main(args + ["steps=2", "resume_during_pretraining=True"])
     assert r2["global_step"] == 5 and r2["last_ckpt"] == path  # save_last overwrites the run's last.ckpt
     c2 = ck.load_file(path)
-    assert c2["global_step"] == 5 and c2["lr_schedulers"][0]["last_epoch"] == 5 and c2["optimizer_states"][0]["step"] == 5
+    assert c2["global_step"] == 5 and c2["lr_schedulers"][0]["last_epoch"] == 5 and c2["optimizer_states"][0]["vlm_step"] == 5
     moved = [n for n in ckpt["state_dict"] if ckpt["state_dict"][n].is_floating_point()
              and not torch.equal(ckpt["state_dict"][n], c2["state_dict"][n])]
     assert "transformer.blocks.0.attn.qkv.weight" in moved
@@ -82,3 +82,131 @@ def test_test_only_irtr_recall(run_mod, pkg, shards, tmp_path):
     for k in ("ir_r1", "ir_r5", "ir_r10", "tr_r1", "tr_r5", "tr_r10"):
         assert 0.0 <= res["recalls/" + k] <= 1.0
     assert res["recalls/ir_r10"] >= res["recalls/ir_r1"] and res["recalls/tr_r10"] >= res["recalls/tr_r1"]
+
+
+def _reference_groups(model, vu):
+    """The reference's optimizer_grouped_parameters (vilt_utils.py:272-312): four filters over named_parameters()."""
+    heads = vu.head_names(model.hparams.config)
+    groups = [[] for _ in range(4)]
+    for n, p in model.named_parameters():
+        groups[vu.param_group_of(n, heads)].append((n, p))
+    return groups
+
+
+def test_optimizer_states_are_torch_layout_both_ways(run_mod, pkg, shards, tmp_path):
+    """`optimizer_states[0]` of a last.ckpt written here loads into a torch.optim optimizer built the reference's way (what
+    Lightning's resume_from_checkpoint does with it), and a state_dict written BY such an optimizer (no vlm_* keys: a
+    reference-written last.ckpt) loads here with every moment at its parameter's place."""
+    cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
+    vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
+    vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
+    ck = importlib.import_module("vl_merging_amd.checkpoint")
+    args = PRETRAIN + ["data_root=" + shards, "log_dir=" + str(tmp_path / "result")]
+    r1 = run_mod.main(args + ["steps=2"])
+    ckpt = ck.load_file(r1["last_ckpt"])
+    osd = ckpt["optimizer_states"][0]
+    cfg = cfgmod.parse_cli(PRETRAIN[1:])
+    ref_model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))  # CPU, plain nn.Parameters
+    groups = _reference_groups(ref_model, vu)
+    assert [len(g["params"]) for g in osd["param_groups"]] == [len(g) for g in groups]
+    assert all(isinstance(k, int) for k in osd["state"]) and osd["state"], "torch keys optimizer state by parameter index"
+    t_opt = torch.optim.AdamW([{"params": [p for _, p in g]} for g in groups], lr=1e-3)
+    t_opt.load_state_dict({"state": osd["state"], "param_groups": osd["param_groups"]})  # torch validates sizes and ids
+    names = [n for g in groups for n, _ in g]
+    params = [p for g in groups for _, p in g]
+    for i, st in osd["state"].items():
+        assert st["exp_avg"].shape == params[i].shape and st["step"] == 2, names[i]
+        assert torch.equal(t_opt.state[params[i]]["exp_avg"], st["exp_avg"])
+    assert osd["vlm_names"] == names
+    i_qkv = names.index("transformer.blocks.0.attn.qkv.weight")
+    assert float(osd["state"][i_qkv]["exp_avg"].abs().max()) > 0 and float(osd["state"][i_qkv]["exp_avg_sq"].abs().max()) > 0
+    assert names.index("transformer.mask_token") not in osd["state"]  # never received a gradient: no Adam state (HF AdamW)
+
+    # the other direction: a torch-written state (one step of torch.optim.AdamW on known gradients) -> this engine
+    for p in params:
+        p.grad = torch.full_like(p, 0.25)
+    params[names.index("transformer.mask_token")].grad = None
+    t2 = torch.optim.AdamW([{"params": [p for _, p in g], "lr": 1e-3, "initial_lr": 1e-3, "weight_decay": 0.01} for g in groups],
+                           betas=(0.9, 0.98), eps=1e-8)
+    t2.step()
+    foreign = t2.state_dict()
+    assert "vlm_names" not in foreign
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).cuda()
+    model.setup_engine()
+    (opt,), _ = vu.set_schedule(model, max_steps=8)
+    opt.load_state_dict(foreign)
+    assert opt.step_count == 1
+    f = model._flat
+    for n in ("transformer.blocks.0.attn.qkv.weight", "text_embeddings.word_embeddings.weight", "itm_score.fc.bias"):
+        o, k = f.offsets[n]
+        want = foreign["state"][names.index(n)]
+        assert torch.equal(opt.m[o:o + k].cpu(), want["exp_avg"].reshape(-1)), n
+        assert torch.equal(opt.v[o:o + k].cpu(), want["exp_avg_sq"].reshape(-1)), n
+    o, k = f.offsets["transformer.mask_token"]
+    assert float(opt.m[o:o + k].abs().max()) == 0.0 and "transformer.mask_token" in opt.inactive_parameters()
+    # a state written for another model must not load silently
+    bad = {"state": foreign["state"], "param_groups": [dict(g, params=g["params"][:-1]) for g in foreign["param_groups"]]}
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"moments": {}})
+
+
+def test_periodic_atomic_save_and_weights_only_resume(run_mod, pkg, shards, tmp_path, capsys, monkeypatch):
+    """last.ckpt is rewritten every save interval through a temporary file (never a partial file at the resume path), and a
+    checkpoint WITHOUT optimizer_states still restores step, epoch, schedule and the place in the epoch."""
+    ck = importlib.import_module("vl_merging_amd.checkpoint")
+    log_dir = str(tmp_path / "result")
+    args = PRETRAIN + ["data_root=" + shards, "log_dir=" + log_dir]
+    monkeypatch.setenv("VLM_SAVE_EVERY", "2")
+    r1 = run_mod.main(args + ["steps=3"])
+    out = capsys.readouterr().out
+    assert "(global_step 2)" in out and "(global_step 3)" in out  # the interval save and the final one
+    d = os.path.dirname(r1["last_ckpt"])
+    assert os.listdir(d) == ["last.ckpt"], os.listdir(d)  # no temporary file left behind
+    ckpt = ck.load_file(r1["last_ckpt"])
+    assert ckpt["global_step"] == 3
+    del ckpt["optimizer_states"]
+    torch.save(ckpt, r1["last_ckpt"])
+    monkeypatch.delenv("VLM_SAVE_EVERY")
+    r2 = run_mod.main(args + ["steps=2", "resume_during_pretraining=True"])
+    out = capsys.readouterr().out
+    assert "holds no optimizer_states" in out
+    assert r2["global_step"] == 5
+    c2 = ck.load_file(r2["last_ckpt"])
+    assert c2["global_step"] == 5 and c2["lr_schedulers"][0]["last_epoch"] == 5 and c2["optimizer_states"][0]["vlm_step"] == 5
+    r3 = run_mod.main(PRETRAIN + ["data_root=" + shards, "log_dir=" + str(tmp_path / "straight"), "steps=5"])
+    assert r1["seen_raw_index"] + r2["seen_raw_index"] == r3["seen_raw_index"]
+
+
+def test_sharded_run_saves_full_optimizer_state_and_resumes(pkg, shards, tmp_path):
+    """use_sharded_training (run.py:231-232) on two ranks (one device, gloo): last.ckpt carries the FULL Adam state gathered from
+    both ranks' shards, and a sharded resume continues from it -- the same parameters as four uninterrupted sharded steps."""
+    import subprocess
+    ck = importlib.import_module("vl_merging_amd.checkpoint")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(VLM_BENCH_ONE_DEVICE="1", VLM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = ["with", "task_test_vit_tiny_mlm_itm_ifm_square_randaug_base_vl", "ufo", "vocab_size=2048", "per_gpu_batchsize=2",
+            "batch_size=4", "max_steps=8", "warmup_steps=0", "learning_rate=1e-3", "vl_mlm_prob=0.3", "use_sharded_training=True",
+            "drop_rate=0.0"]
+
+    def launch(log_dir, extra, port):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "vl-merging_amd", "run.py")] + base + ["log_dir=" + log_dir] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r.stdout
+
+    a = str(tmp_path / "a")
+    launch(a, ["steps=2"], 29611)
+    path = os.path.join(a, os.listdir(a)[0], "version_0", "checkpoints", "last.ckpt")
+    ckpt = ck.load_file(path)
+    osd = ckpt["optimizer_states"][0]
+    assert osd["vlm_step"] == 2 and len(osd["state"]) > 100
+    # every active parameter's moments are there, whichever rank owned its chunk
+    zero = [osd["vlm_names"][i] for i, st in osd["state"].items() if float(st["exp_avg_sq"].abs().max()) == 0.0]
+    assert not zero, zero[:5]
+    out = launch(a, ["steps=2", "resume_during_pretraining=True"], 29612)
+    assert "resumed optimizer at global_step 2" in out
+    c2 = ck.load_file(path)
+    assert c2["global_step"] == 4 and c2["optimizer_states"][0]["vlm_step"] == 4

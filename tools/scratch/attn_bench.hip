@@ -1,5 +1,5 @@
 // Standalone timing harness for the attention kernels (diagnostic, never part of the product library).
-// Build (CPU container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DATT_DIAG_...] \
+// Build (CPU container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DVLM_DIAG: in-kernel stamps] \
 //                           -I include tools/scratch/attn_bench.hip -o tools/scratch/attn_bench[_variant]
 // Run (GPU box):          tools/scratch/attn_bench [B] [mode 0 joint / 1 separate] [bias 0/1]
 #include "../../vl-merging_amd/csrc/attention_fwd.hip"
@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
   const double nn = mode ? (double)n0 * n0 + (double)n1 * n1 : (double)(n0 + n1) * (n0 + n1);
   const double fl = 4.0 * B * H * 64 * nn * (what ? 2.5 : 1.0);
   printf("%s B=%d mode=%d bias=%d: %.1f us  %.0f TFLOP/s\n", what ? "bwd" : "fwd", B, mode, with_bias, us, fl / us / 1e6);
-  if (what == 1 && with_bias && with_dbias) {  // checksum of one pass's bias-table gradient (compare VLM_ATT_DB16=0 / 1 runs)
+  if (what == 1 && with_bias && with_dbias) {  // checksum of one pass's bias-table gradient (compare builds)
     CK(hipMemset(dbias, 0, hb.size() * 4));
     run();
     CK(hipDeviceSynchronize());
@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < g.size(); ++i) { sum += g[i]; sabs += fabs(g[i]); w += g[i] * (double)((i * 2654435761u) % 1000); }
     printf("dbias checksum: sum %.6e abs %.6e weighted %.6e  [%g %g %g %g]\n", sum, sabs, w, g[12 * R + 5], g[13 * R + 700], g[20 * R + 1500], g[23 * R + 2200]);
   }
-#ifdef ATT_DIAG_STAMPS
+#ifdef VLM_DIAG
   {
     unsigned long long st[8 * 64];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(att_stamps), sizeof(st)));

@@ -1,5 +1,5 @@
 // Standalone timing harness for the 256x256 GEMM kernel (diagnostic, never part of the product library).
-// Build (CPU container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGEMM_ONLY_BIG [-DBIG_DIAG_DMA=0 ...] -I include \
+// Build (CPU container):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGEMM_ONLY_BIG [-DVLM_DIAG: in-kernel stamps] -I include \
 //                           tools/scratch/gemm_bench.hip -o tools/scratch/gemm_bench[_variant]
 // Run (GPU box):          tools/scratch/gemm_bench M N K [epilogue variant 0..4]
 #include "../../vl-merging_amd/csrc/gemm.hip"
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
   const double tiles = (double)((M + 255) / 256) * ((N + 255) / 256), rounds = tiles / 256.0;
   printf("M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s   tiles %.0f (%.2f rounds)  -> %.0f cycles @2.4GHz per 32-deep step per tile-round\n", M, N, K, us,
          fl / us / 1e6, tiles, rounds, us * 2400.0 / (K / 32.0) / (rounds < 1 ? 1 : rounds));
-#ifdef VLM_GEMM_STAMPS
+#ifdef VLM_DIAG
   {
     const int wgs = (int)tiles;
     unsigned long long* st; CK(hipMalloc(&st, (size_t)wgs * 64)); CK(hipMemset(st, 0, (size_t)wgs * 64));

@@ -45,6 +45,11 @@ class GemmGroup(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("bias", c_void_p), ("col_sum", c_void_p), ("col_sum_ws", c_void_p)]
 
 
+class WgradGroup(ctypes.Structure):
+    _fields_ = [("row0", ctypes.c_int32), ("rows", ctypes.c_int32), ("C", c_void_p), ("accumulate", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class FoldJob(ctypes.Structure):
     _fields_ = [("partials", c_void_p), ("nblocks", ctypes.c_int32), ("D", ctypes.c_int32), ("out0", c_void_p),
                 ("out1", c_void_p)]
@@ -88,6 +93,8 @@ SIGNATURES = {
                               c_int, ctypes.POINTER(Epilogue), c_void_p]),
     "vlm_gemm_bf16_grouped": (c_int, [c_int, ctypes.POINTER(GemmGroup), c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                       ctypes.POINTER(Epilogue), c_void_p]),
+    "vlm_gemm_wgrad_grouped": (c_int, [c_int, ctypes.POINTER(WgradGroup), c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                       c_void_p, c_u64, c_void_p]),
     "vlm_attention_fwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_void_p]),
     "vlm_attention_bwd_ws_floats": (c_size_t, [ctypes.POINTER(AttnDesc), c_int]),
     "vlm_attention_bwd": (c_int, [ctypes.POINTER(AttnDesc), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,

@@ -63,7 +63,7 @@ def main(argv):
     cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
     vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
     vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
-    from bench import synthetic_batch
+    synthetic_batch = importlib.import_module("vl_merging_amd.synthetic").synthetic_batch
     batches = None  # batches=N: stop after N batches (all ranks together); default: 4 synthetic batches / every Arrow sample
     rest = []
     for a in argv:

@@ -12,10 +12,8 @@
 // bias gradient whose (slow) LDS atomics are amortised over the batch.
 #include "vlm_common.h"
 #include "attention_common.h"
+#include "vlm_diag.h"
 #include <stdlib.h>
-#ifndef ATT_STAMP  // (defined by attention_fwd.hip in diagnostic harness builds)
-#define ATT_STAMP(slot) do { } while (0)
-#endif
 
 struct attn_bwd_params_t {
   attn_params_t f;        // forward description (qkv, bias, index, ranges)
@@ -186,7 +184,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
     const bool masked = tile_masked(kp0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#ifndef ATT_DQ_NOPREFETCH
       bf16x8 kfr[4], vfr[4];
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
@@ -194,19 +191,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         vfr[ss] = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
       }
       __builtin_amdgcn_sched_barrier(0);
-#endif
       f32x16 e = neglse, dp = negdel;
       if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[kb], e);
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
-#ifdef ATT_DQ_NOPREFETCH
-        const bf16x8 ka = att_k_rowfrag(lk, kb * 32 + r, 2 * ss + hh), va = att_k_rowfrag(lv, kb * 32 + r, 2 * ss + hh);
-        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ss], e, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ss], dp, 0, 0, 0);
-#else
         e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ss], qf[ss], e, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ss], dof[ss], dp, 0, 0, 0);
-#endif
       }
       if (masked) {  // workgroup-uniform
 #pragma unroll
@@ -296,10 +286,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   unsigned char* ldsO = smem + 4 * ATT_TILE_BYTES;      // [2] dO row image
   unsigned char* ldsOt = smem + 6 * ATT_TILE_BYTES;     // [2] dO transposed-read image
   float* qstat = reinterpret_cast<float*>(smem + 8 * ATT_TILE_BYTES);  // [2][-lse 64 | -delta 64]
-#ifdef ATT_DIAG_HIST  // experiment (tools/scratch/attn_bench.hip): what an LDS float histogram of every dS costs inside this kernel
-  __shared__ float diag_hist[2624];
-  for (int i = threadIdx.x; i < 2624; i += ATT_THREADS) diag_hist[i] = 0.f;
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
@@ -413,13 +399,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
   store(0);
   __syncthreads();
 
-  int slot = 0;
-  (void)slot;
+  ATT_STAMP_DECL()
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-#ifndef ATT_DKV_NOLOAD
     load(t + 1);
-#endif
     ATT_STAMP(slot++);  // next tile's loads issued
     const unsigned char* lq = ldsQ + cur * ATT_TILE_BYTES;
     const unsigned char* lqt = ldsQt + cur * ATT_TILE_BYTES;
@@ -428,14 +411,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
     const float* st = qstat + cur * 128;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-#ifdef ATT_DKV_PREFETCH  // (explicit fragment prefetch measured 11 % slower here: 256 VGPRs and spills)
-      bf16x8 qfr[4], ofr[4];
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss) {
-        qfr[ss] = att_k_rowfrag(lq, qb * 32 + r, 2 * ss + hh);
-        ofr[ss] = att_k_rowfrag(lo, qb * 32 + r, 2 * ss + hh);
-      }
-#endif
       f32x16 e, dp;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -444,53 +419,24 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
 #pragma unroll
         for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
       }
-#ifdef ATT_DKV_PREFETCH
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       if (wave_masked) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] += kmaskv;
       }
-#ifndef ATT_DKV_NOBIAS
       if (HAS_BIAS) e = att_bias_mfma(sel0, sel1, bw.w[qb], e);
-#endif
-#ifdef ATT_DKV_NOC
-      if (false)
-#endif
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) {
-#ifndef ATT_DKV_PREFETCH
         const bf16x8 qa = att_k_rowfrag(lq, qb * 32 + r, 2 * ss + hh), oa = att_k_rowfrag(lo, qb * 32 + r, 2 * ss + hh);
         e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ss], e, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
-#else
-        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ss], kf[ss], e, 0, 0, 0);     // E[q][key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ss], vf[ss], dp, 0, 0, 0);   // dP[q][key]
-#endif
       }
       ATT_STAMP(slot++);  // score / dP chains issued
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-#ifndef ATT_DKV_NOEXP
         e[i] = att_exp2(e[i]);  // P
-#endif
         dp[i] *= e[i];          // dS (natural units)
       }
       ATT_STAMP(slot++);  // exponentials issued
-#ifdef ATT_DIAG_HIST
-      {
-        const int base = 1300 + ((t * 2 + qb) * 29) % 1200;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#if ATT_DIAG_HIST == 1  // the Toeplitz pattern: r = a(q) - c(key); the two lane halves (queries 4 apart) collide on 28 lanes
-          const int at = base + (i & 3) + 8 * (i >> 2) + 4 * hh - r;
-#else                   // 64 distinct consecutive addresses per instruction
-          const int at = base + 64 * (i & 7) + lane;
-#endif
-          atomicAdd(&diag_hist[at], dp[i]);
-        }
-      }
-#endif
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pf, df;
@@ -499,10 +445,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
           pf[j] = (bf16_t)e[8 * s2 + j];
           df[j] = (bf16_t)dp[8 * s2 + j];
         }
-#ifdef ATT_DKV_NOD
-        dv[0][s2] += (float)pf[0] + (float)df[3];
-        if (false)
-#endif
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16x8 ob = att_tr_frag(lot, qb * 32 + 16 * s2, db, lane);
@@ -513,23 +455,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       }
       ATT_STAMP(slot++);  // dV / dK products issued
     }
-#ifndef ATT_DKV_NOBIAS
     if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, t + 1);  // (past the last tile: unused)
-#endif
-#ifndef ATT_DKV_NOSTORE
     store(cur ^ 1);
-#endif
     ATT_STAMP(slot++);  // next tile stored to LDS
-#ifndef ATT_DKV_NOBAR
     __syncthreads();
-#endif
     ATT_STAMP(slot++);  // barrier passed
   }
 
-#ifdef ATT_DIAG_HIST
-  __syncthreads();
-  if (diag_hist[tid] == 12345.f) dk[0][0] += 1.f;  // keep the histogram alive
-#endif
   // ---- store dK, dV: accumulator rows = keys (registers), column = d (lane & 31) ---------------------------------------
   // (2-byte stores, 64-byte segments per half wave.  Through a wave-private LDS transpose and 16-byte row stores instead:
   // no difference, 714 vs 717 us for the backward pass at 88 samples -- what the stores cost, 16 us, is their traffic.)
@@ -540,11 +472,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
       const int kl = (i & 3) + 8 * (i >> 2) + 4 * hh;
       const int kpi = kp0w + kl;
       const int row = kpi < sp.s_hi ? att_row_of(ps, b, kpi) : -1;
-#ifdef ATT_DKV_NOEPI
-      if (row == 123456789) {
-#else
       if (row >= 0) {
-#endif
         bf16_t* dst = bp.dqkv + (size_t)row * bp.ld_dqkv + D + h * 64 + r;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -590,249 +518,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkv_kernel(const attn
 // samples recomputing E and dP (2 of the 5 MFMA products of the backward, with the same matrix-pipe formulation as
 // the dQ / dK-dV kernels: tiled fp16 bias through selection MFMAs, -lse / -delta as C operands) and only then feeds the
 // summed dS through an LDS histogram -> global atomics.
-// 8 waves: wave (kw = wave & 3, qh = wave >> 2) owns 32 keys x 64 queries; per sample the four operand tiles (K, V of
-// the 128 keys, Q, dO of the 128 queries: 64 KB) are staged global -> VGPR -> LDS by all 512 threads, the next sample's
-// loads in flight during this sample's MFMAs.  [Round 1: 32 x 128 tiles moved 40 KB per 8 MFMAs per wave and gathered
-// the bias from an LDS table per element; this tile moves 64 KB per 20.]
-#define ATT_DB_THREADS 512
-__global__ __launch_bounds__(ATT_DB_THREADS, 2) void attn_bwd_dbias_kernel(const attn_bwd_params_t bp, int n_groups) {
-  const attn_params_t& p = bp.f;
-  // two stages of {K, V of the 128 keys, Q, dO of the 128 queries (row images, 16 KB each), -lse | -delta}: sample b + 1
-  // is written while sample b is read (one barrier per sample; the workgroup owns the CU's LDS anyway: 8 waves, 242 VGPRs)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (8 * ATT_TILE_BYTES + 1024)];
-  constexpr int STAGE = 8 * ATT_TILE_BYTES + 1024;
-  float* hist = reinterpret_cast<float*>(smem);        // aliases the tiles: only used after the sample loop
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kw = wave & 3, qh = wave >> 2;
-  const int r = lane & 31, hh = lane >> 5;
-  const att_pos_t ps = att_pos(p.seq);
-  const int D = p.H * 64;
-  // ---- work item: (key tile, query tile of its span, head, sample group) ------------------------------------------------
-  // XCD-aware order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; id -> (xcd, slot) is remapped so
-  // that one XCD walks a contiguous run of the logical order with the (key tile, query tile) PAIR fastest, then the sample
-  // group, then the head.  The ~25 pairs of one (head, group) are then resident on ONE XCD together and walk the same
-  // samples at about the same time, so a sample's K / V / Q / dO rows (316 KB per head) enter that L2 once instead of
-  // once per pair: round 2's order (group fastest, pairs 36 ids apart on eight different XCDs) shared nothing and ran at
-  // the fabric rate (PMC: 808 MB fetched per launch for 198 MB of distinct operands).
-  const int nkt = att_num_tiles(ps.n0, ps.n1, ps.pos1, p.mode);
-  int pairs = 0;
-  for (int k = 0; k < nkt; ++k) {
-    const att_span_t s_ = att_span(ps, p.mode, k);
-    pairs += (s_.s_hi - s_.s_lo + ATT_BQ - 1) / ATT_BQ;
-  }
-  const int total = pairs * p.H * n_groups, per = (total + 7) >> 3;
-  const int logical = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || logical >= total) return;
-  int item = logical % pairs;
-  const int pair_id = item;
-  const int grp = (logical / pairs) % n_groups;
-  const int h = logical / (pairs * n_groups);
-  const int part_slot = (pair_id * p.H + h) * n_groups + grp;  // where attn_dbias_fold_kernel expects this item's histogram
-  // item now enumerates (key tile, query tile) pairs: key tile kt has nq(kt) query tiles
-  int kt = 0;
-  att_span_t sp = att_span(ps, p.mode, 0);
-  for (;; ++kt) {
-    sp = att_span(ps, p.mode, kt);
-    const int nq = (sp.s_hi - sp.s_lo + ATT_BQ - 1) / ATT_BQ;
-    if (item < nq) break;
-    item -= nq;
-    if (kt + 1 >= nkt) return;
-  }
-  const int qp0 = sp.s_lo + item * ATT_BQ;       // first query position of the tile
-  const int b_lo = (int)((long)ps.B * grp / n_groups), b_hi = (int)((long)ps.B * (grp + 1) / n_groups);
-  if (b_lo >= b_hi) return;
-
-  const int kp = sp.p0 + kw * 32 + r;            // this lane's key position
-  const bool kvalid = kp < sp.s_hi && (kp < ps.n0 || kp >= ps.pos1);
-  const uint8_t* keepk = kp < ps.n0 ? p.keep0 : p.keep1;
-  const int keep_at = kp < ps.n0 ? kp : kp - ps.pos1, keep_n = kp < ps.n0 ? ps.n0 : ps.n1;
-  const bool wave_keep = __any(kvalid && keepk != nullptr);
-
-  f16x8 sel0, sel1;
-  att_select_frags(lane, sel0, sel1);
-  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
-  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<_Float16*>(p.dense_t + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048), 0, (uint32_t)p.dense_tiles * 4096u, 0x00020000);
-  att_bias_t bw;   // both 32-query blocks of this wave's 64 queries: the same for every sample
-  att_bias_load(bw, rbias, att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + kw, lane), (qp0 - sp.s_lo) / ATT_BK + qh);
-
-  // ---- staging: thread -> (row tid >> 3 [+64], chunk tid & 7) of each of the four 128-row tiles -------------------------
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.qkv), 0, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(bp.d_o), 0, (uint32_t)((size_t)p.total_rows * bp.ld_do * 2), 0x00020000);
-  const int srow = tid >> 3, schunk = tid & 7;
-  u32x4 gK[2], gV[2], gQ[2], gO[2];
-  float gstat = 0.f;
-  auto row_off = [&](int b, int pos, int lim, uint32_t ld) -> uint32_t {  // byte offset of the row of position pos, or out of bounds
-    const bool txt = pos < ps.n0, img = pos >= ps.pos1 && pos < ps.NP;
-    const bool ok = (txt || img) && pos < lim;
-    const int row = txt ? ps.base0 + b * ps.n0 + pos : ps.base1 + b * ps.n1 + (pos - ps.pos1);
-    return ok ? (uint32_t)row * ld * 2 : 0xFFFFF000u;
-  };
-  auto g_load = [&](int b) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const uint32_t ko = row_off(b, sp.p0 + srow + 64 * u, sp.s_hi, p.ld_qkv);
-      gK[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, ko + (D + h * 64 + schunk * 8) * 2, 0, 0));
-      gV[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, ko + (2 * D + h * 64 + schunk * 8) * 2, 0, 0));
-      const uint32_t qo = row_off(b, qp0 + srow + 64 * u, sp.s_hi, p.ld_qkv);
-      gQ[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, qo + (h * 64 + schunk * 8) * 2, 0, 0));
-      const uint32_t oo = row_off(b, qp0 + srow + 64 * u, sp.s_hi, bp.ld_do);
-      gO[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, oo + (h * 64 + schunk * 8) * 2, 0, 0));
-    }
-    if (tid < 256) {  // threads 0..127: -lse, 128..255: -delta of the tile's 128 query positions
-      const int qq = qp0 + (tid & 127);
-      const int row = qq < sp.s_hi ? att_row_of(ps, b, qq) : -1;
-      const float* src = tid < 128 ? bp.lse : bp.delta;
-      gstat = row >= 0 ? -src[(size_t)h * p.total_rows + row] : (tid < 128 ? -INFINITY : 0.f);
-    }
-  };
-  auto l_store = [&](int stage) {
-    unsigned char* base = smem + stage * STAGE;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = srow + 64 * u;
-      const uint32_t at = row * 128 + ((schunk ^ (row & 7)) << 4);
-      *reinterpret_cast<u32x4*>(base + at) = gK[u];
-      *reinterpret_cast<u32x4*>(base + 2 * ATT_TILE_BYTES + at) = gV[u];
-      *reinterpret_cast<u32x4*>(base + 4 * ATT_TILE_BYTES + at) = gQ[u];
-      *reinterpret_cast<u32x4*>(base + 6 * ATT_TILE_BYTES + at) = gO[u];
-    }
-    if (tid < 256) reinterpret_cast<float*>(base + 8 * ATT_TILE_BYTES)[tid] = gstat;
-  };
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
-  const float c1 = p.scale * ATT_LOG2E;
-  g_load(b_lo);
-  l_store(0);
-  if (b_lo + 1 < b_hi) g_load(b_lo + 1);
-  __syncthreads();
-  for (int b = b_lo; b < b_hi; ++b) {
-    const int cur = (b - b_lo) & 1;
-    if (b + 1 < b_hi) {
-#ifndef ATT_DB_NOSTORE
-      l_store(cur ^ 1);                   // loaded during the previous sample; that stage was last read two samples ago
-#endif
-#ifndef ATT_DB_NOLOAD
-      if (b + 2 < b_hi) g_load(b + 2);    // flies during this sample's MFMAs
-#endif
-    }
-    const unsigned char* ldsK = smem + cur * STAGE;
-    const unsigned char* ldsV = ldsK + 2 * ATT_TILE_BYTES;
-    const unsigned char* ldsQ = ldsK + 4 * ATT_TILE_BYTES;
-    const unsigned char* ldsO = ldsK + 6 * ATT_TILE_BYTES;
-    const float* qstat = reinterpret_cast<const float*>(ldsK + 8 * ATT_TILE_BYTES);
-    float kmaskv = kvalid ? 0.f : -INFINITY;
-    if (wave_keep && kvalid && keepk && keepk[(size_t)b * keep_n + keep_at] == 0) kmaskv = -INFINITY;
-    const bool wave_masked = __any(kmaskv != 0.f);
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ss = 0; ss < 4; ++ss) {
-      const bf16x8 raw = att_k_rowfrag(ldsK, kw * 32 + r, 2 * ss + hh);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) kf[ss][j] = (bf16_t)((float)raw[j] * c1);
-      vf[ss] = att_k_rowfrag(ldsV, kw * 32 + r, 2 * ss + hh);
-    }
-#ifdef ATT_DB_NOMATH
-    acc[0][0] += (float)kf[0][0] + (float)vf[1][1];
-    if (false)
-#endif
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int q0 = qh * 64 + qb * 32;  // first query row of the block inside the 128-row tile
-      f32x16 e, dp;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(qstat + q0 + 8 * g4 + 4 * hh);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(qstat + 128 + q0 + 8 * g4 + 4 * hh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
-      }
-      if (wave_masked) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] += kmaskv;
-      }
-      e = att_bias_mfma(sel0, sel1, bw.w[qb], e);
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss) {
-        const bf16x8 qa = att_k_rowfrag(ldsQ, q0 + r, 2 * ss + hh), oa = att_k_rowfrag(ldsO, q0 + r, 2 * ss + hh);
-        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ss], e, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[qb][i] += att_exp2(e[i]) * dp[i];
-    }
-    __syncthreads();  // stage cur is free for sample b + 2, stage cur ^ 1 is published
-  }
-
-  // ---- histogram of the batch-summed dS (in the LDS that held the tiles) ---------------------------------------------------
-  __syncthreads();
-  for (int i = tid; i < p.R; i += ATT_DB_THREADS) hist[i] = 0.f;
-  __syncthreads();
-  {
-    // byte offsets (4 x relative-position index) of this lane's 32 (query, key) pairs: element (qb, j) <-> query row
-    // q0 + (j & 3) + 8 * (j >> 2) + 4 * hh, this lane's key; read through the transposed index (row = key position)
-    const bool kin = kp < p.idx_t_rows;
-    const int16_t* irow = p.idx_t + (size_t)(kin ? kp : 0) * p.ld_idx_t;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qpos0 = qp0 + qh * 64 + qb * 32;
-      uint32_t ids[16];
-      bool same = true;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int qq = qpos0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        ids[j] = (kin && qq < p.ld_idx_t) ? (uint32_t)(unsigned short)irow[qq] : 0u;
-        same = same && ids[j] == ids[0];
-      }
-      const uint32_t first = __builtin_amdgcn_readfirstlane(ids[0]);
-      same = same && ids[0] == first;
-      if (__all(same)) {  // text -> image pairs share ONE table row (vilt_module.py:180-181): reduce in registers
-        float tsum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tsum += acc[qb][j];
-        tsum = wave_sum(tsum);
-        if (lane == 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + first), tsum);
-      } else {
-#ifndef ATT_DIAG_NOHIST
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(hist) + ids[j]), acc[qb][j]);
-#else
-        hist[tid] = acc[qb][0] + (float)ids[3];
-#endif
-      }
-    }
-  }
-  __syncthreads();
-  if (bp.dbias_part) {
-    // two-stage reduction: ~80 workgroups per head adding into the same 2 294 addresses serialise at the memory-side
-    // atomic units (measured: 25 us of fixed cost per workgroup); plain stores + one small summing launch instead
-    float* g = bp.dbias_part + (size_t)part_slot * p.R;
-    for (int i = tid; i < p.R; i += ATT_DB_THREADS) g[i] = hist[i];
-  } else {
-    float* g = bp.dbias_t + (size_t)(p.head_row0 + h) * p.R;
-    for (int i = tid; i < p.R; i += ATT_DB_THREADS) {
-      const float v = hist[i];
-      if (v != 0.f) atomicAdd(g + i, v);
-    }
-  }
-}
-
-// ---- the same work item with SIXTEEN waves (four per SIMD) ---------------------------------------------------------------
-// The 8-wave kernel above spends 3.2 us per sample where its MFMAs need 0.6 and its LDS traffic 1.0: two waves per SIMD with
-// 240 registers each cannot cover the LDS -> MFMA -> exp chain of a sample, and the global -> VGPR -> LDS staging adds a
-// vmcnt(0) wait and eight ds_write_b128 per thread to it.  Here wave (kw = wave & 3, qw = wave >> 2) owns 32 keys x 32
-// queries (16 accumulator registers), the four operand tiles of the next sample arrive by LDS-DMA (no staging registers: four
-// 1-KiB pieces per wave and sample, the row-image swizzle on the source side) and nothing is converted on the vector pipe:
-// K stays unscaled, the C operand of the score product is -lse / c1 (the dQ kernel writes it), the bias enters through
-// selection MFMAs whose "one" is 1 / c1 split into an fp16 head and tail (products of fp16 values are exact in the fp32
-// accumulator), and P = exp2(c1 * e).  <= 128 VGPRs.
+// SIXTEEN waves (four per SIMD, <= 128 VGPRs): wave (kw = wave & 3, qw = wave >> 2) owns 32 keys x 32 queries (16 accumulator
+// registers), the four operand tiles of the next sample arrive by LDS-DMA (no staging registers: four 1-KiB pieces per wave and
+// sample, the row-image swizzle on the source side) and nothing is converted on the vector pipe: K stays unscaled, the C operand
+// of the score product is -lse / c1 (the dQ kernel writes it), the bias enters through selection MFMAs whose "one" is 1 / c1 split
+// into an fp16 head and tail (products of fp16 values are exact in the fp32 accumulator), and P = exp2(c1 * e).  The histogram is
+// 64-bit FIXED POINT (ds_add_u64: integer LDS atomics run at the LDS array's rate, float ones at ~130 cycles per wave
+// instruction).  [Round 2's 8-wave kernel -- two waves per SIMD at 240 registers, global -> VGPR -> LDS staging, a float
+// histogram: 3.2 us per sample where its MFMAs need 0.6 -- is in the git history; DESIGN.md 4.3.]
 #define ATT_DB16_THREADS 1024
 __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(const attn_bwd_params_t bp, int n_groups) {
   const attn_params_t& p = bp.f;
@@ -845,7 +538,7 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   const int r = lane & 31, hh = lane >> 5;
   const att_pos_t ps = att_pos(p.seq);
   const int D = p.H * 64;
-  // ---- work item (same order and slots as attn_bwd_dbias_kernel) ------------------------------------------------------------
+  // ---- work item: (key tile, query tile) pair x head x sample group, XCD-aware order --------------------------------------------
   const int nkt = att_num_tiles(ps.n0, ps.n1, ps.pos1, p.mode);
   int pairs = 0;
   for (int k = 0; k < nkt; ++k) {
@@ -944,9 +637,7 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   asm volatile("s_waitcnt vmcnt(0)\n s_barrier" ::: "memory");
   for (int b = b_lo; b < b_hi; ++b) {
     const int cur = (b - b_lo) & 1;
-#ifndef ATT_DB16_NODMA
     if (b + 1 < b_hi) dma(b + 1, cur ^ 1);  // that stage was last read in the previous trip (barrier below)
-#endif
     const unsigned char* ldsK = smem + cur * STAGE;
     const unsigned char* ldsV = ldsK + 2 * ATT_TILE_BYTES;
     const unsigned char* ldsQ = ldsK + 4 * ATT_TILE_BYTES;
@@ -957,12 +648,7 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
     const bool wave_masked = __any(kmaskv != 0.f);
     const int q0 = qw * 32;
     f32x16 e, dp;
-#ifdef ATT_DB16_NOMATH
-    acc[0] += qstat[q0 + lane] + kmaskv;
-    if (false) {
-#else
     {
-#endif
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(qstat + q0 + 8 * g4 + 4 * hh);
@@ -995,10 +681,6 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   // 64-bit FIXED-POINT bins: ds_add_f32 costs ~110-150 cycles per wave instruction on this chip whatever the address pattern
   // (47 of this kernel's 346 us at 88 samples), ds_add_u64 runs at the LDS array's rate -- and integer sums do not depend on
   // the order the waves arrive in.  The step is 2^-48 of the item's largest |sum of dS| (a bin receives at most 2^14 addends).
-#ifdef ATT_DB16_NOTAIL
-  if (acc[0] == 12345.f) reinterpret_cast<float*>(smem)[tid] = acc[1] + acc[7];
-  return;
-#endif
   unsigned long long* hist64 = reinterpret_cast<unsigned long long*>(smem);
   unsigned* smax = reinterpret_cast<unsigned*>(hist64 + p.R);
   for (int i = tid; i < p.R; i += ATT_DB16_THREADS) hist64[i] = 0ull;
@@ -1039,13 +721,9 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
       tsum = wave_sum(tsum);
       if (lane == 0) atomicAdd(hist64 + (first >> 2), (unsigned long long)(long long)(tsum * FIX));
     } else {
-#ifndef ATT_DB16_NOHIST
 #pragma unroll
       for (int j = 0; j < 16; ++j)  // ids are byte offsets of 4-byte entries: 2 * ids addresses the 8-byte bin
         atomicAdd(reinterpret_cast<unsigned long long*>(smem + 2 * ids[j]), (unsigned long long)(long long)(acc[j] * FIX));
-#else
-      reinterpret_cast<float*>(smem)[tid] = acc[0] + acc[5] + (float)ids[3] + (float)ids[9];
-#endif
     }
   }
   __syncthreads();
@@ -1072,15 +750,6 @@ __global__ __launch_bounds__(256) void attn_dbias_fold_kernel(const float* __res
   dbias_t[(size_t)(head_row0 + h) * R + i] += sum;
 }
 
-// VLM_ATT_DB16=0 selects the 8-wave bias-gradient kernel (A/B runs); parsed once
-static bool att_db16_enabled() {
-  static const bool on = []() {
-    const char* e = getenv("VLM_ATT_DB16");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
 // work items of the bias-gradient kernel for this geometry: (key tile, query tile) pairs and sample groups
 static void att_dbias_items(const attn_params_t& p, int& pairs, int& groups) {
   const int NP = p.seq.pos1 + p.seq.n1;
@@ -1093,14 +762,11 @@ static void att_dbias_items(const attn_params_t& p, int& pairs, int& groups) {
   }
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;
-  if (!att_db16_enabled() || pairs <= 0) {
-    groups = pairs > 0 ? (3 * cus + pairs * p.H - 1) / (pairs * p.H) : 1;  // ~3 items per CU
-    if (groups > p.seq.B) groups = p.seq.B;
-    if (groups > 8) groups = 8;
-    if (groups < 1) groups = 1;
+  if (pairs <= 0) {
+    groups = 1;
     return;
   }
-  // 16-wave kernel: an item costs its samples (2.2 us each) plus the histogram tail (10 us); the CUs finish within half an
+  // an item costs its samples (2.2 us each) plus the histogram tail (10 us); the CUs finish within half an
   // item of each other.  (Harness sweep, 300 (pair, head) items per group: 88 samples 330 / 294 / 282 / 297 / 298 us for 1..5
   // groups, 66: 253 / 226 / 218 / 229 / 243, 22: 108 / 104 / 113 / 127 / 131 -- the model picks 3, 3, 2.)
   static const int forced = []() {  // VLM_ATT_DB_GROUPS=n overrides the model (experiments); parsed once
@@ -1166,11 +832,13 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   if (p.bias_t && (!p.dense || !p.dense_t)) return VLM_ERR_ARG;  // biased attention runs on the dense tables (vlm_bias_dense)
   if (p.dense && p.dense_tiles != att_dense_layout(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode).tiles) return VLM_ERR_ARG;
   if (ws_floats < (size_t)p.H * p.total_rows) return VLM_ERR_WORKSPACE;  // delta[h][row]
-  if (p.bias_t && dbias_t && ((size_t)p.R * 4 > 16 * ATT_TILE_BYTES || !p.idx_t)) return VLM_ERR_UNSUPPORTED;  // the histogram lives in the tile LDS
-  // the 16-wave bias-gradient kernel takes its C operands from the dQ launch: workspace = delta | nstat | histograms
+  // the bias-gradient kernel's 64-bit histogram (R bins + the item's maximum) lives in its two operand stages' LDS
+  if (p.bias_t && dbias_t && ((size_t)p.R * 8 + 8 > 2 * (size_t)(8 * ATT_TILE_BYTES + 1024) || !p.idx_t)) return VLM_ERR_UNSUPPORTED;
+  // ... and takes its C operands from the dQ launch: workspace = delta | nstat (-lse / c1, -delta) | per-item histograms
   const size_t hr = (size_t)p.H * p.total_rows;
-  const bool db16 = p.bias_t && dbias_t && ws_floats >= 3 * hr && att_db16_enabled();
-  bp.nstat = db16 ? delta_ws + hr : nullptr;
+  const bool want_dbias = p.bias_t && dbias_t;
+  if (want_dbias && ws_floats < 3 * hr) return VLM_ERR_WORKSPACE;  // vlm_attention_bwd_ws_floats says so
+  bp.nstat = want_dbias ? delta_ws + hr : nullptr;
   bp.o = reinterpret_cast<const bf16_t*>(out);
   bp.ld_o = ld_out;
   bp.inv_c1 = 1.0f / (p.scale * ATT_LOG2E);
@@ -1189,8 +857,7 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
       att_dbias_items(p, pairs, groups);
       const size_t items = (size_t)pairs * p.H * groups, need = 3 * hr + items * p.R;
       bp.dbias_part = ws_floats >= need ? delta_ws + 3 * hr : nullptr;
-      if (db16) hipLaunchKernelGGL(attn_bwd_dbias16_kernel, dim3((unsigned)((items + 7) / 8 * 8)), dim3(ATT_DB16_THREADS), 0, s, bp, groups);
-      else hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3((unsigned)((items + 7) / 8 * 8)), dim3(ATT_DB_THREADS), 0, s, bp, groups);
+      hipLaunchKernelGGL(attn_bwd_dbias16_kernel, dim3((unsigned)((items + 7) / 8 * 8)), dim3(ATT_DB16_THREADS), 0, s, bp, groups);
       if (bp.dbias_part) {
         VLM_CHECK_LAUNCH();
         hipLaunchKernelGGL(attn_dbias_fold_kernel, dim3((p.R + 255) / 256, p.H), dim3(256), 0, s, bp.dbias_part, p.R, p.H, groups,

@@ -20,36 +20,13 @@
 // The additive key mask is applied only on tiles that hold text positions (padding tokens).
 #include "vlm_common.h"
 #include "attention_common.h"
+#include "vlm_diag.h"
 #include <type_traits>
 
-#ifndef ATT_FWD_WAVES
-#define ATT_FWD_WAVES 3
-#endif
-#ifndef ATT_FWD_STAGES
-#define ATT_FWD_STAGES 2
-#endif
-// Row sums: 1 = on the matrix pipe (one MFMA per 16 keys against an all-ones operand: the sum of the bf16-ROUNDED weights
-// that also enter P V, so every output row is an exact convex combination), 0 = fp32 adds on the vector pipe.  Same
-// speed (three waves per SIMD either way); 1 keeps the numerics the parity tolerances were measured with.
-#ifndef ATT_FWD_MFMA_ROWSUM_OFF
-#define ATT_FWD_MFMA_ROWSUM 1
-#endif
-#ifdef ATT_DIAG_STAMPS  // diagnostic builds only (tools/scratch/attn_bench.hip): s_memtime inside the tile loop
-__device__ unsigned long long att_stamps[8 * 64];
-#ifndef ATT_STAMP_BLOCK
-#define ATT_STAMP_BLOCK (8 * 100)
-#endif
-// slots 0..59: s_memtime (shader clock); slots 60 / 61: s_memrealtime (100 MHz) taken together with slots 20 / 50 -> the clock
-#define ATT_STAMP(slot) do { const int s_ = (slot); if (blockIdx.x == ATT_STAMP_BLOCK && lane == 0 && s_ < 60) { att_stamps[wave * 64 + s_] = __builtin_amdgcn_s_memtime(); if (s_ == 20) att_stamps[wave * 64 + 60] = __builtin_amdgcn_s_memrealtime(); if (s_ == 50) att_stamps[wave * 64 + 61] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define ATT_STAMP(slot) do { } while (0)
-#endif
+// Row sums ride on the matrix pipe (one MFMA per 16 keys against an all-ones operand: the sum of the bf16-ROUNDED weights that
+// also enter P V, so every output row is an exact convex combination); fp32 adds on the vector pipe measured the same speed.
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(const attn_params_t p) {
-#ifdef ATT_DIAG_LDSPAD
-  __shared__ unsigned char diag_pad[ATT_DIAG_LDSPAD];
-  if (p.H < 0) diag_pad[threadIdx.x] = 1;
-#endif
+__global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const attn_params_t p) {
   // Two stages as SEPARATE LDS objects: hipcc orders every ds_read behind all pending LDS-DMA writes it cannot prove
   // disjoint (s_waitcnt vmcnt(0) in front of the read) -- with one array and a computed stage offset that serialised
   // the prefetch of tile t+1 with the reads of tile t.  Distinct objects + compile-time stage selection keep the DMA
@@ -57,10 +34,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   __shared__ __attribute__((aligned(16))) unsigned char ldsK0[ATT_TILE_BYTES], ldsK1[ATT_TILE_BYTES];  // [64 keys][128 B] row image
   __shared__ __attribute__((aligned(16))) unsigned char ldsV0[ATT_TILE_BYTES], ldsV1[ATT_TILE_BYTES];  // transposed-read image
   __shared__ float kmask0[64], kmask1[64];
-#if ATT_FWD_STAGES == 3  // K / V two tiles ahead (49 KB per workgroup: three workgroups still fit a CU)
-  __shared__ __attribute__((aligned(16))) unsigned char ldsK2[ATT_TILE_BYTES], ldsV2[ATT_TILE_BYTES];
-  __shared__ float kmask2[64];
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform BY CONSTRUCTION: tell the compiler (else waterfall loops)
@@ -116,14 +89,12 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
-#ifdef ATT_FWD_MFMA_ROWSUM
   f32x16 lacc;
   bf16x8 ones;
 #pragma unroll
   for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
-#endif
 
   // a tile needs the additive mask iff it can hold a padding token (keep masks) or -- without a bias table, whose
   // ATT_NEG_BIG entries mask every invalid position -- a gap, foreign or past-the-end position
@@ -144,10 +115,6 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
     }
   };
   // every wave drains its own LDS-DMA pieces (and bias rows) before the barrier that publishes the tile
-#ifdef ATT_DIAG_NOSYNC
-#define ATT_PUBLISH() do { } while (0)
-#define ATT_PUBLISH_KEEP4() do { } while (0)
-#else
 #define ATT_PUBLISH()                                  \
   do {                                                 \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   \
@@ -161,36 +128,19 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
   do {                                                                             \
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
   } while (0)
-#endif
 
   att_bias_t bw;  // ONE set: the next tile's rows are requested as soon as this tile's selection MFMAs have been issued
   if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, 0);  // issued BEFORE the DMA: vmcnt retires in order
   stage(0, ldsK0, ldsV0, kmask0);
-#if ATT_FWD_STAGES == 3
-  // publish with `keep` younger vector-memory operations still in flight (0, 4 or 8: the next tile's bias rows and / or the
-  // LDS-DMA pieces of the tile after next); one asm statement each (see ATT_PUBLISH_KEEP4)
-  auto publish_keep = [&](int keep) {
-    if (keep >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (keep >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  if (ntiles > 1) stage(1, ldsK1, ldsV1, kmask1);
-  publish_keep(ntiles > 1 ? 4 : 0);
-#else
   ATT_PUBLISH();
-#endif
 
   // one streamed tile; `bw` = this tile's bias rows (complete since the last publish), `bn` receives the next tile's
-  [[maybe_unused]] int slot = 0;
+  ATT_STAMP_DECL()
   auto tile = [&](int t, const unsigned char* lk, const unsigned char* lv, const float* km, unsigned char* nk,
                   unsigned char* nv, float* nm_) {
     const int kp0 = sp.s_lo + t * ATT_BK;
     ATT_STAMP(slot++);
-    if (t + (ATT_FWD_STAGES - 1) < ntiles) {  // nk / nv / nm_: the stage of tile t + 1 (two stages) or t + 2 (three)
-#ifndef ATT_DIAG_NODMA
-      stage(t + (ATT_FWD_STAGES - 1), nk, nv, nm_);
-#endif
-    }
+    if (t + 1 < ntiles) stage(t + 1, nk, nv, nm_);  // nk / nv / nm_: the other stage
 
     // ---- E^T = -m + Bias^T*log2e + K (c1 Q)^T : two 32-key chains of exponents ------------------------------------
     ATT_STAMP(slot++);  // after issuing the next tile's loads
@@ -210,10 +160,8 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
 #pragma unroll
       for (int ss = 0; ss < 4; ++ss) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ss], qf[ss], s, 0, 0, 0);
       ATT_STAMP(slot++);  // score chain issued
-#ifndef ATT_DIAG_NOBIASLOAD
       // the next tile's rows of this block: same registers, consumed by the selection MFMAs above
       if (HAS_BIAS && t + 1 < ntiles) att_bias_load_half(bw, kb, rbias, bvoff, t + 1);
-#endif
       if (tile_masked(kp0)) {  // workgroup-uniform
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -222,15 +170,11 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
           for (int e = 0; e < 4; ++e) s[4 * g4 + e] += mk[e];
         }
       }
-#ifdef ATT_DIAG_NOSOFTMAX
-      float mx = s[0];
-#else
       float mx = att_max3(s[0], s[1], s[2]);
 #pragma unroll
       for (int i = 3; i < 15; i += 2) mx = att_max3(mx, s[i], s[i + 1]);   // 3..14
       mx = att_max2(mx, s[15]);
       mx = att_max2(mx, att_other_half(mx));
-#endif
       ATT_STAMP(slot++);  // maximum known
       if (__any(mx > 6.0f)) {  // some row's exponents exceed 2^6: move those rows' reference points (rare after tile 0)
         const float m_new = mx > 0.f ? (float)(_Float16)(m + mx) : m;
@@ -238,10 +182,8 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
         const float alpha = att_exp2(-delta);
         m = m_new;
         lsum *= alpha;
-#ifdef ATT_FWD_MFMA_ROWSUM
 #pragma unroll
         for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
-#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           s[i] -= delta;
@@ -252,34 +194,16 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
         const bf16_t ml = (bf16_t)(-m_new - (float)mh);  // exact: an fp16 value minus its 8-bit head
         if (hh == 0) { qm[0] = mh; qm[1] = ml; }
       }
-#ifndef ATT_DIAG_NOSOFTMAX
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[i] = att_exp2(s[i]);
-#endif
       ATT_STAMP(slot++);  // exponentials issued
       // row sums on the vector pipe: four independent partial sums
-#ifndef ATT_FWD_MFMA_ROWSUM
-      {
-        float p0 = att_add(s[0], s[1]), p1 = att_add(s[2], s[3]), p2 = att_add(s[4], s[5]), p3 = att_add(s[6], s[7]);
-        p0 = att_add(p0, att_add(s[8], s[9]));
-        p1 = att_add(p1, att_add(s[10], s[11]));
-        p2 = att_add(p2, att_add(s[12], s[13]));
-        p3 = att_add(p3, att_add(s[14], s[15]));
-        lsum = att_add(lsum, att_add(att_add(p0, p1), att_add(p2, p3)));
-      }
-#endif
-#ifdef ATT_DIAG_NOPV
-      o[0][0] += s[0];
-      if (false)
-#endif
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[8 * s2 + j];
-#ifdef ATT_FWD_MFMA_ROWSUM
         lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
-#endif
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const bf16x8 vf = att_tr_frag(lv, kb * 32 + 16 * s2, db, lane);
@@ -288,34 +212,16 @@ __global__ __launch_bounds__(ATT_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(co
       }
       ATT_STAMP(slot++);  // P V issued
     }
-#if defined(ATT_DIAG_NOBIASLOAD) || defined(ATT_DIAG_NODMA)
-    ATT_PUBLISH();
-#elif ATT_FWD_STAGES == 3
-    publish_keep((HAS_BIAS && t + 1 < ntiles ? 4 : 0) + (t + 2 < ntiles ? 4 : 0));  // tile t + 1 is complete, younger ops fly on
-#else
     if (HAS_BIAS && t + 1 < ntiles) ATT_PUBLISH_KEEP4();
     else ATT_PUBLISH();
-#endif
   };
-#if ATT_FWD_STAGES == 3
-  for (int t = 0; t < ntiles; t += 3) {  // three tiles per trip: the LDS stages are distinct objects, selected at compile time
-    tile(t, ldsK0, ldsV0, kmask0, ldsK2, ldsV2, kmask2);
-    if (t + 1 < ntiles) tile(t + 1, ldsK1, ldsV1, kmask1, ldsK0, ldsV0, kmask0);
-    if (t + 2 < ntiles) tile(t + 2, ldsK2, ldsV2, kmask2, ldsK1, ldsV1, kmask1);
-  }
-#else
   for (int t = 0; t < ntiles; t += 2) {  // two tiles per trip: the LDS stages are distinct objects, selected at compile time
     tile(t, ldsK0, ldsV0, kmask0, ldsK1, ldsV1, kmask1);
     if (t + 1 < ntiles) tile(t + 1, ldsK1, ldsV1, kmask1, ldsK0, ldsV0, kmask0);
   }
-#endif
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
-#ifdef ATT_FWD_MFMA_ROWSUM
   const float lt = lacc[0];
-#else
-  const float lt = lsum + __shfl_xor(lsum, 32, 64);  // the two lane halves hold complementary keys of the same query
-#endif
   const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   if (qvalid) {
     bf16_t* op = p.out + qrow * p.ld_out + h * 64 + 4 * hh;

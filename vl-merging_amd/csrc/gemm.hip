@@ -18,12 +18,10 @@
 // The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that each lane ends
 // up with 4 CONSECUTIVE output columns of one row: the epilogue then moves 16-B (fp32) / 8-B (bf16) vectors.
 #include "vlm_common.h"
+#include "vlm_diag.h"
 #include <atomic>
 #include <stdlib.h>
 
-#ifndef GEMM_FRAG_MODE
-#define GEMM_FRAG_MODE 1
-#endif
 #define GEMM_BM 128
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -166,6 +164,12 @@ struct gemm_group_t {
   int ldb, row0, row_end, tile0;
 };
 
+// wgrad form (vlm_gemm_wgrad_grouped): a group is a range of TOKEN rows (the reduction) with its own K slices and its own
+// block of the slice workspace; item0 = first (slice, tile) item of the group in the launch's grid.
+struct gemmT_group_t {
+  int row0, row_end, item0, kps, slice0;
+};
+
 struct gemm_params_t {
   const void* A;
   const void* B;
@@ -178,9 +182,8 @@ struct gemm_params_t {
   int splits, ksteps_per_split;  // split-K (wgrad): block -> (tile, K slice), fp32 atomic accumulation
   int n_groups;                  // 256x256 kernel, GROUPED instantiations only
   gemm_group_t grp[VLM_GEMM_MAX_GROUPS];
-#ifdef VLM_GEMM_STAMPS
-  unsigned long long* stamps;  // diagnostic build only (tools/stamp_gemm.py): 8 u64 per workgroup
-#endif
+  gemmT_group_t grpT[VLM_GEMM_MAX_GROUPS];  // wgrad kernel, GROUPED instantiation only
+  VLM_DIAG_GEMM_FIELD  // empty in the product build (vlm_diag.h)
 };
 
 // v_permlane16_swap_b32: x' = [x.row0, y.row0, x.row2, y.row2], y' = [x.row1, y.row1, x.row3, y.row3] (rows = 16 lanes;
@@ -324,13 +327,7 @@ __device__ __forceinline__ int gemm_epilogue(const gemm_params_t& p, const f32x4
             bf16x8 o;
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-#if defined(EPI_DIAG) && EPI_DIAG == 1  // diagnostic timing build: no stores
-            asm volatile("" ::"v"(o));
-#elif defined(EPI_DIAG) && EPI_DIAG == 2  // diagnostic timing build (wrong results): row-contiguous 128-B segments
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)(mw0 + (hf * 2 + jp) * 8 + (lane >> 3)) * p.ldc + nw0 + (lane & 7) * 8) = o;
-#else
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
-#endif
           }
         }
       }
@@ -481,16 +478,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves, 64x64 each
-#ifdef VLM_GEMM_STAMPS
-#define STAMP(k)                                                                       \
-  if (p.stamps && tid == 0) {                                                          \
-    p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();             \
-    if ((k) == 0 || (k) == 3) p.stamps[(size_t)blockIdx.x * 8 + 4 + (k) / 3] = __builtin_amdgcn_s_memrealtime(); \
-  }
-#else
-#define STAMP(k)
-#endif
-  STAMP(0)
+  GEMM_STAMP(0)
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous
   // run of tiles with n fastest so a 128-row A panel is reused out of that XCD's L2 (bijective for any grid).
@@ -546,15 +534,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     else { stage_load<TB>(sb, rb, n0, kt0 * GEMM_BK, p.ldb, tid); stage_store<TB>(sb, LDS_B(0), tid); }
   }
   __syncthreads();  // hipcc drains a pending LDS-DMA (vmcnt(0)) in front of the barrier
-  STAMP(1)
+  GEMM_STAMP(1)
 
   for (int kt = kt0; kt < kt1; ++kt) {
     const int cur = (kt - kt0) & 1;
-#ifdef VLM_GEMM_EXP_NOLOAD  // diagnostic timing build only: the K loop re-reads the first stage (results are wrong)
-    if (false) {
-#else
     if (kt + 1 < kt1) {  // next tile's loads fly during this tile's MFMAs
-#endif
       if (DMA_A) stage_dma<TA>(ra, LDS_A(cur ^ 1), m0, (kt + 1) * GEMM_BK, p.lda, wave_u, lane);
       else stage_load<TA>(sa, ra, m0, (kt + 1) * GEMM_BK, p.lda, tid);
       if (DMA_B) stage_dma<TB>(rb, LDS_B(cur ^ 1), n0, (kt + 1) * GEMM_BK, p.ldb, wave_u, lane);
@@ -562,25 +546,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
     }
     const unsigned char* la = LDS_A(cur);
     const unsigned char* lb = LDS_B(cur);
-#if GEMM_FRAG_MODE == 0
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag_load<TA>(la, wm * 4 + i, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = frag_load<TB>(lb, wn * 4 + j, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (SPLITK)  // un-swapped: D[m_local = 4*(lane>>4)+r][n_local = lane&15]
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-          else  // swapped: MFMA-A = weight rows (n), MFMA-B = activation rows (m) => D[n_local][m_local]
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-    }
-#else
     // all 16 fragment reads of the K-step are issued before its 32 MFMAs: the compiler's own order (6 reads, wait,
     // 2 MFMAs, wait ...) left ~50 % of the wave cycles parked on lgkmcnt (SQ_WAIT_ANY), see profiles/
     bf16x8 fa[2][4], fb[2][4];
@@ -591,37 +556,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[ks][j] = frag_load<TB>(lb, wn * 4 + j, ks, lane);
     }
-#if GEMM_FRAG_MODE == 1
     __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#ifdef VLM_GEMM_EXP_NOMFMA  // diagnostic timing build only: keep the fragment reads alive without the matrix pipe
-          if (i == j) acc[i][j][0] += (float)fa[ks][i][0] + (float)fb[ks][j][0];
-#else
           if (SPLITK)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
-#endif
         }
-#if GEMM_FRAG_MODE == 1
     __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-#ifndef VLM_GEMM_EXP_NOLOAD
     if (kt + 1 < kt1) {
       if (!DMA_A) stage_store<TA>(sa, LDS_A(cur ^ 1), tid);
       if (!DMA_B) stage_store<TB>(sb, LDS_B(cur ^ 1), tid);
     }
-#endif
     __syncthreads();
   }
-  STAMP(2)
+  GEMM_STAMP(2)
 
   if (SPLITK) {
     float* C = reinterpret_cast<float*>(p.C);
@@ -633,11 +587,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
-#ifdef VLM_GEMM_EXP_NOATOMIC  // diagnostic timing build only (wrong results): what the split-K atomics cost
-          if (m < p.M && n < p.N) C[(size_t)m * p.ldc + n] = acc[i][j][r] * p.epi.alpha;
-#else
           if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.epi.alpha);
-#endif
         }
       }
     return;
@@ -660,16 +610,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void vlm_gemm_kernel(const gemm_pa
       }
     }
   }
-#ifdef VLM_GEMM_STAMPS
-  __builtin_amdgcn_s_waitcnt(0);  // stores issued AND acknowledged for this wave
-  STAMP(3)
-#endif
+  GEMM_STAMP_END()
 }
-
-#ifdef VLM_GEMM_STAMPS
-static unsigned long long* g_stamp_buffer = nullptr;
-extern "C" void vlm_debug_set_stamp_buffer(void* ptr) { g_stamp_buffer = (unsigned long long*)ptr; }
-#endif
 
 template <bool TA, bool TB, bool OUT_F32, bool DMA_A, bool DMA_B, bool SPLITK>
 static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
@@ -712,16 +654,6 @@ static int launch_gemm(const gemm_params_t& p, hipStream_t stream) {
 // keeps accumulators in VGPRs, 1675 vs 1345 cycles per step).
 // LDS image of an operand stage: [256 rows][32 k] bf16, 64-B rows, 16-B slot s of row r holds chunk s ^ f((r>>2)&3),
 // f = (0,2,3,1): conflict-free for ds_read_b128's lane groups (rows {0-3,12-15} x chunk c with rows {4-11} x chunk c^1).
-// diagnostic timing builds only (tools/scratch/gemm_bench.hip; results are wrong): knock out one part of the K loop
-#ifndef BIG_DIAG_DMA
-#define BIG_DIAG_DMA 1
-#endif
-#ifndef BIG_DIAG_READ
-#define BIG_DIAG_READ 1
-#endif
-#ifndef BIG_DIAG_BARRIER
-#define BIG_DIAG_BARRIER 1
-#endif
 #define BIG_BM 256
 #define BIG_BN 256
 #define BIG_BK 32
@@ -745,9 +677,6 @@ __device__ __forceinline__ uint32_t big_swz(uint32_t q) { return (0x78u >> (2 * 
 #ifndef EPIL_LOAD_AUX
 #define EPIL_LOAD_AUX 2  // cache policy of the GELU' argument's loads (the pre-activation saved by the forward pass, read once): 2 = nt
                          // (54296x3072x768: 419 -> 403 us).  The residual loads stay plain: nt there cost 3-40 % (in-place stream)
-#endif
-#ifndef EPIL_DIAG
-#define EPIL_DIAG 0  // diagnostic timing builds (wrong results): 1 no C stores, 2 no input loads, 4 no aux stores, 8 no finish wait
 #endif
 #define EPIL_PITCH (128 * 4 + 16)
 #define EPIL_WAVE_BYTES (32 * EPIL_PITCH)
@@ -810,7 +739,6 @@ struct big_epilogue_t {
   // per-element inputs of the 16-row block i (4 rows per lane): a fixed number of loads per variant, no branch
   __device__ __forceinline__ void load_inputs(epil_in_t& in, int i) const {
     const vlm_epilogue_t& e = p.epi;
-    if (EPIL_DIAG & 2) return;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const uint32_t m = mw0 + 16 * i + RPG * t + lr;
@@ -891,8 +819,7 @@ struct big_epilogue_t {
         bf16x8 o;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-        if (EPIL_DIAG & 1) asm volatile("" ::"v"(o));
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_c, (m * (uint32_t)p.ldc + n) * 2, 0, STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_c, (m * (uint32_t)p.ldc + n) * 2, 0, STORE_AUX);
       }
     }
   }
@@ -989,7 +916,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
     p_grp.epi.col_sum_ws = G.col_sum_ws;
   }
   const gemm_params_t& p = GROUPED ? p_grp : p_in;
-  STAMP(0)
+  GEMM_STAMP(0)
   const uint32_t n0 = tn * BIG_BN;
   const __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.M * p.lda * 2), 0x00020000);
@@ -1080,12 +1007,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   {                                                                                      \
     if (RD) {                                                                            \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
-      if (BIG_DIAG_BARRIER) __builtin_amdgcn_s_barrier();                                \
+      __builtin_amdgcn_s_barrier();                                                      \
     }                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                   \
-    if (WR && BIG_DIAG_DMA) { BIG_LWRITE(RSA, RSB, BUFA_W, BUFB_W) }                     \
-    if (GL && BIG_DIAG_DMA) { BIG_GLOAD(RSA, RSB, (K) + 4) }                             \
-    if (RD && BIG_DIAG_READ) { BIG_READ(FNA, FNB, BUFA_R, BUFB_R) }                      \
+    if (WR) { BIG_LWRITE(RSA, RSB, BUFA_W, BUFB_W) }                                     \
+    if (GL) { BIG_GLOAD(RSA, RSB, (K) + 4) }                                             \
+    if (RD) { BIG_READ(FNA, FNB, BUFA_R, BUFB_R) }                                       \
     BIG_MFMA(FCA, FCB)                                                                   \
     _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                     \
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                 \
@@ -1110,8 +1037,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   BIG_READ(fa0, fb0, sA0, sB0)
-  if (!BIG_DIAG_READ) { BIG_READ(fa1, fb1, sA0, sB0) }
-  STAMP(1)
+  GEMM_STAMP(1)
 
   int kt = 0;
   for (; kt < nk - 4; kt += 2) {
@@ -1126,7 +1052,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
   BIG_STEP(kt + 2, 0, 0, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
   BIG_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
 
-  STAMP(2)
+  GEMM_STAMP(2)
   // epilogue.  Wave tiles that are whole in N and keep the 16-B alignments go through the looped LDS-transpose epilogue
   // (column sums: a wave covers its 128-row half alone -- workspace slot 2 tm + wm when the half is complete, else
   // atomics); the rest (ragged N, odd leading dimensions) take the generic 64x64 epilogue, column sums by atomics.
@@ -1135,10 +1061,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
     BIG_EPILOGUE_LOOP()
     ep.finish(lane, ws_row);
   }
-#ifdef VLM_GEMM_STAMPS
-  __builtin_amdgcn_s_waitcnt(0);
-  STAMP(3)
-#endif
+  GEMM_STAMP_END()
 }
 
 // ---- 256x256 tile for wgrad: dW[M,N] = A^T B with BOTH operands K-strided (A stored [K][M], B stored [K][N]) ---------
@@ -1148,6 +1071,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
 // output tiles on 256 CUs); a slice does not add into C with atomics (1 024 256-B float atomics per workgroup would cost
 // as much as 80 K steps, MI355X_MICROARCH.md "Global float atomics") but stores its fp32 tile into the caller's
 // workspace [slice][M][N] through the looped epilogue, and splitk_reduce_kernel adds the slices into C.
+// GROUPED (vlm_gemm_wgrad_grouped): the token rows of several experts reduce into several weight gradients in one launch;
+// a workgroup's item belongs to one group, whose row range bounds its K slice (rows past the range read zeros).
+template <bool GROUPED = false>
 __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const gemm_params_t p) {
   __shared__ __attribute__((aligned(1024))) unsigned char sA0[BIG_OP_BYTES], sA1[BIG_OP_BYTES], sB0[BIG_OP_BYTES], sB1[BIG_OP_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char epl[4 * EPIL_WAVE_BYTES];
@@ -1161,15 +1087,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const ge
   // slice = block / tiles).
   const uint32_t ntile = p.tiles_m * p.tiles_n;
   const uint32_t q8 = gridDim.x >> 3, r8 = gridDim.x & 7, xcd = blockIdx.x & 7;
-  const uint32_t item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  uint32_t item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  uint32_t k_base = 0, k_end = (uint32_t)p.K, slice0 = 0;
+  int nk = p.ksteps_per_split;  // even, >= 4: launcher
+  if constexpr (GROUPED) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < VLM_GEMM_MAX_GROUPS; ++i)
+      if (i < p.n_groups && item >= (uint32_t)p.grpT[i].item0) g = i;
+    const gemmT_group_t G = p.grpT[g];
+    item -= (uint32_t)G.item0;
+    k_base = (uint32_t)G.row0;
+    k_end = (uint32_t)G.row_end;
+    nk = G.kps;
+    slice0 = (uint32_t)G.slice0;
+  }
   const uint32_t split = item / ntile, tile = item - split * ntile;
   const uint32_t tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const uint32_t m0 = tm * BIG_BM, n0 = tn * BIG_BN;
-  const uint32_t k_first = split * (uint32_t)p.ksteps_per_split * BIG_BK;
+  const uint32_t k_first = k_base + split * (uint32_t)nk * BIG_BK;
   const __amdgpu_buffer_rsrc_t ra =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)p.K * p.lda * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((uint64_t)k_end * p.lda * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rb =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)p.K * p.ldb * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)((uint64_t)k_end * p.ldb * 2), 0x00020000);
 
   // staging: wave instruction j = wave + 4u covers k-rows 2j, 2j+1; lane -> k-row 2j + (lane>>5), 16-B chunk lane&31.
   // Rows k >= K fall off the descriptor (zeros); x >= M or N reads the next row's head: those accumulators are dropped.
@@ -1201,7 +1141,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const ge
       acc10[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc11[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-  const int nk = p.ksteps_per_split;  // even, >= 4: launcher
   const uint32_t stepa = BIG_BK * (uint32_t)p.lda * 2, stepb = BIG_BK * (uint32_t)p.ldb * 2;
   bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
   u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
@@ -1267,7 +1206,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const ge
 
   // this slice's fp32 tile -> workspace [split][M][N] (plain f32 epilogue, alpha applied; rows >= M dropped)
   gemm_params_t pl = p;
-  pl.C = reinterpret_cast<float*>(p.C) + (size_t)split * p.M * p.N;
+  pl.C = reinterpret_cast<float*>(p.C) + (size_t)(slice0 + split) * p.M * p.N;
   pl.ldc = p.N;
   const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
   unsigned char* const wl = epl + wave * EPIL_WAVE_BYTES;
@@ -1285,6 +1224,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const size_t e = i * 4, m = e / N, n = e - m * N;
   f32x4 t = accumulate ? *reinterpret_cast<const f32x4*>(C + m * ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < splits; ++s) t += *reinterpret_cast<const f32x4*>(ws + (size_t)s * M * N + e);
+  *reinterpret_cast<f32x4*>(C + m * ldc + n) = t;
+}
+
+// grouped form: blockIdx.y = group; its slices start at slice0[g]
+struct splitk_groups_t {
+  float* C[VLM_GEMM_MAX_GROUPS];
+  int slice0[VLM_GEMM_MAX_GROUPS], splits[VLM_GEMM_MAX_GROUPS], accumulate[VLM_GEMM_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(const float* __restrict__ ws, const splitk_groups_t g, int M, int N, int ldc) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)M * N / 4;
+  if (i >= per) return;
+  const int gi = blockIdx.y;
+  float* const C = g.C[gi];
+  const size_t e = i * 4, m = e / N, n = e - m * N;
+  f32x4 t = g.accumulate[gi] ? *reinterpret_cast<const f32x4*>(C + m * ldc + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < g.splits[gi]; ++s) t += *reinterpret_cast<const f32x4*>(ws + (size_t)(g.slice0[gi] + s) * M * N + e);
   *reinterpret_cast<f32x4*>(C + m * ldc + n) = t;
 }
 
@@ -1313,7 +1268,7 @@ static int launch_gemm_bigT(gemm_params_t p, const vlm_epilogue_t* epi, hipStrea
   float* const out = reinterpret_cast<float*>(p.C);
   const int ldc = p.ldc;
   p.C = epi->splitk_ws;
-  hipLaunchKernelGGL(vlm_gemm_bigT_kernel, dim3(ntile * splits), dim3(GEMM_THREADS), 0, stream, p);
+  hipLaunchKernelGGL(vlm_gemm_bigT_kernel<false>, dim3(ntile * splits), dim3(GEMM_THREADS), 0, stream, p);
   VLM_CHECK_LAUNCH();
   const size_t per = (size_t)p.M * p.N / 4;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream,
@@ -1333,9 +1288,7 @@ static int launch_gemm_big(gemm_params_t p, hipStream_t stream) {
     return v;
   }();
   p.group_m = group_m ? group_m : (p.tiles_n >= 6 ? 4 : 1);
-#ifdef VLM_GEMM_STAMPS
-  p.stamps = g_stamp_buffer;
-#endif
+  GEMM_STAMP_ARM(p)
   hipLaunchKernelGGL((vlm_gemm_big_kernel<OUT_F32, RES, AUX, GROUPED>), dim3(p.tiles_m * p.tiles_n), dim3(GEMM_THREADS), 0, stream, p);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
@@ -1481,9 +1434,7 @@ static int gemm_dispatch(int ta, int tb, int M, int N, int K, const void* A, int
     return v;
   }();
   p.group_m = group_m ? group_m : (p.tiles_n >= 12 ? 8 : 1);
-#ifdef VLM_GEMM_STAMPS
-  p.stamps = g_stamp_buffer;
-#endif
+  GEMM_STAMP_ARM(p)
   hipStream_t s = (hipStream_t)stream;
   // split-K: pure accumulation into fp32 (wgrad), few output tiles, long reduction
   const int ntile = p.tiles_m * p.tiles_n, nk = (K + GEMM_BK - 1) / GEMM_BK;
@@ -1653,6 +1604,104 @@ extern "C" int vlm_gemm_bf16_grouped(int n_groups, const vlm_gemm_group_t* group
     if (e.row_scale) e.row_scale += r0;
     const int rc = gemm_dispatch(0, 0, G.rows, N, K, reinterpret_cast<const unsigned char*>(A) + r0 * lda * 2, lda, G.B, G.ldb,
                                  reinterpret_cast<unsigned char*>(C) + r0 * ldc * (c_is_f32 ? 4 : 2), ldc, c_is_f32, &e, stream, true);
+    if (rc) return rc;
+  }
+  return VLM_OK;
+}
+
+// Grouped wgrad: dW_g[M,N] (+)= A[rows_g]^T B[rows_g] for every group of token rows in ONE launch of the 256x256 wgrad kernel
+// plus one reduce launch (the experts of an all_moe block, vision_transformer.py:607-681: the text expert's 3 520 tokens are a
+// tenth of a round on their own).  The workgroups of one round are dealt to the groups by their share of the reduction.
+extern "C" int vlm_gemm_wgrad_grouped(int n_groups, const vlm_wgrad_group_t* groups, int M, int N, const void* A, int lda,
+                                      const void* B, int ldb, int ldc, float* splitk_ws, uint64_t splitk_ws_bytes, void* stream) {
+  if (n_groups < 1 || n_groups > VLM_GEMM_MAX_GROUPS || !groups || M < 0 || N < 0) return VLM_ERR_ARG;
+  int prev_end = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    if (groups[g].row0 < prev_end || groups[g].rows < 0 || !groups[g].C) return VLM_ERR_ARG;
+    prev_end = groups[g].row0 + groups[g].rows;
+  }
+  if (M == 0 || N == 0) return VLM_OK;
+  if (!A || !B || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return VLM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  for (int g = 0; g < n_groups; ++g)  // an empty reduction: C_g = 0 unless accumulating
+    if (groups[g].rows == 0 && !groups[g].accumulate &&
+        hipMemset2DAsync(groups[g].C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s) != hipSuccess)
+      return VLM_ERR_LAUNCH;
+  const int K_total = prev_end;
+  bool big = gemm_big_mode() > 0 && splitk_ws && (N % BIG_BN) == 0 && (ldc % 4) == 0 && (uint64_t)M * N * 4 < (1ull << 31) &&
+             (uint64_t)K_total * lda * 2 < (1ull << 31) && (uint64_t)K_total * ldb * 2 < (1ull << 31);
+  gemm_params_t p;
+  p.A = A; p.B = B; p.C = splitk_ws;
+  p.M = M; p.N = N; p.K = K_total;
+  p.lda = lda; p.ldb = ldb; p.ldc = N;
+  p.epi = vlm_epilogue_t{};
+  p.epi.alpha = 1.0f;
+  p.epi.reserved = 1;
+  p.tiles_m = (M + BIG_BM - 1) / BIG_BM;
+  p.tiles_n = (N + BIG_BN - 1) / BIG_BN;
+  p.group_m = 1;
+  p.splits = 1;
+  p.ksteps_per_split = 0;
+  p.n_groups = 0;
+  splitk_groups_t rg{};
+  if (big) {
+    const int ntile = p.tiles_m * p.tiles_n;
+    int cus = vlm_device_cus();
+    if (cus <= 0) cus = 256;
+    long total_steps = 0;
+    int live = 0;
+    for (int g = 0; g < n_groups; ++g)
+      if (groups[g].rows > 0) { total_steps += (groups[g].rows + BIG_BK - 1) / BIG_BK; ++live; }
+    if (live == 0) return VLM_OK;
+    if ((long)live * ntile > cus) big = false;  // more tiles than one round holds: the plain path's own split rules apply
+    // steps per workgroup so that the launch is one round: the smallest target whose slice count fits
+    long target = (total_steps * ntile + cus - 1) / cus;
+    if (target < 16) target = 16;
+    for (; big; target += 2) {
+      long items = 0;
+      for (int g = 0; g < n_groups; ++g)
+        if (groups[g].rows > 0) items += (((groups[g].rows + BIG_BK - 1) / BIG_BK + target - 1) / target) * ntile;
+      if (items <= cus) break;
+    }
+    int item0 = 0, slice0 = 0;
+    for (int g = 0; g < n_groups && big; ++g) {
+      const vlm_wgrad_group_t& G = groups[g];
+      if (G.rows == 0) continue;
+      if ((uintptr_t)G.C & 15) { big = false; break; }
+      const int nk = (G.rows + BIG_BK - 1) / BIG_BK;
+      int splits = (int)((nk + target - 1) / target);
+      int kps = (nk + splits - 1) / splits;
+      kps += kps & 1;
+      if (kps < 4) kps = 4;
+      splits = (nk + kps - 1) / kps;
+      const int i = p.n_groups++;
+      p.grpT[i] = gemmT_group_t{G.row0, G.row0 + G.rows, item0, kps, slice0};
+      rg.C[i] = G.C; rg.slice0[i] = slice0; rg.splits[i] = splits; rg.accumulate[i] = G.accumulate;
+      item0 += splits * ntile;
+      slice0 += splits;
+    }
+    if (big && (size_t)slice0 * M * N * 4 > (size_t)splitk_ws_bytes) big = false;
+    if (big) {
+      hipLaunchKernelGGL(vlm_gemm_bigT_kernel<true>, dim3(item0), dim3(GEMM_THREADS), 0, s, p);
+      VLM_CHECK_LAUNCH();
+      const size_t per = (size_t)M * N / 4;
+      hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3((unsigned)((per + 255) / 256), p.n_groups), dim3(256), 0, s,
+                         reinterpret_cast<const float*>(splitk_ws), rg, M, N, ldc);
+      VLM_CHECK_LAUNCH();
+      return VLM_OK;
+    }
+  }
+  for (int g = 0; g < n_groups; ++g) {  // not offered: one plain wgrad call per group
+    const vlm_wgrad_group_t& G = groups[g];
+    if (G.rows == 0) continue;
+    vlm_epilogue_t e{};
+    e.alpha = 1.0f;
+    e.accumulate = G.accumulate;
+    e.splitk_ws = splitk_ws;
+    e.splitk_ws_bytes = splitk_ws_bytes;
+    const size_t r0 = (size_t)G.row0;
+    const int rc = gemm_dispatch(1, 1, M, N, G.rows, reinterpret_cast<const unsigned char*>(A) + r0 * lda * 2, lda,
+                                 reinterpret_cast<const unsigned char*>(B) + r0 * ldb * 2, ldb, G.C, ldc, 1, &e, stream, true);
     if (rc) return rc;
   }
   return VLM_OK;

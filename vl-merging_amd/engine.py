@@ -619,13 +619,12 @@ class _BlockFn(torch.autograd.Function):
                                    fold=fold)
             ops.gemm_grouped(dy2, [(r0, r1, wT16(e.fc2w), None, e.fc1b.grad if fuse_b1 else None) for r0, r1, e in rg], dh,
                              act=act_bwd, aux=h, col_sum_fold=fold if fuse_b1 else None)
-            for r0, r1, e in rg:
-                rr = slice(r0, r1)
-                if not fuse_b1:
-                    ops.colsum(dh[rr], e.fc1b.grad)
-                with _Side(dy2, a, dh, ln2):
-                    ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
-                    ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
+            if not fuse_b1:
+                for r0, r1, e in rg:
+                    ops.colsum(dh[r0:r1], e.fc1b.grad)
+            with _Side(dy2, a, dh, ln2):
+                ops.gemm_wgrad_grouped(dy2, a, [(r0, r1, e.fc2w.grad) for r0, r1, e in rg])
+                ops.gemm_wgrad_grouped(dh, ln2, [(r0, r1, e.fc1w.grad) for r0, r1, e in rg])
             ops.gemm_grouped(dh, [(r0, r1, wT16(e.fc1w), None, None) for r0, r1, e in rg], dln)
             for r0, r1, e in rg:
                 rr = slice(r0, r1)
@@ -634,10 +633,8 @@ class _BlockFn(torch.autograd.Function):
                 ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad,
                                    fold=fold)
             ops.gemm_grouped(dy1, [(r0, r1, wT16(e.projw), None, None) for r0, r1, e in rg], do)
-            for r0, r1, e in rg:
-                rr = slice(r0, r1)
-                with _Side(dy1, o):
-                    ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
+            with _Side(dy1, o):
+                ops.gemm_wgrad_grouped(dy1, o, [(r0, r1, e.projw.grad) for r0, r1, e in rg])
         with _ExpertStreams(() if grouped else plan.ranges) as es:
             for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
                 rr = slice(r0, r1)
@@ -680,8 +677,8 @@ class _BlockFn(torch.autograd.Function):
                 if e.qb is not None and not fused_qv:
                     ops.colsum(dqkv[rr, :D], e.qb.grad)
                     ops.colsum(dqkv[rr, 2 * D:], e.vb.grad)
-                with _Side(dqkv, ln1):
-                    ops.gemm(dqkv[rr], ln1[rr], e.qkvw.grad, ta=True, tb=True, accumulate=True)
+            with _Side(dqkv, ln1):
+                ops.gemm_wgrad_grouped(dqkv, ln1, [(r0, r1, e.qkvw.grad) for r0, r1, e in plan.ranges])
             ops.gemm_grouped(dqkv, [(r0, r1, wT16(e.qkvw), None, None) for r0, r1, e in plan.ranges], dln1)
             for r0, r1, e in plan.ranges:
                 rr = slice(r0, r1)

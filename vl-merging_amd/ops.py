@@ -135,6 +135,30 @@ def gemm_grouped(a, groups, out, *, act=L.ACT_NONE, aux=None, col_scale=None, ro
     return out
 
 
+def gemm_wgrad_grouped(dy, x, groups, accumulate=True):
+    """dW_g (+)= dy[r0:r1]^T x[r0:r1] for every group (r0, r1, dW_g f32 [M, N]) of token rows in one launch
+    (include/vlm_hip.h vlm_gemm_wgrad_grouped): the weight gradients of an all_moe block's experts."""
+    L.require_cuda(dy, x)
+    if dy.dtype != BF16 or x.dtype != BF16 or dy.shape[0] != x.shape[0]:
+        raise L.VlmError("gemm_wgrad_grouped: bf16 dy [tokens, M] and x [tokens, N]")
+    M, N = dy.shape[1], x.shape[1]
+    arr = (L.WgradGroup * len(groups))()
+    prev, ldc = 0, None
+    for g, (r0, r1, dW) in zip(arr, groups):
+        L.require_cuda(dW)
+        if dW.dtype != F32 or tuple(dW.shape) != (M, N) or r0 < prev or r1 < r0 or r1 > dy.shape[0]:
+            raise L.VlmError("gemm_wgrad_grouped: group (%d, %d) gradient %s for M=%d N=%d" % (r0, r1, tuple(dW.shape), M, N))
+        if ldc is not None and _ld(dW) != ldc:
+            raise L.VlmError("gemm_wgrad_grouped: the groups' gradients must share one leading dimension")
+        ldc = _ld(dW)
+        prev = r1
+        g.row0, g.rows, g.C, g.accumulate = r0, r1 - r0, dW.data_ptr(), int(bool(accumulate))
+    ws = _splitk_workspace(dy.device)
+    rc = L.get_lib().vlm_gemm_wgrad_grouped(len(groups), arr, M, N, L.ptr(dy), _ld(dy), L.ptr(x), _ld(x), ldc, L.ptr(ws),
+                                            ws.numel() * 4, L.stream_ptr())
+    L.check(rc, "vlm_gemm_wgrad_grouped")
+
+
 _SPLITK_WS = {}
 SPLITK_WS_BYTES = 96 << 20
 

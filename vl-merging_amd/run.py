@@ -79,7 +79,11 @@ def evaluate(model, cfg, dm_mod, vu, obj, split, rank, world, dev):
                     sums[k] = sums.get(k, 0.0) + float(v) * bsz
             n += bsz
     keys = sorted(sums)
-    t = torch.tensor([sums[k] for k in keys] + [float(n)], device=dev, dtype=torch.float64)
+    if world > 1:  # a rank that was dealt no batch (more ranks than batches) has seen no loss: agree on the key set first
+        every = [None] * world
+        dist.all_gather_object(every, keys)
+        keys = sorted(set(k for ks in every for k in ks))
+    t = torch.tensor([sums.get(k, 0.0) for k in keys] + [float(n)], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t)
     for i, k in enumerate(keys):
@@ -109,7 +113,7 @@ def main(argv):
     ddp = importlib.import_module("vl_merging_amd.ddp")
     ckpt_mod = importlib.import_module("vl_merging_amd.checkpoint")
     dm_mod = importlib.import_module("vl_merging_amd.vilt.datamodules")
-    from bench import synthetic_batch
+    synthetic_batch = importlib.import_module("vl_merging_amd.synthetic").synthetic_batch
     steps_cap = None
     rest = []
     for a in argv:
@@ -159,10 +163,10 @@ def main(argv):
     data = dm_mod.ArrowBatches(cfg, "train", rank, world) if cfg["data_root"] else None
     if data is not None:
         per_epoch = data.steps_per_epoch()
-        lim = cfg["limit_train_batches"]
+        lim = cfg["limit_train_batches"]  # Lightning: a float is a fraction of the epoch, an int a number of batches
         if isinstance(lim, float) and lim < 1.0:
             per_epoch = int(per_epoch * lim)
-        elif isinstance(lim, int) and lim > 1:
+        elif isinstance(lim, int) and not isinstance(lim, bool) and lim >= 1:
             per_epoch = min(per_epoch, lim)
         if per_epoch < grad_steps:
             raise ValueError("the train split gives %d batches per rank and epoch, fewer than the %d accumulated per step"
@@ -172,17 +176,27 @@ def main(argv):
         if data is None:
             max_steps = 100000
         else:
-            max_steps = (per_epoch // grad_steps) * int(cfg["max_epoch"])
+            max_steps = per_epoch * int(cfg["max_epoch"]) // grad_steps  # len(loader) * max_epochs // accumulate_grad_batches
     (opt,), (sch,) = vu.set_schedule(model, max_steps=max_steps)
     red = ddp.FlatGradReducer(model, sharded=bool(cfg.get("use_sharded_training"))).attach(opt)  # same set-up as bench.py
     opt.grad_scale = red.grad_scale / grad_steps  # mean over micro-batches and ranks, folded into AdamW
     global_step, epoch, in_epoch = 0, 0, 0  # in_epoch: micro-batches of the current epoch consumed so far
-    if resumed is not None and resumed.get("optimizer_states"):
-        opt.load_state_dict(resumed["optimizer_states"][0])
-        sch["scheduler"].load_state_dict(resumed["lr_schedulers"][0])
+    if resumed is not None:
+        # the position of the run (step, epoch, schedule, place in the epoch) is restored whether or not the file holds Adam's
+        # moments: a weights-only checkpoint must not restart the warm-up at step 0 on trained weights
         global_step, epoch = int(resumed.get("global_step", 0)), int(resumed.get("epoch", 0))
         in_epoch = int(resumed.get("vlm_micro_batches_in_epoch", 0))
-        log(rank, "resumed optimizer at global_step %d, epoch %d (+%d micro-batches)" % (global_step, epoch, in_epoch))
+        if resumed.get("lr_schedulers"):
+            sch["scheduler"].load_state_dict(resumed["lr_schedulers"][0])
+        else:
+            sch["scheduler"].load_state_dict({"last_epoch": global_step})
+        if resumed.get("optimizer_states"):
+            opt.load_state_dict(resumed["optimizer_states"][0])
+            log(rank, "resumed optimizer at global_step %d, epoch %d (+%d micro-batches)" % (global_step, epoch, in_epoch))
+        else:
+            opt.step_count = global_step  # Adam's bias correction continues; its moments restart from zero
+            log(rank, "WARNING: %s holds no optimizer_states: Adam's moments restart from zero at global_step %d (schedule, "
+                      "epoch and data position restored)" % (resume, global_step))
     last_step = max_steps if steps_cap is None else min(max_steps, global_step + steps_cap)
     log(rank, "global batch %d = %d per GPU x %d ranks x %d accumulated micro-batches; steps %d -> %d"
         % (B * world * grad_steps, B, world, grad_steps, global_step, last_step))
@@ -205,9 +219,41 @@ def main(argv):
             epoch += 1
             in_epoch = 0
 
+    # ---- ModelCheckpoint(save_last=True) (run.py:189-195): last.ckpt at every validation interval and at the end ---------------
+    vdir = None
+    if cfg["log_dir"]:
+        vdir = os.path.dirname(os.path.dirname(resume)) if resume and os.path.dirname(resume).endswith("checkpoints") \
+            and os.path.abspath(resume).startswith(os.path.abspath(run_dir(cfg))) else next_version_dir(cfg)
+    vci = cfg["val_check_interval"]  # Lightning: a float is a fraction of the epoch, an int a number of training batches
+    if os.environ.get("VLM_SAVE_EVERY"):
+        save_every = int(os.environ["VLM_SAVE_EVERY"])
+    elif data is None:
+        save_every = 0
+    elif isinstance(vci, float):
+        save_every = max(1, int(per_epoch * vci) // grad_steps)
+    else:
+        save_every = max(1, int(vci) // grad_steps)
+
+    def save_last():
+        """Every rank calls it (a sharded optimizer's state is gathered collectively); rank 0 writes, through a temporary
+        file and os.replace: a crash mid-save leaves the previous last.ckpt (the resume source) intact."""
+        extra = {"lr_schedulers": [sch["scheduler"].state_dict()], "vlm_micro_batches_in_epoch": in_epoch,
+                 "optimizer_states": [opt.state_dict()] if (rank == 0 or red.sharded) else None}
+        if rank != 0 or vdir is None:
+            return None
+        os.makedirs(os.path.join(vdir, "checkpoints"), exist_ok=True)
+        path = os.path.join(vdir, "checkpoints", "last.ckpt")
+        tmp = path + ".tmp.%d" % os.getpid()
+        ckpt_mod.save_ckpt(tmp, model, global_step=global_step, epoch=epoch, extra=extra)
+        os.replace(tmp, path)
+        print("saved %s (global_step %d)" % (path, global_step), flush=True)
+        return path
+
     seen = []  # dataset indices of every micro-batch this rank consumed (returned: tests check the resumed data order)
     stream = micro_batches()
     loss = None
+    path = None
+    saved_at = -1
     while global_step < last_step:
         t0 = time.time()
         red.begin_step()
@@ -224,23 +270,14 @@ def main(argv):
         global_step += 1
         if rank == 0 and (global_step % 10 == 0 or global_step == last_step or global_step <= 3):
             print("step %d loss %.4f  %.1f ms" % (global_step, float(loss.detach()), (time.time() - t0) * 1e3), flush=True)
+        if save_every and global_step % save_every == 0 and global_step < last_step:
+            path = save_last() or path
+            saved_at = global_step
 
-    # ---- ModelCheckpoint(save_last=True) ---------------------------------------------------------------------------------
     if world > 1:
         dist.barrier()
-    path = None
-    if rank == 0 and cfg["log_dir"]:
-        vdir = os.path.dirname(os.path.dirname(resume)) if resume and os.path.dirname(resume).endswith("checkpoints") \
-            and os.path.abspath(resume).startswith(os.path.abspath(run_dir(cfg))) else next_version_dir(cfg)
-        os.makedirs(os.path.join(vdir, "checkpoints"), exist_ok=True)
-        path = os.path.join(vdir, "checkpoints", "last.ckpt")
-        extra = {"lr_schedulers": [sch["scheduler"].state_dict()], "vlm_micro_batches_in_epoch": in_epoch}
-        try:
-            extra["optimizer_states"] = [opt.state_dict()]
-        except NotImplementedError as e:  # sharded optimizer: weights only
-            print("last.ckpt without optimizer state:", e, flush=True)
-        ckpt_mod.save_ckpt(path, model, global_step=global_step, epoch=epoch, extra=extra)
-        print("saved %s" % path, flush=True)
+    if saved_at != global_step:
+        path = save_last() or path
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

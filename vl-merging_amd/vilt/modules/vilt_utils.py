@@ -134,29 +134,117 @@ class FusedAdamW:
         return [n for n in self.flat.names if n not in self._active]
 
     # ---- checkpoint / resume (Lightning keeps `optimizer_states` in the .ckpt, run.py:189-195, :218-223, :280) --------
-    def state_dict(self):
-        """Adam's moments as CPU tensors keyed by parameter name (layout-independent), the step count, the active set."""
-        if self._shard is not None:
-            raise NotImplementedError("sharded optimizer state is spread over the ranks: save from an unsharded run")
+    def _torch_order(self):
+        """(index -> parameter name, per-group index lists) in the order torch numbers the reference's optimizer: the four
+        groups of set_schedule one after the other, each in named_parameters() order (vilt_utils.py:272-312)."""
+        heads = head_names(self.model.hparams.config)
+        per_group = [[] for _ in range(4)]
+        for n, _ in self.model.named_parameters():
+            per_group[param_group_of(n, heads)].append(n)
+        names = [n for g in per_group for n in g]
+        idx, k = [], 0
+        for g in per_group:
+            idx.append(list(range(k, k + len(g))))
+            k += len(g)
+        return names, idx
+
+    def _full_moments(self):
+        """Adam's m / v over the whole flat buffer.  Sharded mode (a COLLECTIVE: every rank calls it): each rank scatters the
+        chunks it owns into zeros and the ranks' disjoint pieces meet by all-reduce."""
+        if self._shard is None:
+            return self.m, self.v
+        import torch.distributed as dist
         f = self.flat
+        full = []
+        for packed in (self.m, self.v):
+            t = torch.zeros_like(f.flat_p)
+            for lo, hi, off in self._shard:
+                t[lo:hi].copy_(packed[off:off + hi - lo])
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(t)
+            full.append(t)
+        return full
+
+    def state_dict(self):
+        """torch.optim layout, as the reference's `resume_from_checkpoint` reads it (its optimizer is transformers.AdamW, a
+        torch.optim.Optimizer: state keyed by the parameter's index in param_groups order with `step` / `exp_avg` /
+        `exp_avg_sq`, param_groups with `params` index lists).  Only parameters that have an Adam state appear (HF AdamW
+        creates it at a parameter's first gradient).  `vlm_*` keys carry what this engine needs on top: the index -> name map
+        (a resume does not depend on registration order) and the set of parameters a backward pass has reached.
+        With a sharded optimizer this is a collective (every rank calls it; every rank gets the full state)."""
+        f = self.flat
+        m, v = self._full_moments()
+        names, idx = self._torch_order()
         state = {}
-        for n in f.names:
+        for i, n in enumerate(names):
+            if n not in self._active or n not in f.offsets:
+                continue
             o, k = f.offsets[n]
-            state[n] = {"exp_avg": self.m[o:o + k].detach().cpu().clone(), "exp_avg_sq": self.v[o:o + k].detach().cpu().clone()}
-        return {"state": state, "step": self.step_count, "active": sorted(self._active),
-                "param_groups": [{k: v for k, v in g.items() if k != "ranges"} for g in self.param_groups]}
+            state[i] = {"step": int(self.step_count), "exp_avg": m[o:o + k].detach().cpu().clone(),
+                        "exp_avg_sq": v[o:o + k].detach().cpu().clone()}
+        shapes = {n: tuple(p.shape) for n, p in self.model.named_parameters()}
+        for i, st in state.items():
+            st["exp_avg"] = st["exp_avg"].view(shapes[names[i]])
+            st["exp_avg_sq"] = st["exp_avg_sq"].view(shapes[names[i]])
+        groups = []
+        for g, ids in zip(self.param_groups, idx):
+            d = {k: v_ for k, v_ in g.items() if k != "ranges"}
+            d.update(betas=tuple(self.betas), eps=self.eps, correct_bias=True, params=ids)
+            groups.append(d)
+        return {"state": state, "param_groups": groups, "vlm_names": names, "vlm_step": int(self.step_count),
+                "vlm_active": sorted(self._active)}
 
     def load_state_dict(self, sd):
+        """Accepts (a) the torch layout above -- written here or by the reference's own run (no vlm_* keys: the index -> name map
+        is rebuilt from this model's named_parameters() and checked against the file's group sizes) -- and (b) the
+        name-keyed layout round-3 checkpoints hold.  Anything else raises: a resume that silently drops Adam's moments
+        restarts the warm-up on trained weights."""
         f = self.flat
-        for n, st in sd["state"].items():
+        state = sd.get("state")
+        if not isinstance(state, dict) or "param_groups" not in sd:
+            raise ValueError("optimizer state has neither the torch.optim layout nor this engine's: keys %s" % sorted(sd)[:8])
+        by_name, step = {}, sd.get("vlm_step", sd.get("step"))
+        if all(isinstance(k, str) for k in state):  # (b) round-3 files
+            by_name = state
+        else:
+            names = sd.get("vlm_names")
+            if names is None:
+                names, idx = self._torch_order()
+                sizes = [len(g.get("params", ())) for g in sd["param_groups"]]
+                if sizes != [len(i) for i in idx]:
+                    raise ValueError("optimizer state was written for a different model: its parameter groups hold %s "
+                                     "parameters, this model's %s" % (sizes, [len(i) for i in idx]))
+            for i, st in state.items():
+                if not isinstance(i, int) or i >= len(names):
+                    raise ValueError("optimizer state index %r outside the %d parameters of the model" % (i, len(names)))
+                by_name[names[i]] = st
+        full_m, full_v = (self.m, self.v) if self._shard is None else (torch.zeros_like(f.flat_p), torch.zeros_like(f.flat_p))
+        steps = []
+        for n, st in by_name.items():
             if n not in f.offsets:
                 continue
             o, k = f.offsets[n]
-            self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
-            self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-        self.step_count = int(sd["step"])
-        f.touched |= set(sd.get("active", ()))
+            if st["exp_avg"].numel() != k:
+                raise ValueError("optimizer state of %s has %d elements, the parameter %d" % (n, st["exp_avg"].numel(), k))
+            full_m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            full_v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            if "step" in st:
+                steps.append(int(st["step"]))
+        if self._shard is not None:
+            for lo, hi, off in self._shard:
+                self.m[off:off + hi - lo].copy_(full_m[lo:hi])
+                self.v[off:off + hi - lo].copy_(full_v[lo:hi])
+        if step is None:
+            if not steps:
+                raise ValueError("optimizer state carries no step count")
+            step = max(steps)  # HF AdamW counts per parameter; the bias correction here is global (all active from step 1)
+        self.step_count = int(step)
+        f.touched |= set(sd.get("vlm_active", sd.get("active", by_name.keys())))
         self._discover_active()
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "initial_lr", "weight_decay"):
+                if k in src:
+                    g[k] = src[k]
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
