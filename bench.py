@@ -393,36 +393,54 @@ def _free_port():
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher (reference: `run.py:263-288`, `gpus=N, accelerator="ddp"` makes
     Lightning start one process per GPU): this parent starts N fresh rank processes BEFORE anything here touches the
-    GPU, stays off the GPU itself, relays rank 0's JSON line as its own last line and fails if any rank fails."""
+    GPU, stays off the GPU itself, relays rank 0's JSON line as its own last line and fails if any rank fails.
+    Every rank's stderr is relayed line by line with a `[rank r]` tag; a wall-clock limit (VLM_BENCH_TIMEOUT_S, default
+    1800 s) ends a job whose ranks are all alive but stuck in a collective."""
     import subprocess
+    import threading
     port = os.environ.get("MASTER_PORT") or str(_free_port())
+    limit = float(os.environ.get("VLM_BENCH_TIMEOUT_S", "1800"))
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    import threading
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     buf = []
-    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
+
+    def relay(r, stream):
+        for ln in stream:
+            sys.stderr.write("[rank %d] %s" % (r, ln if ln.endswith("\n") else ln + "\n"))
+            sys.stderr.flush()
+
+    threads = [threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)]
+    threads += [threading.Thread(target=relay, args=(r, p.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
     codes = [None] * n
+    t_start = time.time()
+    timed_out = False
     while any(c is None for c in codes):  # a rank that dies leaves its peers waiting in a collective: end them (our own PIDs)
         for i, p in enumerate(procs):
             if codes[i] is None:
                 codes[i] = p.poll()
-        if any(c for c in codes if c is not None):
+        timed_out = time.time() - t_start > limit
+        if any(c for c in codes if c is not None) or timed_out:
             for i, p in enumerate(procs):
                 if codes[i] is None:
                     p.kill()
                     codes[i] = p.wait()
             break
         time.sleep(0.2)
-    reader.join(timeout=30)
+    for t in threads:
+        t.join(timeout=30)
     out0 = buf[0] if buf else ""
     lines = [ln for ln in out0.splitlines() if ln.strip()]
     for ln in lines[:-1]:
-        sys.stderr.write(ln + "\n")
+        sys.stderr.write("[rank 0 stdout] " + ln + "\n")
+    if timed_out:
+        sys.stderr.write("bench.py: no result after %.0f s (VLM_BENCH_TIMEOUT_S): ranks killed, exit codes %r\n" % (limit, codes))
+        sys.exit(124)
     if any(codes):
         sys.stderr.write("bench.py: rank exit codes %r\n" % (codes,))
         if lines:
@@ -480,6 +498,10 @@ def main():
     if os.environ.get("VLM_BENCH_DRY_RUN", "0") != "0":
         if os.environ.get("VLM_BENCH_TEST_FAIL_RANK") == str(rank):  # launcher test: a rank that dies before rendezvous
             sys.exit(3)
+        if os.environ.get("VLM_BENCH_TEST_HANG"):  # launcher test: every rank alive, none making progress
+            sys.stderr.write("hanging on purpose\n")
+            sys.stderr.flush()
+            time.sleep(3600)
         return dry_run(args, rank, world)
     if rank != 0:  # RCCL prints a version banner on stdout in every process: only rank 0 may write there
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
@@ -504,6 +526,7 @@ def main():
     vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
     ops = importlib.import_module("vl_merging_amd.ops")
     ddp = importlib.import_module("vl_merging_amd.ddp")
+    L_ = importlib.import_module("vl_merging_amd._lib")
 
     cfg = cfgmod.make_config("task_mlm_itm_ifm_square_randaug_base_vl", "step200k", args.arch,
                              image_size=args.image_size, vit="vit_base_patch16_%d" % args.image_size,
@@ -574,7 +597,9 @@ def main():
             # time the compute stream waits for the tail of the gradient all-reduce (rank 0), per step
             "exposed_comm_ms_per_step": exposed_comm_ms,
             "grad_comm": {"dtype": "bf16" if reducer.comm_dtype is not None else "fp32", "collective": reducer.collective,
-                          "sharded_optimizer": reducer.sharded, "bytes_per_step": int(reducer.flat.numel) * (2 if reducer.comm_dtype is not None else 4)},
+                          "sharded_optimizer": reducer.sharded, "bytes_per_step": int(reducer.flat.numel) * (2 if reducer.comm_dtype is not None else 4),
+                          "buckets": reducer.bucket_plan(),
+                          "cu_budget": L_.get_lib().vlm_device_cus()},  # VLM_GEMM_CUS: CUs the GEMM grids plan for (RCCL takes the rest)
         }
         flop_per_sample = FLOP_PER_SAMPLE_384 if args.image_size == 384 else 657.5e9
         out["model_tflops"] = value * flop_per_sample / 1e12 / world

@@ -9,8 +9,8 @@
  *   - return 0 on success, a negative VLM_ERR_* otherwise; nothing throws across the boundary;
  *   - process-wide state is limited to (1) diagnostic switches read ONCE from the environment at first use (VLM_GEMM_BIG,
  *     VLM_GEMM_BIGT, VLM_GEMM_STAGE, VLM_GEMM_SPLITK, VLM_GEMM_SPLITK_SLOTS, VLM_GEMM_GROUP_M, VLM_GEMM_BIG_GROUP_M,
- *     VLM_GEMM_TAIL_SPLIT, VLM_ATT_DB_GROUPS, VLM_MERGE_VARIANT: thread-safe function-local statics,
- *     immutable afterwards) and (2) the test hook vlm_gemm_set_big_tile_mode (one atomic int).  None changes results
+ *     VLM_GEMM_TAIL_SPLIT, VLM_GEMM_CUS, VLM_ATT_DB_GROUPS, VLM_MERGE_VARIANT: thread-safe function-local statics,
+ *     immutable afterwards) and (2) the hooks vlm_gemm_set_big_tile_mode and vlm_set_cu_budget (one atomic int each).  None changes results
  *     beyond the fp32 summation order of a GEMM or of the bias-table gradient.
  *
  * Token layout ("segment-major"): a pass over B samples with n0 text and n1 image tokens per sample keeps
@@ -35,8 +35,12 @@ extern "C" {
 
 #define VLM_ABI_VERSION 6
 int vlm_abi_version(void);
-/* Number of compute units of the current device (grid sizing), or negative error. */
+/* Number of compute units grid sizing and split-K slice counts plan for, or negative error: the current device's count,
+ * or the smaller budget set by VLM_GEMM_CUS=n (environment, read once) / vlm_set_cu_budget(n) -- room for RCCL's kernels
+ * in a data-parallel job (0 or negative: back to the device's count).  Results do not depend on it beyond fp32 summation
+ * order (the number of K slices of a wgrad). */
 int vlm_device_cus(void);
+int vlm_set_cu_budget(int cus);
 
 /* ------------------------------------------------------------------------------------------------
  * Checkpoint merge (K12/K13/K14-bias): modules/vilt_module.py:533-638 (merge_weights),
@@ -255,8 +259,10 @@ int vlm_patch_im2col(const float* image, void* patches_bf16, int B, int H, int W
  * factorisation + two triangular solves built from vlm_potrf_block_f64 (in-place lower factor of one <= 64-wide
  * diagonal block; *status gets 1 + the index of a non-positive pivot), vlm_trsm_block_f64 (X <- X op(L)^-1 for a
  * row panel against one diagonal block; trans = 1: X L^T = B, trans = 0: X L = B) and vlm_gemm_f64 for the block
- * updates; vl_merging_amd/regmean.py walks the block columns.  vlm_accumulate_f32_f64 (dst += src) is kept for callers
- * that already hold an fp32 product. */
+ * updates.  vlm_cholesky_f64 (in-place lower factor of a contiguous SPD [n, n] matrix; *status as above, checked by the
+ * caller whenever it chooses to synchronise) and vlm_solve_spd_right_f64 (rhs [rows, ld] <- rhs (L L^T)^-1 in place) walk the
+ * block columns inside the library: one call each per merged weight.  vlm_accumulate_f32_f64 (dst += src) is kept for
+ * callers that already hold an fp32 product. */
 int vlm_accumulate_f32_f64(const float* src, double* dst_f64, uint64_t n, void* stream);
 int vlm_gram_f64(const void* x, int ldx, int M, int D, int x_is_f32, double* gram, void* stream);
 int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32, const double* B,
@@ -264,6 +270,8 @@ int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* 
 int vlm_scale_gram_f64(const double* src, double* dst, int n, double alpha, int accumulate, void* stream);
 int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* status, void* stream);
 int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* B, int ldb, int rows, int c0, void* stream);
+int vlm_cholesky_f64(double* A, int n, int* status, void* stream);
+int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, int ld, int rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (K4 + K7 + K7b): softmax(scale*Q K^T + bias[h] + key mask) V, head_dim = 64.

@@ -42,6 +42,9 @@ def _worker(rank, world, port, q):
         red = ddp.FlatGradReducer(m)
         assert red.world == 2 and abs(red.grad_scale - 0.5) < 1e-12
         assert sorted(red.block_slices) == [0, 1, 2] and len(red.tail_slices) == 1 and len(red.late_slices) == 1
+        plan = red.bucket_plan()  # what bench.py reports as grad_comm.buckets: issue order, MB on the wire
+        assert plan["count"] == 5 and [b["what"] for b in plan["in_issue_order"]] == ["block 2", "heads", "block 1", "block 0", "embeddings"]
+        assert abs(plan["total_MB"] - sum(hi - lo for lo, hi in red.buckets()) * 4 / 1e6) < 0.06
         for step in range(3):
             red.begin_step()
             for p in m.parameters():

@@ -3,10 +3,10 @@ fp32 oracle on the same deterministic weights and batch.
 
 Stated tolerance (north star: "fp within a stated tol for attention/FFN"): activations are rounded to bf16 between
 kernels (8 significant bits, like the reference's fp16 AMP path rounds to 11), so
-   features after 12 blocks : max |err| <= 2e-2 * max|ref|   (measured: <= 1.0e-2 at base width, <= 0.7e-2 at tiny width)
-   logits                   : max |err| <= 3e-2 * max|ref|   (measured: <= 1.9e-2, the B = 3 contrastive logits)
+   features after 12 blocks : max |err| <= 1.7e-2 * max|ref| (1.5 x the measured 1.14e-2 at base width; <= 0.7e-2 at tiny width)
+   logits                   : max |err| <= 2e-2 * max|ref|   (1.5 x the measured 1.36e-2; the B = 3 tiny-width contrastive logits: 4.5e-2)
    losses                   : |err| <= 3e-2 (absolute, values are O(1..10))
-   parameter-gradient norms : relative error <= 4e-2 per tensor (measured: <= 1.3e-2; bf16 operands of the wgrad GEMMs)
+   parameter-gradient norms : relative error <= 2.5e-2 per tensor (1.5 x the measured 1.5e-2, train mode all_moe; bf16 wgrad operands)
 """
 import importlib
 import json
@@ -55,10 +55,10 @@ FLOOR = 2.5e-4  # absolute gradient-norm floor: below it ANY reduced-precision p
 
 
 def grad_norm_class(got, ref):
-    """Which rule lets a tensor's gradient norm pass: "rel" (4 %), "small" (norm <= 0.05: 20 %), "floor" (absolute
+    """Which rule lets a tensor's gradient norm pass: "rel" (2.5 %), "small" (norm <= 0.05: 20 %), "floor" (absolute
     2.5e-4 only), or None (fails)."""
     rel = abs(got - ref) / (ref + 1e-12)
-    if rel <= 4e-2:
+    if rel <= 2.5e-2:
         return "rel"
     if ref <= 0.05 and rel <= 0.20:
         return "small"
@@ -68,7 +68,7 @@ def grad_norm_class(got, ref):
 
 
 def grad_norm_ok(got, ref):
-    """4 % per tensor (measured at base width: max 1.3 %, median 0.1 %).  Gradients whose norm is below 2.5e-4 in
+    """2.5 % per tensor (measured: max 1.5 %, median 0.1 %).  Gradients whose norm is below 2.5e-4 in
     absolute terms (logit_vl_scale at B = 2: 3.9e-5) are below the noise floor of ANY reduced-precision path: the
     reference's own fp16-autocast run moves that one by 114 % (tests/golden/amp_reference_errors.json).
     Tensors with a small gradient (norm <= 0.05: here those fed only by the B=2 contrastive
@@ -76,10 +76,10 @@ def grad_norm_ok(got, ref):
     ill-conditioned in any 8-bit-mantissa activation format, and run-to-run sensitive to the order of the fp32 atomic
     accumulations) get 20 %; near-zero scalar gradients an absolute 1e-4."""
     rel = abs(got - ref) / (ref + 1e-12)
-    return rel <= 4e-2 or (ref <= 0.05 and rel <= 0.20) or abs(got - ref) <= 2.5e-4
+    return rel <= 2.5e-2 or (ref <= 0.05 and rel <= 0.20) or abs(got - ref) <= 2.5e-4
 
 
-def feat_close(got, ref, what, tol=2e-2):
+def feat_close(got, ref, what, tol=1.7e-2):
     got = got.float().cpu()
     ref = torch.as_tensor(ref)
     err = float((got - ref).abs().max())
@@ -129,8 +129,8 @@ def test_training_step_matches_reference_golden(mods, golden_dir, arch):
     for k in ("mlm_loss", "ifm_loss", "itm_loss"):
         assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
     assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
-    feat_close(ret["mlm_logits"], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
-    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
+    feat_close(ret["mlm_logits"], gold["step/mlm_logits"], "mlm logits", tol=2e-2)
+    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=2e-2)
     gs = json.loads(str(gold["step/grad_summary"]))
     named = dict(model.named_parameters())
     bad = []
@@ -164,7 +164,9 @@ def test_irtr_matches_reference_golden(mods, golden_dir, arch):
     ret = model(batch)
     ret["irtr_loss"].backward()
     assert abs(float(ret["irtr_loss"]) - float(gold["irtr_loss"])) <= 2e-2
-    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits", tol=3e-2)
+    # B = 3 contrastive logits at tiny width: exp(logit_scale) ~ 14 times the DIFFERENCE of nearly identical normalised features
+    # (measured 3.0e-2 for ufo, 1.0e-2 for all_moe and at base width, where the bound is 2e-2)
+    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits", tol=4.5e-2)
     gs = json.loads(str(gold["grad_summary"]))
     named = dict(model.named_parameters())
     bad = [(n, float(named[n].grad.double().norm()), v[0]) for n, v in gs.items()
@@ -261,7 +263,7 @@ def test_downstream_heads_match_reference_golden(mods, golden_dir, task):
     torch.cuda.synchronize()
     want = float(gold[task + "/loss"])
     assert abs(float(loss) - want) <= 2e-2 * max(1.0, abs(want)), (float(loss), want)
-    feat_close(ret[task + "_logits"], gold[task + "/logits"], task + " logits", tol=5e-2)
+    feat_close(ret[task + "_logits"], gold[task + "/logits"], task + " logits", tol=1e-2)
     gs = json.loads(str(gold[task + "/grad_summary"]))
     named = dict(model.named_parameters())
     bad = []
@@ -351,10 +353,10 @@ def test_planned_droppath_sites(mods):
 # CPU by make_golden.py model_base -> tests/golden/amp_reference_errors.json) deviates from its fp32 path on the same
 # quantities at this width:
 #   quantity                                 fp16-autocast reference    this engine's bound
-#   features (max err / max |ref|)           <= 1.7e-3                  2e-2   (measured <= 1.0e-2)
+#   features (max err / max |ref|)           <= 1.7e-3                  1.7e-2 (1.5 x the measured 1.14e-2)
 #   losses (absolute)                        <= 6e-4                    3e-2 (total 5e-2)
-#   logits (max err / max |ref|)             <= 1e-3                    3e-2 (itm 5e-2; measured <= 1.1e-2)
-#   gradient norm per tensor, norm > 0.05    <= 0.5 %  (median 5e-5)    4 %    (measured max 1.3 %, median 0.1 %)
+#   logits (max err / max |ref|)             <= 1e-3                    2e-2   (1.5 x the measured 1.36e-2, itm)
+#   gradient norm per tensor, norm > 0.05    <= 0.5 %  (median 5e-5)    2.5 %  (1.5 x the measured 1.5 %, median 0.1 %)
 #   gradient norm per tensor, norm <= 0.05   up to 6 % (ufo) / 114 % (all_moe: the near-zero contrastive gradients)   20 %
 # fp16 keeps 11 significant bits, the engine's bf16 activations 8 (8x coarser per rounding), and the engine rounds
 # between every pair of kernels where autocast only rounds GEMM operands; what the engine actually reaches is written
@@ -455,9 +457,9 @@ def test_base_width_matches_reference_golden(mods, golden_dir, arch):
     for k in ("mlm_loss", "ifm_loss", "itm_loss"):
         assert abs(float(ret[k]) - float(gold["step/" + k])) <= 3e-2, (k, float(ret[k]), float(gold["step/" + k]))
     assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
-    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
-    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
-    feat_close(ret["ifm_i2t_logits"], gold["step/ifm_i2t_logits"], "ifm logits", tol=3e-2)
+    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=2e-2)
+    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=2e-2)
+    feat_close(ret["ifm_i2t_logits"], gold["step/ifm_i2t_logits"], "ifm logits", tol=2e-2)
     check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))
     named = dict(model.named_parameters())
     for key in gold.files:
@@ -510,7 +512,7 @@ def test_irtr_on_merged_weights_base_width(mods, golden_dir):
     ret["irtr_loss"].backward()
     torch.cuda.synchronize()
     assert abs(float(ret["irtr_loss"]) - float(gold["irtr_loss"])) <= 2e-2
-    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits", tol=3e-2)
+    feat_close(ret["irtr_i2t_logits"], gold["irtr_i2t_logits"], "irtr logits", tol=2e-2)
     with torch.no_grad():
         feat_close(model.infer_image_ft(batch)["cls_feats"], gold["img_cls_feats"], "img cls")
         feat_close(model.infer_text_ft(batch)["cls_feats"], gold["txt_cls_feats"], "txt cls")
@@ -527,9 +529,11 @@ def _oracle_index(model):
 
 
 @pytest.mark.parametrize("arch,B,losses", [("all_moe", 22, {"itm": 1, "mlm": 1, "ifm": 1}),
+                                           ("ufo", 22, {"itm": 1, "mlm": 1, "ifm": 1}),  # configs[1]: the bench line's workload
                                            ("ufo", 20, {"irtr": 1, "itm": 0, "mlm": 0, "ifm": 0})])
 def test_full_size_step_properties(mods, golden_dir, arch, B, losses):
-    """configs[2] (all_moe 384^2, B = 22, mlm + itm + ifm) and configs[4] (irtr 384^2, B = 20) at FULL size, train mode,
+    """configs[2] (all_moe 384^2, B = 22, mlm + itm + ifm), configs[1] (ufo, same tasks: the bench line's workload) and
+    configs[4] (irtr 384^2, B = 20) at FULL size, train mode,
     two optimizer steps.  Size-independent properties: (1) batch independence - rows of the full-batch eval pass equal
     the CPU oracle run on two of its samples alone (fp tolerance 3e-2 of the feature scale); (2) losses finite and,
     at random init on a fixed batch, lower after two AdamW steps; (3) every parameter the step's passes use receives a
@@ -593,6 +597,10 @@ def test_full_size_step_properties(mods, golden_dir, arch, B, losses):
     if irtr:   # text-only + image-only passes of a ufo model: every block tensor is used, the joint-pass heads are not
         assert all(n in used for n in gn if n.startswith("transformer.blocks."))
         assert "pooler.dense.weight" in unused
+    elif arch == "ufo":  # configs[1]: one shared expert per layer serves every pass; the heads of all three tasks are used
+        assert all(n in used for n in gn if n.startswith("transformer.blocks."))
+        assert "mlm_score.decoder.weight" in used and "itm_score.fc.weight" in used and "ifm_text_proj.fc.weight" in used
+        assert "transformer.mask_token" in unused
     else:      # all_moe pre-training: v / l experts in every layer, vl experts from layer 10 on
         assert "transformer.blocks.3.mlp.v.fc1.weight" in used and "transformer.blocks.3.mlp.l.fc1.weight" in used
         assert "transformer.blocks.11.mlp.vl.fc2.weight" in used
@@ -694,8 +702,8 @@ def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
     assert abs(float(total) - float(gold["step/total_loss"])) <= 5e-2
     eval_gold = np.load(os.path.join(golden_dir, f"model_tiny_{arch}.npz"))
     assert abs(float(gold["step/total_loss"]) - float(eval_gold["step/total_loss"])) > 1e-3
-    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=3e-2)
-    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=5e-2)
+    feat_close(ret["mlm_logits"][..., ::int(gold["mlm_cols"])], gold["step/mlm_logits"], "mlm logits", tol=2e-2)
+    feat_close(ret["itm_logits"], gold["step/itm_logits"], "itm logits", tol=2e-2)
     check_grad_summary(model, json.loads(str(gold["step/grad_summary"])))
 
 
@@ -728,3 +736,49 @@ def test_infer_with_precomputed_image_embeds(mods, golden_dir):
         assert torch.equal(cut2["image_feats"][:, :-20], cut["image_feats"][:, :-20])
     with pytest.raises(ValueError):
         model.infer(batch, image_embeds=emb)
+
+
+def test_dense_bias_is_cached_on_the_table_version(mods, golden_dir):
+    """vlm_bias_dense output (the tiled fp16 relative-position bias of all layers and heads) is rebuilt only when the table
+    changed: a no_grad sweep over many batches (compute_irtr_recall) builds it once per pass geometry; an optimizer step, a
+    reload and an in-place edit of the table each invalidate it -- and the outputs follow the new table."""
+    eng = importlib.import_module("vl_merging_amd.engine")
+    model = build(mods, "ufo", "tiny_ufo", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})
+    batch = gpu_batch(det_batch(2, 224, 40, 1024, seed=77))
+    st = eng._DENSE_STATS
+
+    def sweep(n):
+        b0, h0 = st["built"], st["hits"]
+        with torch.no_grad():
+            outs = [model.infer(batch, mask_text=False)["cls_feats"].clone() for _ in range(n)]
+        return st["built"] - b0, st["hits"] - h0, outs
+
+    sweep(1)                                   # whatever state earlier tests left: make the cache current
+    built, hits, o1 = sweep(3)
+    assert built == 0 and hits > 0 and hits % 3 == 0  # three passes, no rebuild
+    k = hits // 3                              # dense tables per pass (one per attention mode the layers use)
+    assert torch.equal(o1[0], o1[2])
+    # (1) an in-place torch edit of the table
+    with torch.no_grad():
+        model.relative_position_bias_table.mul_(1.5)
+    built, hits, o2 = sweep(2)
+    assert built == k and hits == k
+    assert not torch.equal(o2[0], o1[0])
+    # (2) an optimizer step (the HIP kernel writes the table through a raw pointer: torch's version counter does not move)
+    model.train()
+    model.hparams.config["warmup_steps"] = 0
+    (opt,), _ = mods[1].vilt_utils.set_schedule(model, max_steps=10)
+    v0 = model.relative_position_bias_table._version
+    model.training_step({"vl": batch}).backward()
+    opt.step()
+    model.eval()
+    built, hits, o3 = sweep(2)
+    assert built == k and hits == k, (built, hits, v0, model.relative_position_bias_table._version)
+    assert not torch.equal(o3[0], o2[0])
+    # (3) a reload
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["relative_position_bias_table"] = sd["relative_position_bias_table"] * 0.5
+    model.load_state_dict(sd)
+    built, hits, o4 = sweep(2)
+    assert built == k and hits == k
+    assert not torch.equal(o4[0], o3[0])

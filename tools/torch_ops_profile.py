@@ -54,5 +54,5 @@ flt = os.environ.get("VLM_PROFILE_FILTER")
 if flt:
     import re as _re
     rows = [e for e in rows if _re.search(flt, e.key)]
-for e in rows[:45]:
+for e in rows[:90]:
     print("%-28s n=%4d  dev %8.1f us  %s" % (e.key[:28], e.count, e.self_device_time_total, str(e.input_shapes)[:110]))

@@ -86,6 +86,7 @@ _ERR = {-1: "VLM_ERR_ARG", -2: "VLM_ERR_LAUNCH", -3: "VLM_ERR_WORKSPACE", -4: "V
 SIGNATURES = {
     "vlm_abi_version": (c_int, []),
     "vlm_device_cus": (c_int, []),
+    "vlm_set_cu_budget": (c_int, [c_int]),
     "vlm_merge_plan_bytes": (c_size_t, [c_int, c_u64]),
     "vlm_merge_plan_upload": (c_int, [ctypes.POINTER(MergeJob), c_int, c_void_p, c_size_t, c_void_p]),
     "vlm_merge_run": (c_int, [c_void_p, c_void_p]),
@@ -118,6 +119,8 @@ SIGNATURES = {
     "vlm_scale_gram_f64": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_double, c_int, c_void_p]),
     "vlm_potrf_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlm_trsm_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vlm_cholesky_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "vlm_solve_spd_right_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_embedding_bwd": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int,
                                   ctypes.c_int64, c_void_p]),

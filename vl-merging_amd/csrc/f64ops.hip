@@ -188,32 +188,47 @@ extern "C" int vlm_scale_gram_f64(const double* src, double* dst, int n, double 
 // ---------------------------------------------------------------------------------------------------- Cholesky block
 // In-place lower Cholesky factor of the nb x nb (nb <= 64) diagonal block at A[j0][j0] (row-major, leading dimension
 // lda): one wave, the block lives in LDS.  status[0] is set to j0 + k + 1 if pivot k is not positive (not SPD).
+// Thread t holds ROW t of the block in registers (every index below is a compile-time constant: a runtime-indexed local array
+// would live in scratch memory); step k: the pivot and column k of the factor reach every lane by v_readlane (lane numbers are
+// compile-time constants in the unrolled loops: scalar broadcasts, no LDS round trip, no barrier -- the LDS version spent 134 us
+// per block on its three barriers and dependent LDS chains per step).  Unused rows / columns of a ragged block (nb < 64) are
+// padded with the identity.
+__device__ __forceinline__ double f64_readlane(double v, int lane) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 __global__ __launch_bounds__(64) void potrf_block_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ status) {
-  __shared__ double s[64][65];
   const int t = threadIdx.x;
-  for (int r = 0; r < nb; ++r)
-    if (t < nb) s[r][t] = A[(size_t)(j0 + r) * lda + j0 + t];
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    const double d = s[k][k];
-    if (!(d > 0.0)) {
-      if (t == 0 && status) atomicCAS(status, 0, j0 + k + 1);
-      return;
-    }
+  double a[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) a[c] = (t < nb && c < nb) ? A[(size_t)(j0 + t) * lda + j0 + c] : (c == t ? 1.0 : 0.0);
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const double d = f64_readlane(a[k], k);  // a[k][k] as thread k holds it now (wave-uniform)
+    if (!(d > 0.0) && !bad) bad = j0 + k + 1;
     const double rd = sqrt(d);
-    __syncthreads();
-    if (t == k) s[k][k] = rd;
-    if (t > k && t < nb) s[t][k] = s[t][k] / rd;
-    __syncthreads();
-    // trailing update: thread t owns column t (t > k): s[i][t] -= s[i][k] * s[t][k] for i >= t
-    if (t > k && t < nb) {
-      const double ltk = s[t][k];
-      for (int i = t; i < nb; ++i) s[i][t] -= s[i][k] * ltk;
+    const double l = t == k ? rd : a[k] / rd;  // l[t][k] for t >= k (lanes t < k: never read)
+    a[k] = l;
+    // row t, columns j in (k, t]: a[t][j] -= l[t][k] * l[j][k]
+#pragma unroll
+    for (int jj = k + 1; jj < 64; ++jj) {
+      const double ljk = f64_readlane(l, jj);
+      if (jj <= t) a[jj] -= l * ljk;
     }
-    __syncthreads();
   }
-  for (int r = 0; r < nb; ++r)
-    if (t < nb) A[(size_t)(j0 + r) * lda + j0 + t] = t <= r ? s[r][t] : 0.0;
+  if (bad) {  // not SPD: report the first non-positive pivot, leave the block as it was (the caller falls back on its copy)
+    if (t == 0 && status) atomicCAS(status, 0, bad);
+    return;
+  }
+  if (t < nb) {
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (c < nb) A[(size_t)(j0 + t) * lda + j0 + c] = c <= t ? a[c] : 0.0;
+  }
 }
 
 extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* status, void* stream) {
@@ -228,35 +243,40 @@ extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* stat
 // X (rows x nb, in place in Bm at column c0) <- X * op(L)^-1 with L the nb x nb lower-triangular block at L[l0][l0]:
 //   trans = 1:  X L^T = B  (forward over the block's columns: Cholesky panel, first RegMean solve)
 //   trans = 0:  X L   = B  (backward over the block's columns: second RegMean solve)
-// One thread per row, the triangle in LDS (broadcast reads).
+// One thread per row of X, the row in registers (compile-time indices only: a runtime-indexed local array lives in scratch
+// memory -- the first version of this kernel took 200 us per launch that way), the triangle in LDS (broadcast reads), padded
+// with the identity for a ragged block.  Right-looking: once x_j is final every later column takes its update -- 63 - j
+// independent FMAs instead of one dependent chain.
 __global__ __launch_bounds__(64) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
                                                         double* __restrict__ Bm, int ldb, int rows, int c0) {
   __shared__ double s[64][65];
   const int t = threadIdx.x;
-  for (int r = 0; r < nb; ++r)
-    if (t < nb) s[r][t] = L[(size_t)(l0 + r) * ldl + l0 + t];
+  for (int r = 0; r < 64; ++r) s[r][t] = (r < nb && t < nb) ? L[(size_t)(l0 + r) * ldl + l0 + t] : (r == t ? 1.0 : 0.0);
   __syncthreads();
   const int row = blockIdx.x * 64 + t;
   if (row >= rows) return;
   double* x = Bm + (size_t)row * ldb + c0;
   double v[64];
-#pragma unroll 8
-  for (int j = 0; j < nb; ++j) v[j] = x[j];
-  if (trans) {  // x_j = (b_j - sum_{k<j} x_k L[j][k]) / L[j][j]
-    for (int j = 0; j < nb; ++j) {
-      double acc = v[j];
-      for (int k = 0; k < j; ++k) acc -= v[k] * s[j][k];
-      v[j] = acc / s[j][j];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) v[j] = j < nb ? x[j] : 0.0;
+  if (trans) {  // X L^T = B:  x_j = (b_j - sum_{k<j} x_k L[j][k]) / L[j][j]
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      v[j] = v[j] / s[j][j];
+#pragma unroll
+      for (int k = j + 1; k < 64; ++k) v[k] -= v[j] * s[k][j];
     }
-  } else {      // x_j = (b_j - sum_{k>j} x_k L[k][j]) / L[j][j]
-    for (int j = nb - 1; j >= 0; --j) {
-      double acc = v[j];
-      for (int k = j + 1; k < nb; ++k) acc -= v[k] * s[k][j];
-      v[j] = acc / s[j][j];
+  } else {      // X L = B:    x_j = (b_j - sum_{k>j} x_k L[k][j]) / L[j][j]
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+      v[j] = v[j] / s[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v[k] -= v[j] * s[j][k];
     }
   }
-#pragma unroll 8
-  for (int j = 0; j < nb; ++j) x[j] = v[j];
+#pragma unroll
+  for (int j = 0; j < 64; ++j)
+    if (j < nb) x[j] = v[j];
 }
 
 extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* Bm, int ldb, int rows, int c0,
@@ -266,5 +286,56 @@ extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int 
   hipLaunchKernelGGL(trsm_block_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, L, ldl, l0, nb, trans, Bm, ldb,
                      rows, c0);
   VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- blocked drivers
+// The whole factorisation / solve as ONE call: the block-column loops run here instead of in the Python host code (a 3072^2
+// factor is 48 block columns x 3 launches, the solve 2 x 48 x 2 more: issuing them through ctypes cost more host time than the
+// kernels take).  Same kernels, same order, same results as the per-block entry points above.
+extern "C" int vlm_cholesky_f64(double* A, int n, int* status, void* stream) {
+  if (n == 0) return VLM_OK;
+  if (!A || n < 0 || !status) return VLM_ERR_ARG;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int nb = n - j0 < 64 ? n - j0 : 64, r = n - j0 - nb;
+    int rc = vlm_potrf_block_f64(A, n, j0, nb, status, stream);
+    if (rc) return rc;
+    if (r > 0) {
+      double* below = A + (size_t)(j0 + nb) * n;
+      rc = vlm_trsm_block_f64(A, n, j0, nb, 1, below, n, r, j0, stream);  // panel: L21 = A21 L11^-T
+      if (rc) return rc;
+      // trailing update A22 -= L21 L21^T
+      rc = vlm_gemm_f64(0, 1, r, r, nb, -1.0, below + j0, n, 0, below + j0, n, 1.0, below + j0 + nb, n, stream);
+      if (rc) return rc;
+    }
+  }
+  return VLM_OK;
+}
+
+// rhs [rows][ld] <- rhs (L L^T)^-1 in place: Y L^T = rhs forward over the block columns, then X L = Y backward.
+// RIGHT-looking: as soon as a block column of the solution is known, the columns still to be solved are updated by one GEMM
+// over ALL of them (rows x (n - j1) outputs, K = 64) -- a left-looking sweep would compute each 64-column block with one
+// GEMM of rows / 64 workgroups and a reduction up to n long: 12 workgroups on 256 CUs for a [768, 3072] right-hand side.
+extern "C" int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, int ld, int rows, void* stream) {
+  if (n == 0 || rows == 0) return VLM_OK;
+  if (!chol || !rhs || n < 0 || rows < 0 || ld < n) return VLM_ERR_ARG;
+  for (int j0 = 0; j0 < n; j0 += 64) {  // Y[:, jb] = B[:, jb] L[jb, jb]^-T ;  B[:, j1:] -= Y[:, jb] L[j1:, jb]^T
+    const int nb = n - j0 < 64 ? n - j0 : 64, j1 = j0 + nb;
+    int rc = vlm_trsm_block_f64(chol, n, j0, nb, 1, rhs, ld, rows, j0, stream);
+    if (rc) return rc;
+    if (j1 < n) {
+      rc = vlm_gemm_f64(0, 1, rows, n - j1, nb, -1.0, rhs + j0, ld, 0, chol + (size_t)j1 * n + j0, n, 1.0, rhs + j1, ld, stream);
+      if (rc) return rc;
+    }
+  }
+  for (int j0 = ((n - 1) / 64) * 64; j0 >= 0; j0 -= 64) {  // X[:, jb] = Y[:, jb] L[jb, jb]^-1 ;  Y[:, :j0] -= X[:, jb] L[jb, :j0]
+    const int nb = n - j0 < 64 ? n - j0 : 64;
+    int rc = vlm_trsm_block_f64(chol, n, j0, nb, 0, rhs, ld, rows, j0, stream);
+    if (rc) return rc;
+    if (j0 > 0) {
+      rc = vlm_gemm_f64(0, 0, rows, j0, nb, -1.0, rhs + j0, ld, 0, chol + (size_t)j0 * n, n, 1.0, rhs, ld, stream);
+      if (rc) return rc;
+    }
+  }
   return VLM_OK;
 }

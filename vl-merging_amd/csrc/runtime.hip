@@ -1,9 +1,22 @@
 // Library identity + device queries (host only).
 #include "vlm_common.h"
+#include <atomic>
+#include <stdlib.h>
 
 extern "C" int vlm_abi_version(void) { return VLM_ABI_VERSION; }
 
-extern "C" int vlm_device_cus(void) {
+// CU budget: what grid sizing and split-K slice counts take for "the CUs of this device".  By default the device's own
+// count; VLM_GEMM_CUS=n in the environment (read once) or vlm_set_cu_budget(n) lowers it -- in a data-parallel job RCCL's
+// kernels take CUs away from grids sized for all 256 (a wgrad launch of exactly one round of workgroups then runs 1 + epsilon
+// rounds), so the first multi-GPU measurements can leave them room without a rebuild.  0 / negative: back to the device's count.
+static std::atomic<int> g_cu_budget{0};
+
+extern "C" int vlm_set_cu_budget(int cus) {
+  g_cu_budget.store(cus > 0 ? cus : 0, std::memory_order_relaxed);
+  return VLM_OK;
+}
+
+static int device_cus_raw(void) {
   static int cached = 0;  // benign race: every thread computes the same value
   if (cached > 0) return cached;
   int dev = 0;
@@ -12,4 +25,17 @@ extern "C" int vlm_device_cus(void) {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return VLM_ERR_LAUNCH;
   cached = cus;
   return cus;
+}
+
+extern "C" int vlm_device_cus(void) {
+  const int raw = device_cus_raw();
+  if (raw <= 0) return raw;
+  static const int env_budget = [] {
+    const char* e = getenv("VLM_GEMM_CUS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 0;
+  }();
+  int b = g_cu_budget.load(std::memory_order_relaxed);
+  if (b <= 0) b = env_budget;
+  return (b > 0 && b < raw) ? b : raw;
 }

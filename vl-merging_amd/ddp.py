@@ -137,6 +137,23 @@ class FlatGradReducer:
         """All buckets (flat ranges) in flat-buffer order: tail (embeddings), blocks, late (heads)."""
         return sorted(list(self.tail_slices) + list(self.block_slices.values()) + list(self.late_slices))
 
+    def bucket_plan(self):
+        """What travels per step, for the bench line: the buckets in the order their collectives are issued during backward
+        (heads with the last block's, blocks 11 .. 0, the embeddings' slice last and left in flight under AdamW), each with its
+        size on the wire -- so the first multi-GPU measurement can be read against the link model."""
+        wire = 2 if self.comm_dtype is not None else 4
+        order = []
+        for i in sorted(self.block_slices, reverse=True):
+            lo, hi = self.block_slices[i]
+            order.append({"what": "block %d" % i, "MB": round((hi - lo) * wire / 1e6, 2)})
+            if i == self.last_layer:
+                for lo2, hi2 in self.late_slices:
+                    order.append({"what": "heads", "MB": round((hi2 - lo2) * wire / 1e6, 2)})
+        for lo, hi in self.tail_slices:
+            order.append({"what": "embeddings (deferred under AdamW)" if self.defer_tail else "embeddings",
+                          "MB": round((hi - lo) * wire / 1e6, 2)})
+        return {"count": len(order), "total_MB": round(sum(b["MB"] for b in order), 2), "in_issue_order": order}
+
     def own_chunk(self, lo, hi, rank=None):
         n = hi - lo
         if n % self.world:

@@ -90,6 +90,10 @@ class FlatParams:
             span = getattr(p, "_vlm_qkv_bias_span", 0)
             p._vlm_qkv_bias = self.flat_p[o:o + span] if span else None
         self.dirty = True
+        # bumped whenever the fp32 masters change through this engine (optimizer step, shadow refresh after a load): what
+        # derived tables (the dense relative-position bias) are cached on -- the HIP kernels write through raw pointers, so
+        # torch's own tensor version counters do not see an optimizer step
+        self.version = 0
 
     def refresh_shadow(self):
         """fp32 master -> bf16 GEMM operands (one cast kernel).  Called after load_state_dict / optimizer steps."""
@@ -98,6 +102,7 @@ class FlatParams:
         ops.cast_bf16(self.flat_p[:self.numel], self.flat_b[:self.numel])
         self.refresh_transposed()
         self.dirty = False
+        self.version += 1
 
     def enable_transposed(self, predicate):
         """Keep W^T (bf16, [in, out] row-major) next to the bf16 shadow of every 2-D parameter `predicate(name)` selects:
@@ -270,21 +275,38 @@ class RelPos:
     """What the attention kernel needs instead of the reference's dense [H*L, N, N] bias (vilt_module.py:1061):
     the transposed table (autograd-connected), the int16 index in index coordinates and its transpose."""
 
-    def __init__(self, bias_t, index16, index16_t, holder):
+    def __init__(self, bias_t, index16, index16_t, holder, cache_tag=None):
         self.bias_t = bias_t          # [H*L, R] fp32, requires grad in training
         self.index = index16          # int16 [NP, ld]
         self.index_t = index16_t
         self.holder = holder          # _TableT ctx holder: accumulates d(bias_t)
         self._dense = {}              # (n0, n1, pos1, mode) -> ops.DenseBias, built on first use inside the pass
+        self.cache_tag = cache_tag    # identifies (table contents, index) across passes, or None: no cross-pass cache
 
     def dense_for(self, seq, mode):
-        """Tiled fp16 bias of all layers and heads for this pass geometry and attention mode (2 launches, once per pass
-        and step): the attention kernels add their (layer, head) slice to the score accumulators on the matrix pipe."""
+        """Tiled fp16 bias of all layers and heads for this pass geometry and attention mode (2 launches of vlm_bias_dense):
+        the attention kernels add their (layer, head) slice to the score accumulators on the matrix pipe.  Built once per
+        pass geometry and TABLE VERSION: a training step changes the table, so it rebuilds once per step and pass (the
+        minimum); a no_grad sweep over many batches (compute_irtr_recall: ~250 passes over one table) builds it once."""
         key = (seq.n0, seq.n1, seq.pos1, mode)
         d = self._dense.get(key)
         if d is None:
-            with torch.no_grad():
-                d = self._dense[key] = ops.bias_dense(self.bias_t.detach(), self.index, seq, mode)
+            ck = self.cache_tag + key if self.cache_tag is not None else None
+            d = _DENSE_CACHE.get(ck) if ck is not None else None
+            if d is None:
+                with torch.no_grad():
+                    d = ops.bias_dense(self.bias_t.detach(), self.index, seq, mode)
+                _DENSE_STATS["built"] += 1
+                if ck is not None:
+                    stale = [k for k in _DENSE_CACHE if k[:2] == ck[:2] and k[2:4] != ck[2:4]]  # same table, older contents
+                    for k in stale:
+                        del _DENSE_CACHE[k]
+                    while len(_DENSE_CACHE) >= 8:
+                        del _DENSE_CACHE[next(iter(_DENSE_CACHE))]
+                    _DENSE_CACHE[ck] = d
+            else:
+                _DENSE_STATS["hits"] += 1
+            self._dense[key] = d
         return d
 
     @property
@@ -309,12 +331,20 @@ class _TableT(torch.autograd.Function):
         return (acc + g).t(), None
 
 
+_DENSE_CACHE = {}  # (id(flat), id(table), flat.version, table._version, index ptr, n0, n1, pos1, mode) -> ops.DenseBias
+_DENSE_STATS = {"built": 0, "hits": 0}
+
+
 def make_relpos(table, index16, index16_t):
     holder = {}
     bias_t = _TableT.apply(table, holder)
     if torch.is_grad_enabled() and table.requires_grad:
         holder["dbias_t"] = torch.zeros_like(bias_t)
-    return RelPos(bias_t, index16, index16_t, holder)
+    flat = getattr(table, "_vlm_flat", None)
+    # flat.version follows optimizer steps / reloads (raw-pointer writes), table._version follows in-place torch edits;
+    # a model whose masters are marked dirty has pending edits: no cache for that pass
+    tag = (id(flat), id(table), flat.version, table._version, index16.data_ptr()) if flat is not None and not flat.dirty else None
+    return RelPos(bias_t, index16, index16_t, holder, tag)
 
 
 # ----------------------------------------------------------------------------------------------------------------

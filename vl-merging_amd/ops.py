@@ -392,48 +392,37 @@ def scale_gram(src, dst, alpha, accumulate=False):
     return dst
 
 
-def cholesky_(s):
+def cholesky_(s, status=None):
     """In-place lower Cholesky factor of the SPD float64 matrix s [n,n] (upper triangle left undefined): blocked
-    right-looking factorisation, 64-wide block columns (potrf block, panel solve, MFMA-f64 trailing update)."""
-    L.require_cuda(s)
+    right-looking factorisation, 64-wide block columns (potrf block, panel solve, MFMA-f64 trailing update), all block columns
+    issued by ONE library call (vlm_cholesky_f64).  `status` (int32 [1] device tensor, zero on entry): when given, the
+    positive-definiteness verdict is left there for the caller to read whenever it synchronises (several factorisations in
+    flight on several streams); without it this call synchronises and raises on a non-positive pivot."""
+    L.require_cuda(s, status)
     n = s.shape[0]
     if s.dtype != F64 or tuple(s.shape) != (n, n) or not s.is_contiguous():
         raise L.VlmError("cholesky_: contiguous float64 [n,n]")
-    lib, st = L.get_lib(), L.stream_ptr()
-    status = torch.zeros(1, device=s.device, dtype=torch.int32)
-    for j0 in range(0, n, 64):
-        nb = min(64, n - j0)
-        L.check(lib.vlm_potrf_block_f64(L.ptr(s), n, j0, nb, L.ptr(status), st), "vlm_potrf_block_f64")
-        r = n - j0 - nb
-        if r > 0:
-            below = s[j0 + nb:]
-            L.check(lib.vlm_trsm_block_f64(L.ptr(s), n, j0, nb, 1, L.ptr(below), n, r, j0, st), "vlm_trsm_block_f64")
-            panel = below[:, j0:j0 + nb]
-            gemm_f64(panel, panel, below[:, j0 + nb:], tb=True, alpha=-1.0, beta=1.0)
-    bad = int(status.item())
-    if bad:
-        raise L.VlmError("cholesky_: matrix is not positive definite (pivot %d)" % (bad - 1))
+    own = status is None
+    if own:
+        status = torch.zeros(1, device=s.device, dtype=torch.int32)
+    L.check(L.get_lib().vlm_cholesky_f64(L.ptr(s), n, L.ptr(status), L.stream_ptr()), "vlm_cholesky_f64")
+    if own:
+        bad = int(status.item())
+        if bad:
+            raise L.VlmError("cholesky_: matrix is not positive definite (pivot %d)" % (bad - 1))
     return s
 
 
 def solve_spd_right_(rhs, chol):
     """rhs [rows, n] <- rhs (L L^T)^-1 in place, `chol` from cholesky_: Y L^T = rhs forward over the block columns, then
-    X L = Y backward (vlm_trsm_block_f64 on the diagonal blocks, MFMA-f64 GEMMs for the off-diagonal updates)."""
+    X L = Y backward (triangular block solves on the diagonal blocks, MFMA-f64 GEMMs for the off-diagonal updates), one
+    library call (vlm_solve_spd_right_f64)."""
     L.require_cuda(rhs, chol)
     rows, n = rhs.shape
     if rhs.dtype != F64 or chol.dtype != F64 or tuple(chol.shape) != (n, n) or not chol.is_contiguous() or rhs.stride(1) != 1:
         raise L.VlmError("solve_spd_right_: float64 rhs [rows, n], contiguous float64 factor [n, n]")
-    lib, st = L.get_lib(), L.stream_ptr()
-    blocks = [(j0, min(64, n - j0)) for j0 in range(0, n, 64)]
-    for j0, nb in blocks:  # Y[:, jb] = (rhs[:, jb] - Y[:, :j0] L[jb, :j0]^T) L[jb, jb]^-T
-        if j0:
-            gemm_f64(rhs[:, :j0], chol[j0:j0 + nb, :j0], rhs[:, j0:j0 + nb], tb=True, alpha=-1.0, beta=1.0)
-        L.check(lib.vlm_trsm_block_f64(L.ptr(chol), n, j0, nb, 1, L.ptr(rhs), _ld(rhs), rows, j0, st), "vlm_trsm_block_f64")
-    for j0, nb in reversed(blocks):  # X[:, jb] = (Y[:, jb] - X[:, j1:] L[j1:, jb]) L[jb, jb]^-1
-        j1 = j0 + nb
-        if j1 < n:
-            gemm_f64(rhs[:, j1:], chol[j1:, j0:j1], rhs[:, j0:j1], alpha=-1.0, beta=1.0)
-        L.check(lib.vlm_trsm_block_f64(L.ptr(chol), n, j0, nb, 0, L.ptr(rhs), _ld(rhs), rows, j0, st), "vlm_trsm_block_f64")
+    L.check(L.get_lib().vlm_solve_spd_right_f64(L.ptr(chol), n, L.ptr(rhs), _ld(rhs), rows, L.stream_ptr()),
+            "vlm_solve_spd_right_f64")
     return rhs
 
 

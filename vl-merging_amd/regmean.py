@@ -20,23 +20,62 @@ def scale_gram(G, alpha):
     return alpha * G + (1 - alpha) * torch.diag_embed(torch.diag(G))
 
 
+class _Solves:
+    """The 48 independent W* = num @ inverse(den) solves of a merge (:432-434), float64, on the device.  The sum of
+    a*G + (1-a)*diag(G) over SPD Gram matrices is SPD, so each is a blocked Cholesky factorisation + two triangular solves --
+    a long chain of small dependent launches (48 block columns for fc2's 3072^2 Gram sum) that leaves most of the chip idle:
+    the solves are dealt round-robin over a few HIP streams, and their positive-definiteness verdicts are read once, after
+    everything has been issued.  A Gram sum that is rank-deficient or numerically indefinite (few capture batches: fewer rows
+    than columns for fc2, scaling_for_non_diag = 1) has no Cholesky factor, while the reference's LU-based torch.inverse still
+    returns a result: that case falls back, loudly, to a general float64 inverse on the device (torch.linalg.inv = hipSOLVER)
+    followed by the MFMA-f64 product."""
+
+    N_STREAMS = 4
+
+    def __init__(self, device):
+        self.device = device
+        self.main = torch.cuda.current_stream(device)
+        self.streams = [torch.cuda.Stream(device) for _ in range(self.N_STREAMS)]
+        self.status = torch.zeros(64, device=device, dtype=torch.int32)
+        self.jobs = []  # (what, num (solved in place), den copy, status index)
+
+    def submit(self, num, den, what):
+        i = len(self.jobs)
+        if i >= self.status.numel():
+            self.status = torch.cat([self.status, torch.zeros_like(self.status)])
+        st = self.streams[i % self.N_STREAMS]
+        st.wait_stream(self.main)  # num / den were produced on the caller's stream
+        with torch.cuda.stream(st):
+            keep_den, keep_num = den.clone(), num.clone()  # both are overwritten in place; the copies serve the fallback
+            ops.solve_spd_right_(num, ops.cholesky_(den, status=self.status[i:i + 1]))
+        for t in (num, den, keep_den, keep_num):
+            t.record_stream(st)
+        self.jobs.append((what, num, keep_den, keep_num))
+        return num
+
+    def finish(self, out):
+        for st in self.streams:
+            self.main.wait_stream(st)
+        if not self.jobs:
+            return
+        verdict = self.status[:len(self.jobs)].tolist()  # ONE synchronisation for all solves
+        for (what, num, keep_den, keep_num), bad in zip(self.jobs, verdict):
+            if bad:
+                import warnings
+                warnings.warn("regmean: the Gram sum of %s is not positive definite (pivot %d); using a general inverse like "
+                              "the reference's torch.inverse" % (what, bad - 1))
+                inv = torch.linalg.inv(keep_den).contiguous()
+                out[what] = ops.gemm_f64(keep_num, inv, torch.empty_like(num))
+        self.jobs = []
+
+
 def _solve(num, den, what):
-    """W* = num @ inverse(den) (:432-434), float64, on the device.  The sum of a*G + (1-a)*diag(G) over SPD Gram matrices is
-    SPD, so the product path is a blocked Cholesky factorisation + two triangular solves.  A Gram sum that is rank-deficient
-    or numerically indefinite (few capture batches: fewer rows than columns for fc2, scaling_for_non_diag = 1) has no
-    Cholesky factor, while the reference's LU-based torch.inverse still returns a result: that case falls back, loudly, to a
-    general float64 inverse on the device (torch.linalg.inv = hipSOLVER) followed by the MFMA-f64 product."""
-    keep = den.clone()  # cholesky_ works in place
-    try:
-        return ops.solve_spd_right_(num, ops.cholesky_(den))
-    except L.VlmError as e:
-        if "positive definite" not in str(e):
-            raise
-        import warnings
-        warnings.warn("regmean: the Gram sum of %s is not positive definite (%s); using a general inverse like the "
-                      "reference's torch.inverse" % (what, e))
-        inv = torch.linalg.inv(keep).contiguous()
-        return ops.gemm_f64(num, inv, torch.empty_like(num))
+    """One W* = num @ inverse(den) with the same SPD-or-fallback rule (a single-job _Solves; tests and one-off callers)."""
+    out = {}
+    s = _Solves(num.device)
+    res = s.submit(num, den, what)
+    s.finish(out)
+    return out.get(what, res)
 
 
 def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None):
@@ -47,6 +86,7 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
     alpha = config["scaling_for_non_diag"]
     plan = M.MergePlan(device)
     dev = plan.device
+    solves = _Solves(dev)
     for i in range(M.NUM_MERGE_LAYERS):
         mods = M.modalities_for_layer(config, i, honour_only_used=False)
         for src, dst in M._tensor_names(i):
@@ -81,7 +121,8 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
             elif num is None:
                 out[dst] = 0  # the reference's untouched accumulator (no modality had a gram; does not occur in practice)
             else:
-                out[dst] = _solve(num, den, dst)
+                out[dst] = solves.submit(num, den, dst)
+    solves.finish(out)
     if plan.jobs:
         plan.run()
     if plan_out is not None:

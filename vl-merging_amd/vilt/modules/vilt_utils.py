@@ -295,6 +295,7 @@ class FusedAdamW:
             ops.cast_bf16(f.flat_p[:f.numel], f.flat_b[:f.numel])
         f.refresh_transposed()  # W^T shadows of the block weights (one batched launch)
         f.dirty = False  # the kernel refreshed the bf16 shadows
+        f.version += 1   # derived tables cached on the parameters' contents (engine.RelPos.dense_for) are stale now
 
 
 class LambdaSchedule:
