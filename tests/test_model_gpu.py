@@ -721,7 +721,9 @@ def test_infer_with_precomputed_image_embeds(mods, golden_dir):
         emb, masks, _, _ = model.transformer.visual_embed(batch["image"][0], max_image_len=model.hparams.config["max_image_len"])
         got = model.infer(batch, image_embeds=emb, image_masks=masks)
         for k in ("text_feats", "image_feats", "cls_feats", "raw_cls_feats"):
-            assert torch.equal(got[k], want[k]), k
+            # not bit-equal: the pass that embeds the image adds (conv bias + token type) in the patch-embed GEMM's epilogue
+            # (engine.pass_rows), visual_embed's output gets the token type added afterwards -- one fp32 rounding apart
+            feat_close(got[k], want[k].float().cpu(), "precomputed embeds " + k, tol=5e-3)
         assert got["image"] is None and got["image_labels"] is None and got["patch_index"] is None
         m2 = masks.clone()
         m2[:, -20:] = 0

@@ -911,3 +911,66 @@ class _PatchEmbedFn(torch.autograd.Function):
 
 def patch_embed(image, weight, bias, patch):
     return _PatchEmbedFn.apply(image, weight, bias, patch)
+
+
+class _PassRowsFn(torch.autograd.Function):
+    """The token matrix a pass starts from, x = [text rows ; image rows] (segment-major, fp32), with the image side of
+    visual_embed fused into the patch-embed GEMM (reference vision_transformer.py:952-991 + vilt_module.py:1111-1117):
+        image row (b, 0)     = cls_token + token_type[idx]
+        image row (b, 1 + p) = conv(patch p) + conv_bias + token_type[idx]
+    The GEMM writes its rows straight into x with (conv_bias + token_type[idx]) as its bias; B lead rows are then overwritten
+    with the cls row.  Replaces three passes over the [B * rows, D] fp32 image rows (the cls concat, the token-type add, the
+    text / image concat) and, backward, the column sum over all image rows for the token-type gradient plus the slice copies.
+    Gradients: conv weight through the wgrad GEMM (in place into .grad), conv bias += colsum over the patch rows, token_type[idx]
+    = that colsum + the lead rows' sum, cls_token = the lead rows' sum; the text rows' gradient is the matching slice of dx."""
+
+    @staticmethod
+    def forward(ctx, trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch):
+        B, C, Hh, Ww = image.shape
+        Dm = weight.shape[0]
+        rows = 1 + (Hh // patch) * (Ww // patch)
+        K = C * patch * patch
+        nt = 0 if trows is None else trows.shape[0]
+        dev = image.device
+        x = torch.empty(nt + B * rows, Dm, device=dev, dtype=F32)
+        if nt:
+            x[:nt].copy_(trows)
+        cols = torch.empty(B * rows, K, device=dev, dtype=BF16)
+        ops.patch_im2col(image.contiguous().float(), cols, patch, 1)
+        tt = tt_weight.detach()[tt_idx].float()
+        ops.gemm(cols, w16(weight).view(Dm, K), x[nt:], bias=(bias.detach().float() + tt).contiguous())
+        x[nt:].view(B, rows, Dm)[:, 0] = cls_token.detach().reshape(Dm).float() + tt
+        ctx.save_for_backward(cols)
+        ctx.weight, ctx.bias, ctx.geom = weight, bias, (B, rows, Dm, nt, tt_idx)
+        ctx.cls_shape, ctx.tt_shape = cls_token.shape, tt_weight.shape
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        (cols,) = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        B, rows, Dm, nt, tt_idx = ctx.geom
+        g = gx[nt:]
+        lead = g.view(B, rows, Dm)[:, 0].float().sum(0)                     # d(cls row) = sum over the samples' lead rows
+        g16 = torch.empty(B * rows, Dm, device=g.device, dtype=BF16)
+        g16.copy_(g)
+        g16.view(B, rows, Dm)[:, 0].zero_()                                 # lead rows carry no patch
+        touch(weight if weight.requires_grad else None, bias if bias is not None and bias.requires_grad else None)
+        if weight.requires_grad:
+            ops.gemm(g16, cols, weight.grad.view(Dm, -1), ta=True, tb=True, accumulate=True)
+        csum = torch.zeros(Dm, device=g.device, dtype=F32)
+        ops.colsum(g16, csum)                                               # sum over the patch rows (= d conv_bias)
+        if bias is not None and bias.requires_grad:
+            bias.grad.add_(csum)
+        d_tt = None
+        if ctx.needs_input_grad[5]:
+            d_tt = torch.zeros(ctx.tt_shape, device=g.device, dtype=F32)
+            d_tt[tt_idx] = csum + lead
+        d_cls = lead.view(ctx.cls_shape) if ctx.needs_input_grad[4] else None
+        return (gx[:nt] if nt and ctx.needs_input_grad[0] else None), None, None, None, d_cls, d_tt, None, None
+
+
+def pass_rows(trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch):
+    """x = [trows ; image rows of `image`] for a pass (trows may be None: an image-only pass); see _PassRowsFn."""
+    return _PassRowsFn.apply(trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch)
+

@@ -346,6 +346,17 @@ class ViLTransformerSS(nn.Module):
         x = x + self.token_type_embeddings.weight[image_token_type_idx]
         return x.reshape(-1, x.shape[-1]), x_mask, x.shape[1]
 
+    def _pass_rows(self, trows, img, image_token_type_idx=1):
+        """x = [text rows ; image rows] of a pass with the image side of visual_embed fused into the patch-embed GEMM
+        (engine.pass_rows).  -> (x, image mask of ones [B, I], I)."""
+        tr = self.transformer
+        pe = tr.patch_embed
+        x = engine.pass_rows(trows, img, pe.proj.weight, pe.proj.bias, tr.cls_token, self.token_type_embeddings.weight,
+                             image_token_type_idx, pe.patch_size[0])
+        I = 1 + pe.num_patches if img.shape[-1] == pe.img_size[1] and img.shape[-2] == pe.img_size[0] \
+            else 1 + (img.shape[-2] // pe.patch_size[0]) * (img.shape[-1] // pe.patch_size[1])
+        return x, torch.ones(img.shape[0], I, device=img.device), I
+
     def _final_norm(self, x):
         n = self.transformer.norm
         return engine.layer_norm(x, n.weight, n.bias, n.eps)
@@ -400,11 +411,15 @@ class ViLTransformerSS(nn.Module):
             xi = image_embeds + self.token_type_embeddings.weight[image_token_type_idx]
             irows, I = xi.reshape(-1, xi.shape[-1]), xi.shape[1]
             keep1 = image_masks.to(torch.uint8).contiguous()
-        else:
+            x = torch.cat([trows, irows], 0)
+        elif mask_image:
             img = batch[imgkey][0]
             irows, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+            x = torch.cat([trows, irows], 0)
+        else:
+            img = batch[imgkey][0]
+            x, image_masks, I = self._pass_rows(trows, img, image_token_type_idx)
         image_masks = image_masks.type_as(text_masks)
-        x = torch.cat([trows, irows], 0)
         index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
             else self.text_imag_relative_position_index
         pc = self._pass_ctx(ops.Seq(B, T, I), self.hparams.config["num_heads"], self.get_rel_pos_bias(index, T),
@@ -472,7 +487,11 @@ class ViLTransformerSS(nn.Module):
         img = batch[imgkey][0]
         B, T = text_ids.shape
         trows = self._text_rows(text_ids, text_masks)
-        irows, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+        if mask_image:
+            irows, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+            x = torch.cat([trows, irows], 0)
+        else:
+            x, image_masks, I = self._pass_rows(trows, img, image_token_type_idx)
         image_masks = image_masks.type_as(text_masks)
         index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
             else self.text_imag_relative_position_index
@@ -480,7 +499,6 @@ class ViLTransformerSS(nn.Module):
                             keep0=text_masks.to(torch.uint8).contiguous())
         pc.independent_segments = True
         pc.plan_drop_path(self._drop_sites(with_vlffn))
-        x = torch.cat([trows, irows], 0)
         hs = None
         for i, blk in enumerate(self.transformer.blocks):
             x = blk.run(x, pc, 3, self._hook())
@@ -530,7 +548,10 @@ class ViLTransformerSS(nn.Module):
         text_masks = batch["text_masks"]
         img = batch[imgkey][0]
         B = img.shape[0]
-        x, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+        if mask_image:
+            x, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
+        else:
+            x, image_masks, I = self._pass_rows(None, img, image_token_type_idx)
         image_masks = image_masks.type_as(text_masks)
         pc = self._pass_ctx(ops.Seq(B, 0, I), self.hparams.config["num_heads"],
                             self.get_rel_pos_bias(self.relative_position_index, 0))
