@@ -1,19 +1,27 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace stats + three separate PMC passes over the SAME bench command, condensed into
 # gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: tools/profile_round.sh r02
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate"
+CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- $CMD > $OUT/trace.log 2>&1
-PMC="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calibrate --no-gemm-timer"
+PMC="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calibrate --no-gemm-timer --no-secondary"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o run -- $PMC > $OUT/pmc_mfma.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o run -- $PMC > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- $PMC > $OUT/pmc_write.log 2>&1
+# configs[2] on one GPU (all_moe: grouped expert GEMMs) and the fp64 leg (RegMean + Gram capture), kernel traces only
+MOE="python3 $ROOT/bench.py --arch all_moe --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary --no-merge"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_moe -o run -- $MOE > $OUT/trace_moe.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f64 -o run -- python3 $ROOT/tools/bench_f64_leg.py > $OUT/trace_f64.log 2>&1
 cd $ROOT
-python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate under rocprofv3 --kernel-trace --stats; 6 steps + merge bench"
+python3 tools/prof_summary.py $OUT/trace_moe/run_kernel_stats.csv $OUT/${TAG}_train_all_moe384_b22_kernel_stats.csv "bench.py --arch all_moe --steps 4 --warmup 2 --no-secondary --no-merge under rocprofv3 --kernel-trace --stats; 6 steps"
+python3 tools/prof_summary.py $OUT/trace_f64/run_kernel_stats.csv $OUT/${TAG}_f64_leg_kernel_stats.csv "tools/bench_f64_leg.py (RegMean at base size x2, Gram capture D = 768 / 3072 at 54 296 rows x4) under rocprofv3 --kernel-trace --stats"
+grep -E "^(regmean|gram capture)" $OUT/trace_f64.log > $OUT/${TAG}_f64_leg_log.txt
+grep -E '^\{"metric' $OUT/trace_moe.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_all_moe_under_trace.txt
+python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps + merge bench"
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/traffic.txt
 python3 - <<PY
 import collections, csv, glob, json, re
@@ -30,5 +38,5 @@ for k, v in acc.items():
 json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 2 --warmup 1: busy cycles summed over the 1024 SIMDs / (1024 x per-XCD active cycles), time-weighted over all launches of a kernel", "kernels": res}, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
-tail -1 $OUT/trace.log | cut -c1-400 > $OUT/${TAG}_bench_line_under_trace.txt
+grep -E '^\{"metric' $OUT/trace.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_under_trace.txt
 head -25 $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv
