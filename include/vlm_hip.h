@@ -223,8 +223,8 @@ int vlm_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, uint64_
 int vlm_cast_f32_bf16(const float* src, void* dst_bf16, uint64_t n, void* stream);
 /* Backward of the word-embedding gather (HF BertEmbeddings.word_embeddings = nn.Embedding(vocab, D, padding_idx),
  * vilt_module.py:63, :1090; what torch's embedding_dense_backward + grad accumulation compute):
- * dW[ids[t], 0..D) += gy[t, 0..D) for every t in [0, n) with ids[t] != padding_idx (pass -1 for none).  ids are int64 and
- * must lie in [0, vocab); dW is ACCUMULATED (float atomics: the sum order of tokens sharing an id is not fixed). */
+ * dW[ids[t], 0..D) += gy[t, 0..D) for every t in [0, n) with ids[t] != padding_idx (pass -1 for none).  ids are int64; a token
+ * whose id lies outside [0, vocab) is skipped (nothing is written out of bounds); dW is ACCUMULATED (float atomics: the sum order of tokens sharing an id is not fixed). */
 int vlm_embedding_bwd(const float* gy, int ld, const int64_t* ids, int64_t n, int D, int64_t padding_idx, float* dW, int ld_w,
                       int64_t vocab, void* stream);
 /* Transposed bf16 weight shadows.  The backward of F.linear (dX = dY . W, modules/vision_transformer.py:291/:295/:335/

@@ -93,3 +93,46 @@ def test_shard_schema_and_model_consumes_batch_keys(tmp_path):
     t = pa.ipc.open_file(pa.memory_map(os.path.join(str(tmp_path), "vg.arrow"), "r")).read_all()
     assert t.schema.names == ["image", "caption", "image_id", "split"]
     assert t.schema.field("image").type == pa.binary() and t.schema.field("caption").type == pa.list_(pa.string())
+
+
+def test_prefetch_thread_yields_the_same_batches_in_order(pkg, tmp_path, monkeypatch):
+    """ArrowBatches.train_epoch with the decode + collate of the next batches on a worker thread (default) against the
+    synchronous path: same samples in the same batches, a resumed epoch skips the same ones, an abandoned generator releases its
+    worker, a decoding error surfaces in the consumer."""
+    import importlib
+    import threading
+    import time
+    ds = importlib.import_module("vl_merging_amd.vilt.datasets")
+    dm = importlib.import_module("vl_merging_amd.vilt.datamodules")
+    cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
+    d = str(tmp_path / "data")
+    ds.write_synthetic_shard(os.path.join(d, "synthetic_0.arrow"), 9, 2, image_hw=(40, 48), seed=1)
+    ds.build_synthetic_tokenizer(os.path.join(d, "vocab.txt"))
+    cfg = cfgmod.parse_cli(["task_test_vit_tiny_mlm_itm_ifm_square_randaug_base_vl", "ufo", "vocab_size=2048", "per_gpu_batchsize=2",
+                            "data_root=" + d])
+    data = dm.ArrowBatches(cfg, "train")
+
+    def order(depth, skip=0, stop_after=None):
+        monkeypatch.setenv("VLM_PREFETCH_BATCHES", str(depth))
+        out = []
+        for b in data.train_epoch(0, "cpu", skip=skip):
+            out.append(list(b["raw_index"]))
+            if stop_after and len(out) == stop_after:
+                break
+        return out
+
+    sync = order(0)
+    assert len(sync) == data.steps_per_epoch() and len(sync) >= 4
+    assert order(2) == sync and order(1) == sync
+    assert order(2, skip=2) == sync[2:]
+    n0 = threading.active_count()
+    assert order(2, stop_after=1) == sync[:1]
+    for _ in range(50):  # the abandoned generator's worker ends by itself
+        if threading.active_count() <= n0:
+            break
+        time.sleep(0.1)
+    assert threading.active_count() <= n0
+    monkeypatch.setattr(data.data, "collate", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("bad shard")))
+    import pytest as _pt
+    with _pt.raises(RuntimeError, match="bad shard"):
+        order(2)

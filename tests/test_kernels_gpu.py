@@ -576,6 +576,17 @@ def test_embedding_bwd_matches_torch(ops):
     ops.embedding_bwd(gy, ids, got, padding_idx=0)
     assert_close(got - 0.25, w.grad, 1e-5, 1e-4, "embedding backward")
     assert float((got[0] - 0.25).abs().max()) == 0.0  # the padding row receives nothing
+    # ids outside [0, vocab) are skipped, never written out of bounds (guard rows behind the table stay untouched)
+    table = torch.full((V + 4, D), 0.5, device="cuda")
+    bad = ids.clone()
+    bad[3::11] = V + 2
+    bad[4::13] = -5
+    ops.embedding_bwd(gy, bad, table[:V], padding_idx=0)
+    keep = (bad >= 0) & (bad < V)
+    w2 = torch.zeros(V, D, device="cuda", requires_grad=True)
+    torch.nn.functional.embedding(bad[keep], w2, padding_idx=0).backward(gy[keep])
+    assert_close(table[:V] - 0.5, w2.grad, 1e-5, 1e-4, "embedding backward with out-of-range ids")
+    assert float((table[V:] - 0.5).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("M,N,K,mode", [(13574, 3072, 768, 1), (13574, 3072, 768, 0), (880, 3072, 768, 1), (333, 1000, 128, 1)])

@@ -144,11 +144,12 @@ extern "C" int vlm_cast_f32_bf16(const float* src, void* dst, uint64_t n, void* 
 // step for 4 400 tokens); here one wave per token adds its row straight into the flat gradient buffer (float atomics on
 // 256-B segments: the full-rate shape).
 __global__ __launch_bounds__(EW_THREADS) void embedding_bwd_kernel(const float* __restrict__ gy, int ld, const int64_t* __restrict__ ids,
-                                                                   int64_t n, int D, int64_t pad, float* __restrict__ dW, int ld_w) {
+                                                                   int64_t n, int D, int64_t pad, float* __restrict__ dW, int ld_w,
+                                                                   int64_t vocab) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t t = (int64_t)blockIdx.x * (EW_THREADS / 64) + wave; t < n; t += (int64_t)gridDim.x * (EW_THREADS / 64)) {
     const int64_t id = ids[t];
-    if (id == pad) continue;  // wave-uniform
+    if (id == pad || id < 0 || id >= vocab) continue;  // wave-uniform; an id outside the table adds nowhere (never out of bounds)
     const float* src = gy + t * ld;
     float* dst = dW + id * ld_w;
     for (int c = lane; c < D; c += 64) atomicAdd(dst + c, src[c]);
@@ -162,7 +163,7 @@ extern "C" int vlm_embedding_bwd(const float* gy, int ld, const int64_t* ids, in
   int64_t blocks = (n + (EW_THREADS / 64) - 1) / (EW_THREADS / 64);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, gy, ld, ids, n, D,
-                     padding_idx, dW, ld_w);
+                     padding_idx, dW, ld_w, vocab);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

@@ -84,28 +84,93 @@ class ArrowBatches:
     def steps_per_epoch(self):
         return (len(self.data) // self.world) // self.B  # DistributedSampler(drop_last) then DataLoader(drop_last)
 
-    def _collate(self, idxs, device):
+    def _host_batch(self, idxs, pin=False):
+        """Decode + tokenise + collate on the host (the expensive part with real JPEG shards); `pin`: page-locked tensors,
+        so that the upload is an asynchronous DMA."""
         b = self.data.collate([self.data[i] for i in idxs], self.collator)
+        if pin:
+            pinned = lambda t: t.pin_memory() if t.numel() else t  # noqa: E731
+            for k, v in list(b.items()):
+                if torch.is_tensor(v):
+                    b[k] = pinned(v)
+                elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+                    b[k] = [pinned(t) for t in v]
+        return b
+
+    @staticmethod
+    def _upload(b, device, non_blocking=False):
         out = {}
         for k, v in b.items():
             if torch.is_tensor(v):
-                out[k] = v.to(device)
+                out[k] = v.to(device, non_blocking=non_blocking)
             elif isinstance(v, list) and v and torch.is_tensor(v[0]):
-                out[k] = [t.to(device) for t in v]
+                out[k] = [t.to(device, non_blocking=non_blocking) for t in v]
             else:
                 out[k] = v
         return out
 
+    def _collate(self, idxs, device):
+        return self._upload(self._host_batch(idxs), device)
+
+    def _prefetched(self, index_lists, device, depth):
+        """Batches of `index_lists` with decode + collate of batch t + 1 (and t + 2) running on a worker thread under step t,
+        into pinned host memory; the consumer only issues the asynchronous upload.  Same batches in the same order as the
+        synchronous path.  A consumer that stops early (steps= cap, exception) releases the worker."""
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=depth), threading.Event()
+        pin = torch.cuda.is_available() and str(device) != "cpu"
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def worker():
+            try:
+                for idxs in index_lists:
+                    if not put(("batch", self._host_batch(idxs, pin=pin))):
+                        return
+                put(("end", None))
+            except BaseException as e:  # surfaces in the training thread, at the batch it belongs to
+                put(("error", e))
+
+        th = threading.Thread(target=worker, name="vlm-batch-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                kind, item = q.get()
+                if kind == "end":
+                    return
+                if kind == "error":
+                    raise item
+                yield self._upload(item, device, non_blocking=pin)
+        finally:
+            stop.set()
+
     def train_epoch(self, epoch, device, skip=0):
         """DistributedSampler(shuffle=True, seed=0).set_epoch(epoch) semantics: one permutation per epoch shared by the
-        ranks, rank r takes elements r, r + W, ...; incomplete batches dropped.  `skip`: batches of this epoch a resumed
-        run has already consumed (passed over without decoding)."""
+        ranks, rank r takes elements r, r + W, ...; incomplete batches dropped (the reference's sampler PADS the
+        permutation to a multiple of the world size instead of dropping its tail, and seeds with 0: here the permutation is
+        seeded with cfg["seed"] + epoch -- a different but equally valid shuffle; what is pinned is the per-sample batch
+        contract, tests/test_batch_contract_cpu.py).  `skip`: batches of this epoch a resumed run has already consumed (passed over
+        without decoding).  Decode + collate of the next batches run on a worker thread (VLM_PREFETCH_BATCHES, default 2 ahead;
+        0: synchronous)."""
         g = torch.Generator().manual_seed(int(self.cfg["seed"]) + epoch)
         perm = torch.randperm(len(self.data), generator=g).tolist()
         per_rank = len(perm) // self.world
         mine = perm[self.rank: per_rank * self.world: self.world]
-        for lo in range(skip * self.B, len(mine) - self.B + 1, self.B):
-            yield self._collate(mine[lo: lo + self.B], device)
+        lists = [mine[lo: lo + self.B] for lo in range(skip * self.B, len(mine) - self.B + 1, self.B)]
+        depth = int(os.environ.get("VLM_PREFETCH_BATCHES", "2"))
+        if depth <= 0:
+            for idxs in lists:
+                yield self._collate(idxs, device)
+        else:
+            yield from self._prefetched(lists, device, depth)
 
     def eval_batches(self, device, all_ranks=False):
         """In order; batch j belongs to rank j % world unless `all_ranks` (retrieval preloads shard later by themselves)."""
