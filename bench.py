@@ -47,20 +47,40 @@ class GemmTimer:
         self.records = []
         self.on = False
 
+    def _bracket(self, fn, flop):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.records.append((e0, e1, flop))
+        return r
+
     def install(self):
+        orig, orig_g, orig_w = self.orig, self.ops.gemm_grouped, self.ops.gemm_wgrad_grouped
+
         def timed(a, b, out, ta=False, tb=False, **kw):
             if not self.on:
-                return self.orig(a, b, out, ta, tb, **kw)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = self.orig(a, b, out, ta, tb, **kw)
-            e1.record()
+                return orig(a, b, out, ta, tb, **kw)
             M, N = out.shape
             K = a.shape[0] if ta else a.shape[1]
-            self.records.append((e0, e1, 2.0 * M * N * K))
-            return r
+            return self._bracket(lambda: orig(a, b, out, ta, tb, **kw), 2.0 * M * N * K)
+
+        def timed_grouped(a, groups, out, **kw):  # all_moe: one launch over the experts' row ranges
+            if not self.on:
+                return orig_g(a, groups, out, **kw)
+            rows = sum(r1 - r0 for r0, r1, *_ in groups)
+            return self._bracket(lambda: orig_g(a, groups, out, **kw), 2.0 * rows * out.shape[1] * a.shape[1])
+
+        def timed_wgrad(dy, x, groups, **kw):
+            if not self.on:
+                return orig_w(dy, x, groups, **kw)
+            rows = sum(r1 - r0 for r0, r1, _ in groups)
+            return self._bracket(lambda: orig_w(dy, x, groups, **kw), 2.0 * rows * dy.shape[1] * x.shape[1])
+
         self.ops.gemm = timed
+        self.ops.gemm_grouped = timed_grouped
+        self.ops.gemm_wgrad_grouped = timed_wgrad
 
     def summary(self):
         if not self.records:
@@ -78,13 +98,13 @@ GEMM_HELPERS = ("splitk_reduce_kernel",)  # second launch of a wgrad call: its b
 
 def pmc_traffic(kernels, helpers=()):
     """HBM-side bytes per launch of a kernel (or, launch-weighted, of a family of kernels that serve the same call) from the
-    committed rocprofv3 --pmc passes over this same bench command (profiles/r03_pmc_traffic.json, made by
+    committed rocprofv3 --pmc passes over this same bench command (profiles/r04_pmc_traffic.json, made by
     tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950).
     Counters cannot be read from inside the timed process; None if the file is absent."""
     if isinstance(kernels, str):
         kernels = (kernels,)
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):  # the newest committed PMC passes
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC passes
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]
@@ -607,8 +627,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(GEMM_KERNELS, GEMM_HELPERS),
                                "traffic_unit": "HBM-side bytes per vlm_gemm_bf16 call, launch-weighted over the kernels "
-                                               "that serve it (rocprofv3 PMC, profiles/r03_pmc_traffic.json)",
-                               "kernel": "vlm_gemm_bf16: " + " / ".join(GEMM_KERNELS),
+                                               "that serve it (rocprofv3 PMC, profiles/r04_pmc_traffic.json)",
+                               "kernel": "vlm_gemm_bf16 (+ _grouped / vlm_gemm_wgrad_grouped for all_moe): " + " / ".join(GEMM_KERNELS),
                                "note": "peak = nominal dense bf16; a loop of nothing but independent MFMAs reaches 1515 "
                                        "TFLOP/s on this chip (clock drops to 1.45 GHz: DESIGN.md 4.1)",
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],

@@ -243,47 +243,53 @@ extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* stat
 // X (rows x nb, in place in Bm at column c0) <- X * op(L)^-1 with L the nb x nb lower-triangular block at L[l0][l0]:
 //   trans = 1:  X L^T = B  (forward over the block's columns: Cholesky panel, first RegMean solve)
 //   trans = 0:  X L   = B  (backward over the block's columns: second RegMean solve)
-// One thread per row of X, the row in registers (compile-time indices only: a runtime-indexed local array lives in scratch
-// memory -- the first version of this kernel took 200 us per launch that way), the triangle in LDS (broadcast reads), padded
-// with the identity for a ragged block.  Right-looking: once x_j is final every later column takes its update -- 63 - j
-// independent FMAs instead of one dependent chain.
-__global__ __launch_bounds__(64) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
-                                                        double* __restrict__ Bm, int ldb, int rows, int c0) {
+// One WAVE per row of X: lane j holds x_j (b_j on entry); step k broadcasts x_k = b_k / L[k][k] from lane k by v_readlane (lane
+// numbers are compile-time constants in the unrolled loop: scalar broadcasts) and every lane still to be solved takes its
+// update b_j -= x_k L[..] with its OWN element of column / row k of the triangle from LDS (stride-65 rows: conflict-free).  64 short
+// steps per row and 4 rows per workgroup instead of one thread grinding through 2 016 dependent FMAs per row: rows / 4
+// workgroups fill the chip, the row is read and written as one coalesced 512-B piece.  (History: a runtime-indexed `double v[64]`
+// per thread lived in scratch memory, 201 us per launch; fully unrolled in registers it was instruction-fetch bound, 62 us.)
+// A ragged block (nb < 64) is padded with the identity.
+__global__ __launch_bounds__(256) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
+                                                         double* __restrict__ Bm, int ldb, int rows, int c0) {
   __shared__ double s[64][65];
-  const int t = threadIdx.x;
-  for (int r = 0; r < 64; ++r) s[r][t] = (r < nb && t < nb) ? L[(size_t)(l0 + r) * ldl + l0 + t] : (r == t ? 1.0 : 0.0);
+  __shared__ double invd[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    s[r][c] = (r < nb && c < nb) ? L[(size_t)(l0 + r) * ldl + l0 + c] : (r == c ? 1.0 : 0.0);
+  }
   __syncthreads();
-  const int row = blockIdx.x * 64 + t;
-  if (row >= rows) return;
+  if (tid < 64) invd[tid] = 1.0 / s[tid][tid];
+  __syncthreads();
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= rows) return;  // wave-uniform
   double* x = Bm + (size_t)row * ldb + c0;
-  double v[64];
+  double b = lane < nb ? x[lane] : 0.0;
+  const double rd = invd[lane];
+  if (trans) {  // X L^T = B:  x_k = (b_k - sum_{j<k} x_j L[k][j]) / L[k][k];  after x_k: b_j -= x_k L[j][k] for j > k
 #pragma unroll
-  for (int j = 0; j < 64; ++j) v[j] = j < nb ? x[j] : 0.0;
-  if (trans) {  // X L^T = B:  x_j = (b_j - sum_{k<j} x_k L[j][k]) / L[j][j]
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      v[j] = v[j] / s[j][j];
-#pragma unroll
-      for (int k = j + 1; k < 64; ++k) v[k] -= v[j] * s[k][j];
+    for (int k = 0; k < 64; ++k) {
+      const double xk = f64_readlane(b, k) * f64_readlane(rd, k);
+      const double ljk = s[lane][k];
+      b = lane == k ? xk : (lane > k ? __builtin_fma(-xk, ljk, b) : b);
     }
-  } else {      // X L = B:    x_j = (b_j - sum_{k>j} x_k L[k][j]) / L[j][j]
+  } else {      // X L = B:    x_k = (b_k - sum_{j>k} x_j L[j][k]) / L[k][k];  after x_k: b_j -= x_k L[k][j] for j < k
 #pragma unroll
-    for (int j = 63; j >= 0; --j) {
-      v[j] = v[j] / s[j][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v[k] -= v[j] * s[j][k];
+    for (int k = 63; k >= 0; --k) {
+      const double xk = f64_readlane(b, k) * f64_readlane(rd, k);
+      const double lkj = s[k][lane];
+      b = lane == k ? xk : (lane < k ? __builtin_fma(-xk, lkj, b) : b);
     }
   }
-#pragma unroll
-  for (int j = 0; j < 64; ++j)
-    if (j < nb) x[j] = v[j];
+  if (lane < nb) x[lane] = b;
 }
 
 extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* Bm, int ldb, int rows, int c0,
                                   void* stream) {
   if (nb == 0 || rows == 0) return VLM_OK;
   if (!L || !Bm || nb < 0 || nb > 64 || rows < 0 || l0 < 0 || c0 < 0) return VLM_ERR_ARG;
-  hipLaunchKernelGGL(trsm_block_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, L, ldl, l0, nb, trans, Bm, ldb,
+  hipLaunchKernelGGL(trsm_block_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, L, ldl, l0, nb, trans, Bm, ldb,
                      rows, c0);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
