@@ -209,6 +209,19 @@ int vlm_layerscale_bwd(const float* dx, int lddx, const void* y_bf16, int ldy, c
 int vlm_colsum_bf16(const void* a, int lda, int M, int N, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Cross-entropy of the MLM head (modules/objectives.py:88-143: F.cross_entropy(mlm_logits.view(-1, vocab), mlm_labels.view(-1),
+ * ignore_index=-100)) on the bf16 logits [rows, ld] the decoder GEMM wrote (V valid columns, ld % 8 == 0), fp32 arithmetic:
+ *   fwd: lse[r] = logsumexp(logits[r, :V]);  loss_rows[r] = lse[r] - logits[r, labels[r]], or 0 where labels[r] == ignore_index
+ *        (the caller forms the mean over the rows that count);
+ *   bwd: dlogits[r, c] = scale_dev[0] * (exp(logits[r, c] - lse[r]) - [c == labels[r]]) as bf16 for c < V, 0 for V <= c < ld_d
+ *        and in ignored rows: written whole, padding included, so the buffer is the decoder dgrad / wgrad GEMMs' operand as it
+ *        stands.  scale_dev: device scalar (upstream gradient / number of counted rows), no host round trip. */
+int vlm_cross_entropy_fwd(const void* logits_bf16, int ld, int rows, int V, const int64_t* labels, int64_t ignore_index,
+                          float* loss_rows, float* lse, void* stream);
+int vlm_cross_entropy_bwd(const void* logits_bf16, int ld, int rows, int V, const int64_t* labels, int64_t ignore_index,
+                          const float* lse, const float* scale_dev, void* dlogits_bf16, int ld_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Flat-buffer elementwise kernels.
  * vlm_adamw_step: transformers-4.x AdamW as instantiated at modules/vilt_utils.py:314-317
  *   (betas=(0.9, beta_2), eps=1e-8, bias-corrected step_size computed by the caller, decoupled decay applied

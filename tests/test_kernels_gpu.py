@@ -769,3 +769,49 @@ def test_gemm_wgrad_grouped(ops, L, big_tile, rows, M, N, accumulate):
             one = b.clone()
             ops.gemm(dy[r0:r1], x[r0:r1], one, ta=True, tb=True, accumulate=accumulate)
             assert_close(g, one, 1e-3, tol, "grouped vs plain wgrad rows %d:%d" % (r0, r1))
+
+
+@pytest.mark.parametrize("rows,V,frac_ignored", [(880, 30522, 0.8), (37, 1024, 0.5), (5, 30522, 1.0), (64, 777, 0.0)])
+def test_cross_entropy_matches_torch(pkg, ops, rows, V, frac_ignored):
+    """vlm_cross_entropy_fwd / _bwd (the MLM head's loss, objectives.py:88-143) against F.cross_entropy on the fp32 upcast of the same
+    bf16 logits: loss, the gradient (as the zero-padded bf16 matrix the decoder GEMMs take), ignore_index rows, a vocabulary that is
+    not a multiple of 8, every row ignored (nan, like torch)."""
+    engine = importlib.import_module("vl_merging_amd.engine")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(rows + V)
+    Vp = (V + 63) // 64 * 64
+    buf = torch.full((rows, Vp), 9.0, device="cuda", dtype=torch.bfloat16)  # what the decoder GEMM leaves: garbage in the padding
+    buf[:, :V] = (torch.randn(rows, V, device="cuda", generator=gen) * 3).to(torch.bfloat16)
+    logits = buf[:, :V].detach().requires_grad_(True)
+    labels = torch.randint(0, V, (rows,), device="cuda", generator=gen)
+    labels[torch.rand(rows, device="cuda", generator=gen) < frac_ignored] = -100
+    if frac_ignored == 1.0:
+        labels[:] = -100
+    loss = engine.cross_entropy(logits, labels, ignore_index=-100)
+    ref_in = logits.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, labels, ignore_index=-100)
+    if frac_ignored == 1.0:
+        assert torch.isnan(loss) and torch.isnan(ref)
+        return
+    assert abs(float(loss) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    (loss * 1.7).backward()
+    (ref * 1.7).backward()
+    g = logits.grad
+    assert g.dtype == torch.bfloat16
+    assert_close(g, ref_in.grad, 1e-2, 1e-7, "cross-entropy gradient")
+    assert float(g[labels == -100].abs().max() if (labels == -100).any() else 0.0) == 0.0
+
+
+def test_l2_normalize_matches_autograd(pkg):
+    engine = importlib.import_module("vl_merging_amd.engine")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    x = torch.randn(22, 768, device="cuda", generator=gen).to(torch.bfloat16)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya = engine.l2_normalize(a)
+    bf = b.float()
+    yb = bf / bf.norm(dim=-1, keepdim=True)
+    w = torch.randn(22, 768, device="cuda", generator=gen)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    assert_close(ya, yb, 1e-6, 1e-7, "l2 forward")
+    assert_close(a.grad, b.grad, 1e-2, 1e-4, "l2 backward")

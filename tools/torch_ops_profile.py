@@ -1,6 +1,7 @@
 """Which torch ops (not our HIP kernels) run inside a training step, by device time: torch.profiler over 2 steps of the
 bench workload.  python tools/torch_ops_profile.py [arch]"""
 import importlib
+import os
 import sys
 
 import torch
@@ -45,8 +46,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
         step()
     torch.cuda.synchronize()
 ev = prof.key_averages(group_by_input_shape=True)
-ev = [e for e in ev if e.key.startswith("aten::")]
-rows = sorted(ev, key=lambda e: -e.self_device_time_total)
+ev = [e for e in ev if e.key.startswith("aten::") and e.self_device_time_total > 0]
+rows = sorted(ev, key=lambda e: (-e.count if os.environ.get("VLM_PROFILE_BY_COUNT") else 0, -e.self_device_time_total))
 tot = sum(e.self_device_time_total for e in ev)
 print("total device time %.2f ms over 2 steps" % (tot / 1e3))
 import os

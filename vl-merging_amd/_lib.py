@@ -121,6 +121,9 @@ SIGNATURES = {
     "vlm_trsm_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vlm_cholesky_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vlm_solve_spd_right_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "vlm_cross_entropy_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
+    "vlm_cross_entropy_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_embedding_bwd": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int,
                                   ctypes.c_int64, c_void_p]),

@@ -771,14 +771,19 @@ class _LinearFn(torch.autograd.Function):
         x2, pre = ctx.saved_tensors
         weight, bias, N, Np = ctx.weight, ctx.bias, ctx.N, ctx.Np
         M, K = x2.shape
-        dy = torch.zeros(M, Np, device=x2.device, dtype=BF16)
         gy2 = gy.reshape(M, N)
-        if ctx.gelu:
-            hh = pre[:, :N].float().requires_grad_(True)
-            with torch.enable_grad():
-                act = torch.nn.functional.gelu(hh)
-            gy2 = torch.autograd.grad(act, hh, gy2.float())[0]
-        dy[:, :N].copy_(gy2)
+        if (not ctx.gelu and gy2.dtype == BF16 and gy2.stride() == (Np, 1) and gy2.storage_offset() == 0
+                and _PADDED_GRADS.pop(gy2.data_ptr(), None) == (M, Np)):
+            # the fused cross-entropy's gradient: already the zero-padded bf16 [M, Np] operand (registered by _CrossEntropyFn)
+            dy = torch.as_strided(gy2, (M, Np), (Np, 1))
+        else:
+            dy = torch.zeros(M, Np, device=x2.device, dtype=BF16)
+            if ctx.gelu:
+                hh = pre[:, :N].float().requires_grad_(True)
+                with torch.enable_grad():
+                    act = torch.nn.functional.gelu(hh)
+                gy2 = torch.autograd.grad(act, hh, gy2.float())[0]
+            dy[:, :N].copy_(gy2)
         touch(weight if weight.requires_grad else None, bias if bias is not None and bias.requires_grad else None)
         if bias is not None and bias.requires_grad:
             if N % 8 == 0:
@@ -807,6 +812,72 @@ class _LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, gelu=False):
     return _LinearFn.apply(x, weight, bias, gelu)
+
+
+class _L2NormFn(torch.autograd.Function):
+    """y = x / ||x||_2 over the last dim in fp32 (the contrastive heads' feature normalisation, objectives.py:248-300): two kernels
+    forward and four backward -- dx = (g - y (g . y)) / ||x|| -- instead of the dozen autograd derives for x / x.norm(...)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        n = x.norm(dim=-1, keepdim=True)
+        y = x / n
+        ctx.save_for_backward(y, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, n = ctx.saved_tensors
+        g = g.float()
+        t = (g * y).sum(-1, keepdim=True)
+        return torch.addcmul(g, y, t, value=-1.0).div_(n)
+
+
+_FUSED_LOSS = os.environ.get("VLM_FUSED_LOSS", "1") != "0"  # A/B switch: 0 = torch's cross_entropy / x / x.norm() graphs
+
+
+def l2_normalize(x):
+    if not _FUSED_LOSS:
+        x = x.float()
+        return x / x.norm(dim=-1, keepdim=True)
+    return _L2NormFn.apply(x)
+
+
+_PADDED_GRADS = {}  # data_ptr -> (rows, padded columns) of gradient buffers born zero-padded (consumed once by _LinearFn.backward)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """mean-reduced F.cross_entropy(logits, labels, ignore_index) on bf16 logits [rows, V] as they leave the decoder GEMM
+    (objectives.py:88-143), through the two row kernels of csrc/lossops.hip: no fp32 copy of the [880, 30 522] logits, and the
+    gradient is born as the padded bf16 matrix the decoder's dgrad / wgrad GEMMs read (_LinearFn.backward takes it as is)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        loss_rows, lse = ops.cross_entropy_fwd(logits, labels, ignore_index)
+        count = (labels != ignore_index).sum().to(F32)
+        ctx.save_for_backward(logits, labels, lse, count)
+        ctx.ignore_index = ignore_index
+        return loss_rows.sum() / count  # no counted row: 0 / 0 = nan, like F.cross_entropy
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse, count = ctx.saved_tensors
+        scale = (g.to(F32) / count).reshape(1)
+        d = ops.cross_entropy_bwd(logits, labels, lse, scale, ctx.ignore_index)
+        if len(_PADDED_GRADS) > 64:
+            _PADDED_GRADS.clear()  # entries nobody consumed (a caller that is not _LinearFn): never grow
+        _PADDED_GRADS[d.data_ptr()] = (d.shape[0], (d.shape[1] + 63) // 64 * 64)
+        return d, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """F.cross_entropy(logits.float(), labels, ignore_index=ignore_index) for 2-D bf16 CUDA logits whose rows are 16-B aligned (the
+    MLM head's); anything else goes to torch."""
+    if (_FUSED_LOSS and logits.is_cuda and logits.dtype == BF16 and logits.dim() == 2 and logits.stride(1) == 1 and logits.stride(0) % 8 == 0
+            and logits.data_ptr() % 16 == 0 and labels.dtype == torch.int64):
+        return _CrossEntropyFn.apply(logits, labels.contiguous(), ignore_index)
+    return torch.nn.functional.cross_entropy(logits.float(), labels, ignore_index=ignore_index)
 
 
 class _LayerNormFn(torch.autograd.Function):

@@ -275,6 +275,31 @@ def embedding_bwd(gy, ids, dW, padding_idx=-1):
     return dW
 
 
+def cross_entropy_fwd(logits, labels, ignore_index=-100):
+    """(loss_rows f32 [rows], lse f32 [rows]) of bf16 logits [rows, V] (row stride a multiple of 8), include/vlm_hip.h."""
+    L.require_cuda(logits, labels)
+    rows, V = logits.shape
+    if logits.dtype != BF16 or labels.dtype != torch.int64 or labels.numel() != rows or not labels.is_contiguous():
+        raise L.VlmError("cross_entropy: bf16 logits [rows, V], contiguous int64 labels [rows]")
+    loss_rows = torch.empty(rows, device=logits.device, dtype=F32)
+    lse = torch.empty(rows, device=logits.device, dtype=F32)
+    L.check(L.get_lib().vlm_cross_entropy_fwd(L.ptr(logits), _ld(logits), rows, V, L.ptr(labels), int(ignore_index), L.ptr(loss_rows),
+                                              L.ptr(lse), L.stream_ptr()), "vlm_cross_entropy_fwd")
+    return loss_rows, lse
+
+
+def cross_entropy_bwd(logits, labels, lse, scale, ignore_index=-100):
+    """dlogits (bf16 view [rows, V] of a zero-padded [rows, roundup(V, 64)] buffer) = scale[0] * (softmax - onehot), 0 in ignored
+    rows; `scale` is a device scalar."""
+    L.require_cuda(logits, labels, lse, scale)
+    rows, V = logits.shape
+    Vp = (V + 63) // 64 * 64
+    buf = torch.empty(rows, Vp, device=logits.device, dtype=BF16)
+    L.check(L.get_lib().vlm_cross_entropy_bwd(L.ptr(logits), _ld(logits), rows, V, L.ptr(labels), int(ignore_index), L.ptr(lse),
+                                              L.ptr(scale), L.ptr(buf), Vp, L.stream_ptr()), "vlm_cross_entropy_bwd")
+    return buf[:, :V]
+
+
 def colsum(a, out):
     """out[n] += sum_m a[m,n]  (a bf16)."""
     L.require_cuda(a, out)

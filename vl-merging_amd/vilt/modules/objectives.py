@@ -7,6 +7,8 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import engine
+
 
 _LOCAL_ONLY = [False]
 
@@ -57,8 +59,7 @@ def compute_mlm(pl_module, batch):
     infer = pl_module.infer(batch, mask_text=True, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"])
     mlm_labels = infer["text_labels"]
-    mlm_loss = F.cross_entropy(mlm_logits.float().view(-1, pl_module.hparams.config["vocab_size"]),
-                               mlm_labels.view(-1), ignore_index=-100)
+    mlm_loss = engine.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), ignore_index=-100)
     return {"mlm_loss": mlm_loss * pl_module.hparams.config["vl_mlm_weight"], "mlm_logits": mlm_logits,
             "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
 
@@ -197,8 +198,7 @@ def compute_mlm_itm_fused(pl_module, batch, sim_i2t, sim_t2i):
     infer = pl_module.infer(big, mask_text=False, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"][:bsz])
     mlm_labels = batch["text_labels_mlm"]
-    mlm_loss = F.cross_entropy(mlm_logits.float().view(-1, pl_module.hparams.config["vocab_size"]),
-                               mlm_labels.view(-1), ignore_index=-100)
+    mlm_loss = engine.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), ignore_index=-100)
     itm_labels = torch.cat([torch.ones(bsz, device=img.device), torch.zeros(2 * bsz, device=img.device)])
     itm_logits = pl_module.itm_score(infer["cls_feats"][bsz:])
     itm_loss = F.cross_entropy(itm_logits.float(), itm_labels.long())

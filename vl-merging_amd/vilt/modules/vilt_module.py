@@ -453,8 +453,7 @@ class ViLTransformerSS(nn.Module):
 
     @staticmethod
     def _l2(x):
-        x = x.float()
-        return x / x.norm(dim=-1, keepdim=True)
+        return engine.l2_normalize(x)
 
     def _infer_text(self, batch, mask_text, with_vlffn):
         self._ensure_engine()
