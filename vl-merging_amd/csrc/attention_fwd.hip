@@ -85,7 +85,7 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const attn_par
   // m = the value subtracted from this row's exponents so far (0 until a score exceeds 2^6, then a running maximum
   // rounded to fp16 so that it is exact in every format it passes through); negm = -m in all 16 registers, the C
   // operand of each score chain; lacc = row sums (every register holds this lane's query's sum)
-  float m = 0.f, lsum = 0.f;  // lsum: this lane's half (keys 4*hh + {0..3} mod 8) of its query's row sum
+  float m = 0.f;
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
@@ -181,7 +181,6 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const attn_par
         const float delta = m_new - m;  // exact: both are fp16 values
         const float alpha = att_exp2(-delta);
         m = m_new;
-        lsum *= alpha;
 #pragma unroll
         for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
 #pragma unroll
