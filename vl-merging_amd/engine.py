@@ -573,18 +573,19 @@ class _BlockFn(torch.autograd.Function):
                              act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h)
             ops.gemm_grouped(a, [(r0, r1, w16(e.fc2w), e.fc2b, None) for r0, r1, e in rg], x2, col_scale=plan.gamma2,
                              row_scale=rs2, residual=x1, aux=y2)
-        with _ExpertStreams(() if grouped else plan.ranges) as es:  # each expert's proj -> LayerNorm -> fc1 -> fc2 chain is independent
-            for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
-                with es.on(idx):
-                    ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
-                             row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
-                    ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
-                    # h = gelu'(pre-activation) (VLM_GELU_SAVE_DERIV, default): the forward epilogue has erf and exp in
-                    # hand anyway, and the fc2-dgrad epilogue of the backward pass becomes a multiplication
-                    ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b,
-                             act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h[r0:r1])
-                    ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
-                             row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
+        else:
+            with _ExpertStreams(plan.ranges) as es:  # each expert's proj -> LayerNorm -> fc1 -> fc2 chain is independent
+                for idx, (r0, r1, e) in enumerate(plan.ranges):
+                    with es.on(idx):
+                        ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
+                                 row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
+                        ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
+                        # h = gelu'(pre-activation) (VLM_GELU_SAVE_DERIV, default): the forward epilogue has erf and exp in
+                        # hand anyway, and the fc2-dgrad epilogue of the backward pass becomes a multiplication
+                        ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b,
+                                 act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h[r0:r1])
+                        ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
+                                 row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
         if pc.gram is not None:
             # Gram cache: the LayerNorm outputs enter in fp32 (re-computed here, capture runs are not timed), like the
             # fp32 activations the reference's hooks see; the attention output and the GELU output exist only as the bf16
@@ -665,8 +666,8 @@ class _BlockFn(torch.autograd.Function):
             ops.gemm_grouped(dy1, [(r0, r1, wT16(e.projw), None, None) for r0, r1, e in rg], do)
             with _Side(dy1, o):
                 ops.gemm_wgrad_grouped(dy1, o, [(r0, r1, e.projw.grad) for r0, r1, e in rg])
-        with _ExpertStreams(() if grouped else plan.ranges) as es:
-            for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
+        with _ExpertStreams(plan.ranges) as es:  # (grouped: nothing left for the per-expert chains -- no side stream either)
+            for idx, (r0, r1, e) in enumerate(plan.ranges if not grouped else ()):
                 rr = slice(r0, r1)
                 with es.on(idx):
                     ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad,
@@ -714,8 +715,8 @@ class _BlockFn(torch.autograd.Function):
                 rr = slice(r0, r1)
                 ops.layernorm_bwd(dln1[rr], x[rr], st1[rr], e.n1w, dx[rr], dres=dx1[rr], dgamma=e.n1w.grad,
                                   dbeta=e.n1b.grad, fold=fold)
-        with _ExpertStreams(() if grouped else plan.ranges) as es:
-            for idx, (r0, r1, e) in enumerate(() if grouped else plan.ranges):
+        with _ExpertStreams(plan.ranges) as es:
+            for idx, (r0, r1, e) in enumerate(plan.ranges if not grouped else ()):
                 rr = slice(r0, r1)
                 with es.on(idx):
                     if e.qb is not None and not fused_qv:
