@@ -134,13 +134,14 @@ class FlatParams:
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# weight-gradient side stream: wgrad GEMMs (reduction over tokens, only 100-150 output tiles) are off the critical
-# path of backward and under-fill 256 CUs on their own; they run on a second HIP stream so the hardware co-schedules
-# them with the dgrad / attention kernels of the main stream.  The main stream re-joins at the end of backward.
-# Off by default: +1.0 % on one GPU (241 -> 243.4 samples/s), but the gradient all-reduce of a block then also waits for
-# the side stream, and two ranks time-sharing ONE GPU over gloo (the only multi-rank run available this round) fell to
-# 9 s per step with it on; not enabled until it is measured on a real multi-GPU node (VLM_WGRAD_STREAM=1).
-_WGRAD = {"stream": None, "enabled": os.environ.get("VLM_WGRAD_STREAM", "0") != "0", "pending": False}
+# weight-gradient side stream: wgrad GEMMs (a reduction over tokens into a small output: exactly one round of workgroups) are off
+# the critical path of backward; issued on a second HIP stream the hardware co-schedules them with the dgrad / attention / row
+# kernels of the main stream, whose last partial rounds leave CUs idle -- the more the smaller the pass: A/B on one box each,
+# configs[4] (irtr, B = 20: M = 12 340 rows, 147 tiles of the N = 768 GEMMs on 256 CUs) 16.49 -> 15.58 ms per step (+5.8 %),
+# configs[1] (ufo, B = 22) 71.59 -> 70.88 ms (+1.0 %).  The main stream re-joins at the end of backward (and the optimizer and
+# every gradient bucket's collective wait for the side stream).  Default on since round 4 (the two-rank tests run with it);
+# VLM_WGRAD_STREAM=0 keeps every wgrad on the main stream.
+_WGRAD = {"stream": None, "enabled": os.environ.get("VLM_WGRAD_STREAM", "1") != "0", "pending": False}
 
 
 def wgrad_stream():
