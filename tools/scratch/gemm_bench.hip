@@ -14,9 +14,10 @@ extern "C" int vlm_device_cus(void) { return 256; }
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
   // variant: 0 plain bf16, 1 bias + GELU + pre-activation copy (fc1 fwd), 2 GELU' + column sums (fc2 dgrad),
+  //          5 GELU' factor saved by the forward pass (MUL_AUX) + column sums (fc2 dgrad as the engine runs it),
   //          3 f32 residual stream: bias, gamma, row scale, residual in place, branch copy (proj / fc2 fwd), 4 plain f32
   const int variant = argc > 4 ? atoi(argv[4]) : 0;
-  const int f32 = variant >= 3;
+  const int f32 = variant == 3 || variant == 4;
   std::vector<uint16_t> h((size_t)(M > N ? M : N) * K);
   uint32_t s = 12345;
   for (auto& v : h) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; uint32_t u; memcpy(&u, &f, 4); v = u >> 16; }
@@ -32,6 +33,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&ws, (size_t)(M / 128 + 2) * 2 * N * 4));
   if (variant == 1) { e.bias = vec; e.act = VLM_ACT_GELU; e.aux = aux; e.ld_aux = N; }
   if (variant == 2) { e.act = VLM_ACT_GELU_BWD; e.aux = aux; e.ld_aux = N; e.col_sum = vec + N; e.col_sum_ws = ws; }
+  if (variant == 5) { e.act = VLM_ACT_MUL_AUX; e.aux = aux; e.ld_aux = N; e.col_sum = vec + N; e.col_sum_ws = ws; }  // fc2 dgrad with the saved GELU' factor
   if (variant == 3) { e.bias = vec; e.col_scale = vec + 2 * N; e.row_scale = vec + 4 * N; e.residual = (float*)nullptr; e.aux = aux; e.ld_aux = N; }
   if (variant == 3) { e.residual = (const float*)C; e.ld_res = N; }
   setenv("VLM_GEMM_BIG", "2", 1);
@@ -60,13 +62,26 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> hs((size_t)wgs * 8);
     CK(hipMemcpy(hs.data(), st, (size_t)wgs * 64, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0, tot = 0, real = 0;
-    for (int w = 0; w < wgs; ++w) {
+    int live = 0;
+    for (int w = 0; w < wgs; ++w) live += hs[(size_t)w * 8 + 3] != 0;  // a persistent launch has fewer workgroups than tiles
+    for (int w = 0; w < live; ++w) {
       const unsigned long long* q = &hs[(size_t)w * 8];
       pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); tot += (double)(q[3] - q[0]);
       real += (double)(q[5] - q[4]);
     }
+    {
+      double bnd = 0, epi_issue = 0; int nb = 0;
+      int live = 0;
+      for (int w = 0; w < wgs; ++w) live += hs[(size_t)w * 8 + 3] != 0;
+      for (int w = 0; w < live; ++w) {
+        const unsigned long long* q = &hs[(size_t)w * 8];
+        if (q[6] && q[1] > q[6]) { bnd += (double)(q[1] - q[6]); ++nb; }
+        epi_issue += (double)(q[7] - q[2]);
+      }
+      printf("persistent: tile boundary (end of a tile's epilogue -> next tile's fragments read) %.0f over %d workgroups; epilogue issue (no drain) %.0f\n", nb ? bnd / nb : 0.0, nb, epi_issue / live);
+    }
     printf("stamps (avg per workgroup, s_memtime ticks): prologue %.0f  loop %.0f (%.0f per 32-deep step)  epilogue %.0f  total %.0f ; s_memrealtime ticks %.0f -> memtime/realtime = %.3f\n",
-           pro / wgs, loop / wgs, loop / wgs / (K / 32.0), epi / wgs, tot / wgs, real / wgs, tot / real);
+           pro / live, loop / live, loop / live / (K / 32.0), epi / live, tot / live, real / live, tot / real);
   }
 #endif
   return 0;

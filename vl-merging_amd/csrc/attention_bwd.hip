@@ -589,7 +589,18 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
       const_cast<_Float16*>(p.dense_t + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048), 0, (uint32_t)p.dense_tiles * 4096u, 0x00020000);
   att_bias_t bw;  // this wave's 32-query block (the same for every sample): bw.w[qw & 1]
   att_bias_load_half(bw, qw & 1, rbias, att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + kw, lane), (qp0 - sp.s_lo) / ATT_BK + (qw >> 1));
-  const u32x4 bw0 = bw.w[qw & 1][0], bw1 = bw.w[qw & 1][1];
+  // the tile's bias block is the same for every sample: the four selection MFMAs run ONCE, their result (bias / c1 in accumulator
+  // layout) is added to each sample's -lse / c1 on the vector pipe (16 v_add against 4 of 12 MFMAs per sample)
+  f32x16 bias_acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bias_acc[i] = 0.f;
+  {
+    const u32x4 bw0 = bw.w[qw & 1][0], bw1 = bw.w[qw & 1][1];
+    bias_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh0, __builtin_bit_cast(f16x8, bw0), bias_acc, 0, 0, 0);
+    bias_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh1, __builtin_bit_cast(f16x8, bw1), bias_acc, 0, 0, 0);
+    bias_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl0, __builtin_bit_cast(f16x8, bw0), bias_acc, 0, 0, 0);
+    bias_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl1, __builtin_bit_cast(f16x8, bw1), bias_acc, 0, 0, 0);
+  }
 
   // ---- LDS-DMA staging: wave w moves piece w (rows 8w .. 8w+7) of each of the four 128-row tiles ----------------------------
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
@@ -633,18 +644,28 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // The waits are BUILTINS, not inline asm: hipcc's wait-count pass cannot see into an asm statement, believed the bias
+  // loads above still pending inside the loop and put a counted vmcnt in front of their first use -- which, four or five
+  // LDS-DMA instructions later, waited for the NEXT sample's first tile.  The key-padding byte of a sample is requested one
+  // trip ahead and BEFORE that trip's DMA for the same reason (vmcnt counts in order: waiting for a load that is younger
+  // than the DMA drains the DMA).
+  auto keep_byte = [&](int b) -> uint32_t {
+    return (wave_keep && kvalid && keepk && b < b_hi) ? (uint32_t)keepk[(size_t)b * keep_n + keep_at] : 1u;
+  };
+  uint32_t keep_cur = keep_byte(b_lo);
   dma(b_lo, 0);
-  asm volatile("s_waitcnt vmcnt(0)\n s_barrier" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  asm volatile("s_barrier" ::: "memory");
   for (int b = b_lo; b < b_hi; ++b) {
     const int cur = (b - b_lo) & 1;
+    const uint32_t keep_next = keep_byte(b + 1);
     if (b + 1 < b_hi) dma(b + 1, cur ^ 1);  // that stage was last read in the previous trip (barrier below)
     const unsigned char* ldsK = smem + cur * STAGE;
     const unsigned char* ldsV = ldsK + 2 * ATT_TILE_BYTES;
     const unsigned char* ldsQ = ldsK + 4 * ATT_TILE_BYTES;
     const unsigned char* ldsO = ldsK + 6 * ATT_TILE_BYTES;
     const float* qstat = reinterpret_cast<const float*>(ldsK + 8 * ATT_TILE_BYTES);
-    float kmaskv = kvalid ? 0.f : -INFINITY;
-    if (wave_keep && kvalid && keepk && keepk[(size_t)b * keep_n + keep_at] == 0) kmaskv = -INFINITY;
+    const float kmaskv = (kvalid && keep_cur != 0u) ? 0.f : -INFINITY;
     const bool wave_masked = __any(kmaskv != 0.f);
     const int q0 = qw * 32;
     f32x16 e, dp;
@@ -654,16 +675,12 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
       const f32x4 a = *reinterpret_cast<const f32x4*>(qstat + q0 + 8 * g4 + 4 * hh);
       const f32x4 c = *reinterpret_cast<const f32x4*>(qstat + 128 + q0 + 8 * g4 + 4 * hh);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i]; dp[4 * g4 + i] = c[i]; }
+      for (int i = 0; i < 4; ++i) { e[4 * g4 + i] = a[i] + bias_acc[4 * g4 + i]; dp[4 * g4 + i] = c[i]; }
     }
     if (wave_masked) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) e[i] += kmaskv;
     }
-    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh0, __builtin_bit_cast(f16x8, bw0), e, 0, 0, 0);
-    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sh1, __builtin_bit_cast(f16x8, bw1), e, 0, 0, 0);
-    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl0, __builtin_bit_cast(f16x8, bw0), e, 0, 0, 0);
-    e = __builtin_amdgcn_mfma_f32_32x32x16_f16(sl1, __builtin_bit_cast(f16x8, bw1), e, 0, 0, 0);
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
       const bf16x8 qa = att_k_rowfrag(ldsQ, q0 + r, 2 * ss + hh), ka = att_k_rowfrag(ldsK, kw * 32 + r, 2 * ss + hh);
@@ -674,7 +691,9 @@ __global__ __launch_bounds__(ATT_DB16_THREADS) void attn_bwd_dbias16_kernel(cons
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = __builtin_fmaf(att_exp2(e[i] * c1), dp[i], acc[i]);
     }
-    asm volatile("s_waitcnt vmcnt(0)\n s_barrier" ::: "memory");  // stage cur ^ 1 is published, stage cur is free
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): stage cur ^ 1 has landed (and keep_next with it)
+    asm volatile("s_barrier" ::: "memory");  // ... is published, stage cur is free
+    keep_cur = keep_next;
   }
 
   // ---- histogram of the batch-summed dS (in the LDS that held the tiles) ---------------------------------------------------

@@ -697,7 +697,7 @@ struct epil_in_t {
 // of an all-in-one version took 14k of its 25k cycles).
 // STORE_AUX: cache policy of the C / aux stores.  WCOLS: columns of the wave tile (128; 64 served the 256x128 experiment): WCOLS/8 lanes cover a row, 512/WCOLS rows per wave
 // instruction, WCOLS*4+16 bytes of LDS row pitch.
-template <bool OUT_F32, bool RES, int AUX, int WCOLS = 128, int STORE_AUX = EPIL_STORE_AUX>
+template <bool OUT_F32, bool RES, int AUX, int WCOLS = 128, int STORE_AUX = EPIL_STORE_AUX, bool ALPHA = false>
 struct big_epilogue_t {
   static constexpr int LPR = WCOLS / 8, RPG = 64 / LPR, T = 16 / RPG, PITCH = WCOLS * 4 + 16;
   const gemm_params_t& p;
@@ -760,11 +760,16 @@ struct big_epilogue_t {
       const uint32_t m = mw0 + 16 * i + RPG * t + lr;
       const f32x4 lo = *reinterpret_cast<const f32x4*>(rd + lds_off + t * RPG * PITCH);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(rd + lds_off + t * RPG * PITCH + 16);
+      // One wave per SIMD executes this alone, so every vector instruction is paid in full: the plain variant used to spend 35
+      // per 8 elements, 22 of them on factors that were 1 and on sums nobody asked for (12.4k cycles per tile against a
+      // 32k-cycle K loop at K = 768; 7.5k now).  So: alpha is 1 here unless ALPHA (the wgrad slices; other calls with a factor
+      // go to the 128x128 kernel: launch_gemm_big_variant), the column scale exists only in the residual variants and the
+      // column sums only in the GELU'-argument variant (AUX == 2).
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = lo[r] * e.alpha + bia[r];
-        v[4 + r] = hi[r] * e.alpha + bia[4 + r];
+        v[r] = ALPHA ? lo[r] * e.alpha + bia[r] : lo[r] + bia[r];
+        v[4 + r] = ALPHA ? hi[r] * e.alpha + bia[4 + r] : hi[r] + bia[4 + r];
       }
       if (bwd) {
         if (e.act == VLM_ACT_MUL_AUX) {  // the forward pass saved gelu' itself (wave-uniform branch)
@@ -795,11 +800,9 @@ struct big_epilogue_t {
           for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
         }
       }
-      if (e.col_scale) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= gam[r];
-      }
       if (RES) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gam[r];  // 1.0 without a column scale: exact
         if (e.row_scale) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] *= in.rs[t];
@@ -807,9 +810,11 @@ struct big_epilogue_t {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += in.rsd[t][r >> 2][r & 3];
       }
-      if (m < (uint32_t)p.M) {
+      if (AUX == 2) {
+        if (m < (uint32_t)p.M) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) csum[r] += v[r];
+          for (int r = 0; r < 8; ++r) csum[r] += v[r];
+        }
       }
       if (OUT_F32) {
         const uint32_t co = (m * (uint32_t)p.ldc + n) * 4;
@@ -827,7 +832,7 @@ struct big_epilogue_t {
   // column sums of the wave tile: the 4 lane groups hold the same columns for rows = lane>>4 (mod 4)
   __device__ __forceinline__ void finish(int lane, float* ws_row) {
     const vlm_epilogue_t& e = p.epi;
-    if (!e.col_sum) return;
+    if (AUX != 2 || !e.col_sum) return;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       if (LPR == 8) csum[r] += __shfl_xor(csum[r], 8);
@@ -857,6 +862,29 @@ struct big_epilogue_t {
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
     *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * j) = A0[II][j];                                  \
     *reinterpret_cast<f32x4*>(wr + (OFF) + 64 * (4 + j)) = A1[II][j];                            \
+  }
+// AUX == 2 without the residual stream (fc2 dgrad: the saved GELU' factor is this epilogue's only per-element input, 16 B per
+// lane and row): with the factor SAVED by the forward pass the epilogue has next to no arithmetic left, and two input sets in
+// flight made it wait for memory four times per wave tile.  Six of the eight blocks' factors are requested at once after the
+// K loop (96 registers: the fragments and staging sets are dead by then; all eight spilled five), the last two once the first
+// two are used up: one exposed latency per tile; the loop is unrolled so that every set has a static name.
+#define BIG_EPILOGUE_LOOP_DEEP()                                                                                  \
+  unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;                                            \
+  epil_in_t in8[8];                                                                                                \
+  _Pragma("unroll") for (int b8 = 0; b8 < 6; ++b8) ep.load_inputs(in8[b8], b8);                                    \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                  \
+    switch (q) {                                                                                                   \
+      case 0: EPIL_DUMP_ROW(acc00, acc01, 0, 0) EPIL_DUMP_ROW(acc00, acc01, 1, 16 * EPIL_PITCH) break;             \
+      case 1: EPIL_DUMP_ROW(acc00, acc01, 2, 0) EPIL_DUMP_ROW(acc00, acc01, 3, 16 * EPIL_PITCH) break;             \
+      case 2: EPIL_DUMP_ROW(acc10, acc11, 0, 0) EPIL_DUMP_ROW(acc10, acc11, 1, 16 * EPIL_PITCH) break;             \
+      default: EPIL_DUMP_ROW(acc10, acc11, 2, 0) EPIL_DUMP_ROW(acc10, acc11, 3, 16 * EPIL_PITCH) break;            \
+    }                                                                                                              \
+    ep.process(in8[2 * q], 2 * q, 0);                                                                              \
+    ep.process(in8[2 * q + 1], 2 * q + 1, 16 * EPIL_PITCH);                                                        \
+    if (q == 0) {                                                                                                  \
+      ep.load_inputs(in8[6], 6);                                                                                   \
+      ep.load_inputs(in8[7], 7);                                                                                   \
+    }                                                                                                              \
   }
 #define BIG_EPILOGUE_LOOP()                                                                                       \
   unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;                                            \
@@ -954,6 +982,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
       acc11[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
+  // "+a" pin: as soon as the code AFTER the K loop keeps many registers live (the input sets of BIG_EPILOGUE_LOOP_DEEP) hipcc's
+  // allocator parks other values in accumulator registers and shuffles accumulators through VGPRs inside the K loop (96
+  // v_accvgpr moves per pair of steps); an empty asm statement that wants every accumulator in an AGPR before the loop keeps
+  // them there.  (A second pin in front of the epilogue made the allocator permute accumulators between the loop and the tail
+  // steps through scratch.)  tests/test_build_cpu.py watches the outcome.
+#define BIG_PIN_ACC()                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {         \
+    asm volatile("" : "+a"(acc00[i][j]), "+a"(acc01[i][j]), "+a"(acc10[i][j]), "+a"(acc11[i][j]));      \
+  }
+  constexpr bool DEEP = AUX == 2 && !RES;  // BIG_EPILOGUE_LOOP_DEEP
+  if constexpr (DEEP) { BIG_PIN_ACC() }
+
   const int nk = p.K / BIG_BK;
   const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
   unsigned char* const wl = epl + wave * EPIL_WAVE_BYTES;
@@ -1044,19 +1084,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
     BIG_STEP(kt + 0, 1, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
     BIG_STEP(kt + 1, 1, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
   }
-  // the epilogue's first inputs (bias / scale vectors, the first 16-row block) are requested here, four K steps
-  // before they are needed: nothing else loads from memory any more and the staging registers are free
-  EPIL_SETUP()
-  BIG_STEP(kt + 0, 0, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
-  BIG_STEP(kt + 1, 0, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
-  BIG_STEP(kt + 2, 0, 0, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)
+#define BIG_TAIL_STEPS()                                                               \
+  BIG_STEP(kt + 0, 0, 1, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)          \
+  BIG_STEP(kt + 1, 0, 1, 1, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)          \
+  BIG_STEP(kt + 2, 0, 0, 1, fa0, fb0, fa1, fb1, ra0, rb0, sA0, sB0, sA1, sB1)          \
   BIG_STEP(kt + 3, 0, 0, 0, fa1, fb1, fa0, fb0, ra1, rb1, sA1, sB1, sA0, sB0)
-
-  GEMM_STAMP(2)
-  // epilogue.  Wave tiles that are whole in N and keep the 16-B alignments go through the looped LDS-transpose epilogue
-  // (column sums: a wave covers its 128-row half alone -- workspace slot 2 tm + wm when the half is complete, else
-  // atomics); the rest (ragged N, odd leading dimensions) take the generic 64x64 epilogue, column sums by atomics.
-  {  // the launcher sends only shapes here whose wave tiles are whole in N and keep the 16-B alignments
+  // epilogue: wave tiles are whole in N and keep the 16-B alignments (launcher), so every variant goes through the looped
+  // LDS-transpose epilogue (column sums: a wave covers its 128-row half alone -- workspace slot 2 tm + wm when the half is
+  // complete, else atomics)
+  if constexpr (DEEP) {
+    // nothing of the epilogue is set up before the last K step: its eight input sets are requested together afterwards, and
+    // an early first set (below) only added to the register pressure of the tail steps (30 spilled registers)
+    BIG_TAIL_STEPS()
+    GEMM_STAMP(2)
+    big_epilogue_t<OUT_F32, RES, AUX> ep(p, wl, mw0, nw0, lane);
+    float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm_ws * 2 + wm) * 2) * p.N : nullptr;
+    BIG_EPILOGUE_LOOP_DEEP()
+    ep.finish(lane, ws_row);
+  } else {
+    // the epilogue's first inputs (bias / scale vectors, the first 16-row block) are requested here, four K steps
+    // before they are needed: nothing else loads from memory any more and the staging registers are free
+    EPIL_SETUP()
+    BIG_TAIL_STEPS()
+    GEMM_STAMP(2)
     float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm_ws * 2 + wm) * 2) * p.N : nullptr;
     BIG_EPILOGUE_LOOP()
     ep.finish(lane, ws_row);
@@ -1210,7 +1260,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_bigT_kernel(const ge
   pl.ldc = p.N;
   const uint32_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
   unsigned char* const wl = epl + wave * EPIL_WAVE_BYTES;
-  big_epilogue_t<true, false, 0, 128, 0> ep(pl, wl, mw0, nw0, lane);  // plain stores: the reduce launch reads the slices right away
+  big_epilogue_t<true, false, 0, 128, 0, true> ep(pl, wl, mw0, nw0, lane);  // plain stores: the reduce launch reads the slices right away
   epil_in_t inA, inB;
   ep.load_inputs(inA, 0);
   BIG_EPILOGUE_LOOP()
@@ -1302,6 +1352,13 @@ static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStr
   const bool res = e.residual != nullptr;
   const int aux = e.aux ? ((e.act == VLM_ACT_GELU_BWD || e.act == VLM_ACT_MUL_AUX) ? 2 : 1) : 0;
   if (e.row_scale && !res) return 1;
+  {  // what the looped epilogue leaves out (big_epilogue_t::process): a scale factor, a column scale without the residual stream,
+     // column sums outside the GELU'-argument variant
+    bool any_cs = e.col_sum != nullptr;
+    if (GROUPED)
+      for (int g = 0; g < p.n_groups; ++g) any_cs = any_cs || p.grp[g].col_sum != nullptr;
+    if (e.alpha != 1.0f || (e.col_scale && !res) || (any_cs && aux != 2)) return 1;
+  }
   if (!c_is_f32 && !res) {
     if (aux == 0) return launch_gemm_big<false, false, 0, GROUPED>(p, s);
     if (aux == 1) return launch_gemm_big<false, false, 1, GROUPED>(p, s);
