@@ -33,7 +33,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 6
+#define VLM_ABI_VERSION 7
 int vlm_abi_version(void);
 /* Number of compute units grid sizing and split-K slice counts plan for, or negative error: the current device's count,
  * or the smaller budget set by VLM_GEMM_CUS=n (environment, read once) / vlm_set_cu_budget(n) -- room for RCCL's kernels
@@ -191,6 +191,27 @@ int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, i
                       const float* gamma, int M, int D, const float* dres, int lddres, float* dx, int lddx,
                       float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes, int* deferred_blocks,
                       void* stream);
+/* vlm_layernorm_bwd followed by vlm_layerscale_bwd on the row it has just produced, in one pass: `dx` (the residual-stream
+ * gradient in front of this LayerNorm) is also the gradient arriving at the LayerScale of the branch below it
+ * (vision_transformer.py:586,:603), so that branch's dy / dgamma / dbias are taken while the row is in registers -- the same
+ * operations in the same order as the two calls, bit for bit.  workspace / workspace_bytes in `scale`: its own partial
+ * region (a second fold job when deferred: [deferred_blocks][2][D], dgamma then dbias). */
+typedef struct {
+  const void* y;          /* bf16 [M, D]: the branch's saved output (incl. its bias) */
+  int32_t ldy;
+  const float* gamma;     /* LayerScale vector [D] or NULL (ones) */
+  const float* row_scale; /* DropPath row factors [M] or NULL */
+  void* dy;               /* bf16 [M, D] out */
+  int32_t lddy;
+  float* dgamma;          /* += sum_m row_scale*dx*y, or NULL */
+  float* dbias;           /* += sum_m dy, or NULL */
+  float* workspace;
+  size_t workspace_bytes;
+} vlm_layerscale_t;
+int vlm_layernorm_bwd_scale(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx, const float* stats,
+                            const float* gamma, int M, int D, const float* dres, int lddres, float* dx, int lddx,
+                            float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                            const vlm_layerscale_t* scale, int* deferred_blocks, void* stream);
 #define VLM_MAX_FOLD_JOBS 16
 typedef struct {
   const float* partials; /* workspace written by a deferred row kernel: [nblocks][2][D] */

@@ -287,6 +287,44 @@ def test_layerscale_bwd_and_colsum(ops):
     assert_close(out2, a[:, 1536:].float().sum(0), 1e-4, 1e-3, "colsum slice")
 
 
+@pytest.mark.parametrize("M,D", [(1, 192), (37, 192), (880, 768), (13574, 768), (9, 1024)])
+@pytest.mark.parametrize("fold,with_rs", [(False, False), (True, True)])
+def test_layernorm_bwd_scale_is_the_two_calls(ops, M, D, fold, with_rs):
+    """vlm_layernorm_bwd_scale = vlm_layernorm_bwd, then vlm_layerscale_bwd on the row it produced: every output bit for bit
+    (dx, the branch's bf16 gradient; the four column sums to the order of their partial sums when folded from the same grid)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M * 7 + D)
+    x = torch.randn(M, D, device="cuda", generator=gen) * 2 + 0.3
+    g = 1 + 0.1 * torch.randn(D, device="cuda", generator=gen)
+    stats = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, g, torch.zeros(D, device="cuda"), 1e-6, torch.empty(M, D, device="cuda", dtype=torch.bfloat16), stats)
+    dy = bf(torch.randn(M, D, device="cuda", generator=gen))
+    dres = torch.randn(M, D, device="cuda", generator=gen)
+    y = bf(torch.randn(M, D, device="cuda", generator=gen))
+    sg = torch.randn(D, device="cuda", generator=gen) * 0.1
+    rs = ((torch.rand(M, device="cuda", generator=gen) > 0.3).float() / 0.7) if with_rs else None
+
+    def run(fused):
+        dx = torch.empty(M, D, device="cuda"); sdy = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        sums = [torch.full((D,), 0.5, device="cuda") for _ in range(4)]
+        fb = ops.FoldBatch(x.device, D) if fold else None
+        if fused:
+            ops.layernorm_bwd_scale(dy, x, stats, g, dx, dres, sums[0], sums[1], y=y, sgamma=sg, row_scale=rs, sdy=sdy,
+                                    dsgamma=sums[2], dsbias=sums[3], fold=fb)
+        else:
+            ops.layernorm_bwd(dy, x, stats, g, dx, dres=dres, dgamma=sums[0], dbeta=sums[1], fold=fb)
+            ops.layerscale_bwd(dx, y, sg, rs, sdy, sums[2], sums[3], fold=fb)
+        if fb is not None:
+            fb.flush()
+        torch.cuda.synchronize()
+        return dx, sdy, sums
+
+    dx0, sdy0, s0 = run(False)
+    dx1, sdy1, s1 = run(True)
+    assert torch.equal(dx0, dx1) and torch.equal(sdy0, sdy1)
+    for a, b, name in zip(s0, s1, ("dgamma", "dbeta", "dsgamma", "dsbias")):
+        assert_close(b, a, 1e-5, 1e-4 * math.sqrt(M), name)  # the fused launch has half the workgroups: other partial sums
+
+
 def test_adamw_matches_hf4_rule(ops):
     gen = torch.Generator(device="cuda"); gen.manual_seed(2)
     n = 4096 * 3 + 4

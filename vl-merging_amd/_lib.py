@@ -55,6 +55,12 @@ class FoldJob(ctypes.Structure):
                 ("out1", c_void_p)]
 
 
+class LayerScale(ctypes.Structure):  # vlm_layerscale_t
+    _fields_ = [("y", c_void_p), ("ldy", ctypes.c_int32), ("gamma", c_void_p), ("row_scale", c_void_p), ("dy", c_void_p),
+                ("lddy", ctypes.c_int32), ("dgamma", c_void_p), ("dbias", c_void_p), ("workspace", c_void_p),
+                ("workspace_bytes", c_size_t)]
+
+
 class AttnColsum(ctypes.Structure):
     _fields_ = [("dq", c_void_p * 2), ("dv", c_void_p * 2)]
 
@@ -105,6 +111,9 @@ SIGNATURES = {
     "vlm_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                   c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                   ctypes.POINTER(c_int), c_void_p]),
+    "vlm_layernorm_bwd_scale": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                        c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        ctypes.POINTER(LayerScale), ctypes.POINTER(c_int), c_void_p]),
     "vlm_layerscale_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
     "vlm_colreduce_batch": (c_int, [ctypes.POINTER(FoldJob), c_int, c_void_p]),

@@ -96,21 +96,40 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_fwd_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------ LayerNorm backward
 // dx[m,:] = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; dx_out = dx (+ dres) ; column sums by
 // one atomicAdd per column per block (fp32 grads are accumulated across passes anyway).
-template <int MAXU, bool DY_BF16>
-__global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? 4 : 2) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
+// SCALE (vlm_layernorm_bwd_scale): the row this kernel has just produced is the residual-stream gradient the LayerScale backward
+// of the branch BELOW this LayerNorm reads next (Block.forward: x = x + gamma_1 * attn(norm1(x)); x = x + gamma_2 * mlp(norm2(x)),
+// vision_transformer.py:586,:603) -- taken while it is in registers (ls_t: that branch's saved output, its gamma and row
+// scale, its bf16 gradient out, its two column-sum targets) the second kernel's 4-B-per-element read of dx and its launch go.
+struct ls_t {
+  const bf16_t* y;
+  int ldy;
+  const float* gamma;
+  const float* row_scale;
+  bf16_t* dy;
+  int lddy;
+  float* dgamma;
+  float* dbias;
+  float* partials;
+};
+template <int MAXU, bool DY_BF16, bool SCALE = false>
+__global__ __launch_bounds__(ROW_THREADS, (MAXU <= 3 && !SCALE) ? 4 : 2) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
                                                              const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, int M, int D,
                                                              const float* __restrict__ dres, int lddres,
                                                              float* __restrict__ dx, int lddx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ partials) {
-  __shared__ float red[ROW_WAVES][2][MAXU * 256];
+                                                             float* __restrict__ partials, const ls_t ls) {
+  __shared__ float red[ROW_WAVES][SCALE ? 4 : 2][MAXU * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 g[MAXU], ag[MAXU], ab[MAXU];
+  f32x4 g2[SCALE ? MAXU : 1], ag2[SCALE ? MAXU : 1], ab2[SCALE ? MAXU : 1];
   load_vec<MAXU>(gamma, D, lane, g, 1.0f);
+  if (SCALE) load_vec<SCALE ? MAXU : 1>(ls.gamma, D, lane, g2, 1.0f);
 #pragma unroll
   for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < (SCALE ? MAXU : 1); ++u) ag2[u] = ab2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float invD = 1.0f / (float)D;
   for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
     f32x4 v[MAXU], d[MAXU], rs[MAXU];
@@ -119,6 +138,12 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? 4 : 2) void ln_bwd_kernel(
     // the residual-path gradient is fetched with the row, not after the two wave reductions (its latency used to sit
     // between the reduction and the store of every row)
     if (dres) load_row<MAXU, false>(dres, row, lddres, D, lane, rs);
+    f32x4 yy[SCALE ? MAXU : 1];
+    float srow = 1.0f;
+    if (SCALE) {
+      load_row<SCALE ? MAXU : 1, true>(ls.y, row, ls.ldy, D, lane, yy);
+      if (ls.row_scale) srow = ls.row_scale[row];
+    }
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -148,10 +173,31 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? 4 : 2) void ln_bwd_kernel(
         for (int r = 0; r < 4; ++r) o[r] = rstd * (d[u][r] - m1 - v[u][r] * m2);
         if (dres) o += rs[u];
         *reinterpret_cast<f32x4*>(dx + row * lddx + c) = o;
+        if (SCALE) {  // the same operations, in the same order, as scale_bwd_kernel on the stored row
+          bf16x4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sd = srow * o[r];
+            const float q = sd * g2[u][r];
+            ag2[u][r] += sd * yy[u][r];
+            h[r] = (bf16_t)q;
+            ab2[u][r] += (float)h[r];
+          }
+          *reinterpret_cast<bf16x4*>(ls.dy + row * ls.lddy + c) = h;
+        }
       }
     }
   }
-  if (dgamma || dbeta) {
+  if (SCALE) {
+#pragma unroll
+    for (int u = 0; u < (SCALE ? MAXU : 1); ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[wave][SCALE ? 2 : 0][u * 256 + lane * 4 + r] = ag2[u][r];
+        red[wave][SCALE ? 3 : 1][u * 256 + lane * 4 + r] = ab2[u][r];
+      }
+  }
+  if (dgamma || dbeta || SCALE) {
 #pragma unroll
     for (int u = 0; u < MAXU; ++u)
 #pragma unroll
@@ -173,6 +219,21 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? 4 : 2) void ln_bwd_kernel(
       } else {
         if (dgamma) atomicAdd(dgamma + c, sg);
         if (dbeta) atomicAdd(dbeta + c, sb);
+      }
+      if (SCALE) {
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROW_WAVES; ++w) {
+          tg += red[w][SCALE ? 2 : 0][c];
+          tb += red[w][SCALE ? 3 : 1][c];
+        }
+        if (ls.partials) {
+          ls.partials[((size_t)blockIdx.x * 2 + 0) * D + c] = tg;
+          ls.partials[((size_t)blockIdx.x * 2 + 1) * D + c] = tb;
+        } else {
+          if (ls.dgamma) atomicAdd(ls.dgamma + c, tg);
+          if (ls.dbias) atomicAdd(ls.dbias + c, tb);
+        }
       }
     }
   }
@@ -356,10 +417,10 @@ extern "C" int vlm_layernorm_fwd(const float* x, int ldx, int M, int D, const fl
   return VLM_OK;
 }
 
-extern "C" int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx,
-                                 const float* stats, const float* gamma, int M, int D, const float* dres,
-                                 int lddres, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
-                                 size_t workspace_bytes, int* deferred_blocks, void* stream) {
+static int layernorm_bwd_impl(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx,
+                              const float* stats, const float* gamma, int M, int D, const float* dres,
+                              int lddres, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                              size_t workspace_bytes, int* deferred_blocks, void* stream, const vlm_layerscale_t* sc) {
   if (M == 0) return VLM_OK;
   if (!dy || !x || !stats || !dx || M < 0 || D <= 0 || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) ||
       (dres && (lddres & 3)))
@@ -369,10 +430,24 @@ extern "C" int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const 
   // one round of resident workgroups: D <= 768 runs at 4 waves/SIMD (<= 128 VGPRs) = 4 workgroups per CU
   const int resident = (D <= 768 ? 4 : 2) * (vlm_device_cus() > 0 ? vlm_device_cus() : 256);
   if (g > resident) g = resident;
+  if (sc && g > resident / 2) g = resident / 2;  // the fused form holds two more accumulator sets: two workgroups per CU
   float* part = (workspace && workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && (dgamma || dbeta)) ? workspace : nullptr;
   dim3 grid(g), block(ROW_THREADS);
   hipStream_t s = (hipStream_t)stream;
-#define LN_BWD(U, B) hipLaunchKernelGGL((ln_bwd_kernel<U, B>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part)
+  ls_t ls = {};
+  if (sc) {
+    if (!sc->y || !sc->dy || (sc->ldy & 3) || (sc->lddy & 3)) return VLM_ERR_ARG;
+    const bool want = sc->dgamma || sc->dbias;
+    float* part2 = (sc->workspace && sc->workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && want) ? sc->workspace : nullptr;
+    if (deferred_blocks && want && !part2) return VLM_ERR_ARG;  // deferral needs both partial workspaces
+    ls.y = reinterpret_cast<const bf16_t*>(sc->y); ls.ldy = sc->ldy; ls.gamma = sc->gamma; ls.row_scale = sc->row_scale;
+    ls.dy = reinterpret_cast<bf16_t*>(sc->dy); ls.lddy = sc->lddy; ls.dgamma = sc->dgamma; ls.dbias = sc->dbias; ls.partials = part2;
+  }
+#define LN_BWD(U, B)                                                                                                             \
+  do {                                                                                                                           \
+    if (sc) hipLaunchKernelGGL((ln_bwd_kernel<U, B, true>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<U, B, false>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
+  } while (0)
   if (D <= 256) { if (dy_is_f32) LN_BWD(1, false); else LN_BWD(1, true); }
   else if (D <= 768) { if (dy_is_f32) LN_BWD(3, false); else LN_BWD(3, true); }
   else { if (dy_is_f32) LN_BWD(4, false); else LN_BWD(4, true); }
@@ -381,11 +456,34 @@ extern "C" int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const 
   if (deferred_blocks) {
     if (!part && (dgamma || dbeta)) return VLM_ERR_ARG;  // deferral needs the partial workspace
     *deferred_blocks = part ? g : 0;
-  } else if (part) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * D + 255) / 256, 32), dim3(256), 0, s, part, g, D, dgamma, dbeta);
-    VLM_CHECK_LAUNCH();
+  } else {
+    if (part) {
+      hipLaunchKernelGGL(colreduce_kernel, dim3((2 * D + 255) / 256, 32), dim3(256), 0, s, part, g, D, dgamma, dbeta);
+      VLM_CHECK_LAUNCH();
+    }
+    if (ls.partials) {
+      hipLaunchKernelGGL(colreduce_kernel, dim3((2 * D + 255) / 256, 32), dim3(256), 0, s, ls.partials, g, D, ls.dgamma, ls.dbias);
+      VLM_CHECK_LAUNCH();
+    }
   }
   return VLM_OK;
+}
+
+extern "C" int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx,
+                                 const float* stats, const float* gamma, int M, int D, const float* dres,
+                                 int lddres, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                                 size_t workspace_bytes, int* deferred_blocks, void* stream) {
+  return layernorm_bwd_impl(dy, lddy, dy_is_f32, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, workspace,
+                            workspace_bytes, deferred_blocks, stream, nullptr);
+}
+
+extern "C" int vlm_layernorm_bwd_scale(const void* dy, int lddy, int dy_is_f32, const float* x, int ldx,
+                                       const float* stats, const float* gamma, int M, int D, const float* dres,
+                                       int lddres, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                                       size_t workspace_bytes, const vlm_layerscale_t* scale, int* deferred_blocks, void* stream) {
+  if (!scale) return VLM_ERR_ARG;
+  return layernorm_bwd_impl(dy, lddy, dy_is_f32, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, workspace,
+                            workspace_bytes, deferred_blocks, stream, scale);
 }
 
 extern "C" int vlm_layerscale_bwd(const float* dx, int lddx, const void* y, int ldy, const float* gamma,

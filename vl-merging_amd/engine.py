@@ -521,6 +521,21 @@ def _qkv_bias(e):
     return torch.cat((e.qb.detach(), torch.zeros_like(e.vb), e.vb.detach()))
 
 
+# norm2's backward and the attention branch's LayerScale backward as ONE pass over the rows (K3-style fusion of two row kernels:
+# the second one's 4-B-per-element read of the residual-stream gradient and its launch go; bit-identical).  VLM_FUSE_LN_SCALE=0:
+# two launches.
+_FUSE_LN_SCALE = os.environ.get("VLM_FUSE_LN_SCALE", "1") != "0"
+
+
+def _ln2_bwd_scale1(dln, x1, st2, e, dx1, dx2, y1, g1, rs1, dy1, fold):
+    if _FUSE_LN_SCALE and x1.shape[1] <= 768:  # (wider rows: the fused kernel's four accumulator sets spill)
+        ops.layernorm_bwd_scale(dln, x1, st2, e.n2w, dx1, dx2, e.n2w.grad, e.n2b.grad, y=y1, sgamma=g1, row_scale=rs1, sdy=dy1,
+                                dsgamma=g1.grad, dsbias=e.projb.grad, fold=fold)
+    else:
+        ops.layernorm_bwd(dln, x1, st2, e.n2w, dx1, dres=dx2, dgamma=e.n2w.grad, dbeta=e.n2b.grad, fold=fold)
+        ops.layerscale_bwd(dx1, y1, g1, rs1, dy1, g1.grad, e.projb.grad, fold=fold)
+
+
 class _BlockFn(torch.autograd.Function):
     """One transformer block evaluation (LayerNorm -> QKV -> attention -> proj+LayerScale+residual -> LayerNorm ->
     fc1+GELU -> fc2+LayerScale+residual), forward and hand-written backward over the HIP kernels.
@@ -660,10 +675,8 @@ class _BlockFn(torch.autograd.Function):
             ops.gemm_grouped(dh, [(r0, r1, wT16(e.fc1w), None, None) for r0, r1, e in rg], dln)
             for r0, r1, e in rg:
                 rr = slice(r0, r1)
-                ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
-                                  dbeta=e.n2b.grad, fold=fold)
-                ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad, e.projb.grad,
-                                   fold=fold)
+                _ln2_bwd_scale1(dln[rr], x1[rr], st2[rr], e, dx1[rr], dx2[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None,
+                                dy1[rr], fold)
             ops.gemm_grouped(dy1, [(r0, r1, wT16(e.projw), None, None) for r0, r1, e in rg], do)
             with _Side(dy1, o):
                 ops.gemm_wgrad_grouped(dy1, o, [(r0, r1, e.projw.grad) for r0, r1, e in rg])
@@ -683,10 +696,8 @@ class _BlockFn(torch.autograd.Function):
                         ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
                         ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
                     _dgrad(dh[rr], e.fc1w, dln[rr])
-                    ops.layernorm_bwd(dln[rr], x1[rr], st2[rr], e.n2w, dx1[rr], dres=dx2[rr], dgamma=e.n2w.grad,
-                                      dbeta=e.n2b.grad, fold=fold)
-                    ops.layerscale_bwd(dx1[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None, dy1[rr], g1.grad,
-                                       e.projb.grad, fold=fold)
+                    _ln2_bwd_scale1(dln[rr], x1[rr], st2[rr], e, dx1[rr], dx2[rr], y1[rr], g1,
+                                    rs1[rr] if rs1 is not None else None, dy1[rr], fold)
                     _dgrad(dy1[rr], e.projw, do[rr])
                     with _Side(dy1, o):
                         ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)

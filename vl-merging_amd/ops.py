@@ -185,9 +185,10 @@ def layernorm_fwd(x, gamma, beta, eps, out, stats=None):
 _ROW_WS = {}
 
 
-def _row_workspace(device, D):
-    """Per-device scratch for the row kernels' per-workgroup column partials (VLM_ROW_WS_BYTES)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _row_workspace(device, D, slot=0):
+    """Per-device scratch for the row kernels' per-workgroup column partials (VLM_ROW_WS_BYTES); slot 1: the second
+    partial region of a fused call."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, slot)
     n = 1536 * 2 * max(D, 1024)
     ws = _ROW_WS.get(key)
     if ws is None or ws.numel() < n:
@@ -220,6 +221,16 @@ class FoldBatch:
         i = len(self.jobs)
         return self.ws[i * self.region:(i + 1) * self.region]
 
+    def next_regions(self, n):
+        """n consecutive free regions (a fused row kernel parks one job per column-sum pair): all reserved BEFORE the launch,
+        because making room (flush) after the first was taken would fold a region the launch has not written yet."""
+        if len(self.jobs) + n > self.MAX:
+            if self.multi_stream:
+                raise L.VlmError("FoldBatch overflow while its producers run on several streams")
+            self.flush()
+        i = len(self.jobs)
+        return [self.ws[(i + k) * self.region:(i + k + 1) * self.region] for k in range(n)]
+
     def add(self, region, nblocks, D, out0, out1):
         if nblocks > 0:
             self.jobs.append((region, nblocks, D, out0, out1))
@@ -248,6 +259,33 @@ def layernorm_bwd(dy, x, stats, gamma, dx, dres=None, dgamma=None, dbeta=None, f
     L.check(rc, "vlm_layernorm_bwd")
     if fold is not None:
         fold.add(ws, nb.value, D, dgamma, dbeta)
+    return dx
+
+
+def layernorm_bwd_scale(dy, x, stats, gamma, dx, dres, dgamma, dbeta, *, y, sgamma, row_scale, sdy, dsgamma=None, dsbias=None,
+                        fold=None):
+    """layernorm_bwd(...) followed by layerscale_bwd(dx, y, sgamma, row_scale, sdy, dsgamma, dsbias) in ONE pass over the rows
+    (vlm_layernorm_bwd_scale): the LayerScale backward of the branch below this LayerNorm reads the row while it is in
+    registers.  Bit-identical to the two calls."""
+    L.require_cuda(dy, x, stats, gamma, dx, dres, dgamma, dbeta, y, sgamma, row_scale, sdy, dsgamma, dsbias)
+    M, D = x.shape
+    nb = ctypes.c_int(0)
+    if fold is not None:
+        ws, ws2 = fold.next_regions(2)  # two jobs of the batch: this LayerNorm's sums and the LayerScale's
+    else:
+        ws, ws2 = _row_workspace(x.device, D), _row_workspace(x.device, D, slot=1)
+    sc = L.LayerScale()
+    sc.y, sc.ldy, sc.gamma, sc.row_scale = L.ptr(y), _ld(y), L.ptr(sgamma), L.ptr(row_scale)
+    sc.dy, sc.lddy, sc.dgamma, sc.dbias = L.ptr(sdy), _ld(sdy), L.ptr(dsgamma), L.ptr(dsbias)
+    sc.workspace, sc.workspace_bytes = L.ptr(ws2), ws2.numel() * 4
+    rc = L.get_lib().vlm_layernorm_bwd_scale(L.ptr(dy), _ld(dy), int(dy.dtype == F32), L.ptr(x), _ld(x), L.ptr(stats),
+                                             L.ptr(gamma), M, D, L.ptr(dres), _ld(dres) if dres is not None else 0,
+                                             L.ptr(dx), _ld(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), ws.numel() * 4,
+                                             ctypes.byref(sc), ctypes.byref(nb) if fold is not None else None, L.stream_ptr())
+    L.check(rc, "vlm_layernorm_bwd_scale")
+    if fold is not None:
+        fold.add(ws, nb.value, D, dgamma, dbeta)
+        fold.add(ws2, nb.value, D, dsgamma, dsbias)
     return dx
 
 
