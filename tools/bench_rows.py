@@ -25,4 +25,7 @@ for M in (22 * 617, 88 * 617):
     t = timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-6, y, st)); print("M=%d ln_fwd  %.1f us  %.2f TB/s" % (M, t, M * D * 6 / t / 1e6))
     t = timeit(lambda: ops.layernorm_bwd(dy, x, st, g, dx, dres=dres, dgamma=dg, dbeta=db)); print("M=%d ln_bwd  %.1f us  %.2f TB/s" % (M, t, M * D * 14 / t / 1e6))
     t = timeit(lambda: ops.layerscale_bwd(dx, y, g, rs, dy, dg, db)); print("M=%d scale_bwd %.1f us  %.2f TB/s" % (M, t, M * D * 8 / t / 1e6))
+    sdy = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    t = timeit(lambda: ops.layernorm_bwd_scale(dy, x, st, g, dx, dres, dg, db, y=y, sgamma=g, row_scale=rs, sdy=sdy, dsgamma=dg, dsbias=db))
+    print("M=%d ln_bwd + scale_bwd in one pass %.1f us  %.2f TB/s" % (M, t, M * D * 18 / t / 1e6))
     t = timeit(lambda: ops.colsum(dh, cs)); print("M=%d colsum3072 %.1f us  %.2f TB/s" % (M, t, M * 3072 * 2 / t / 1e6))

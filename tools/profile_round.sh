@@ -7,11 +7,19 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary"
+# Two kernel traces of the same command.  (1) VLM_WGRAD_STREAM=0: every launch alone on the chip -- the per-kernel durations
+# that bench.py's roofline figure (whose bracketed steps also run without the side stream) has to agree with; the PMC passes
+# below run the same way.  (2) the default schedule (weight-gradient GEMMs on a second stream): what the timed steps execute.
+export VLM_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- $CMD > $OUT/trace.log 2>&1
+unset VLM_WGRAD_STREAM
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_overlap -o run -- $CMD > $OUT/trace_overlap.log 2>&1
+export VLM_WGRAD_STREAM=0
 PMC="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-calibrate --no-gemm-timer --no-secondary"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o run -- $PMC > $OUT/pmc_mfma.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o run -- $PMC > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o run -- $PMC > $OUT/pmc_write.log 2>&1
+unset VLM_WGRAD_STREAM
 # configs[2] on one GPU (all_moe: grouped expert GEMMs) and the fp64 leg (RegMean + Gram capture), kernel traces only
 MOE="python3 $ROOT/bench.py --arch all_moe --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary --no-merge"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_moe -o run -- $MOE > $OUT/trace_moe.log 2>&1
@@ -21,7 +29,9 @@ python3 tools/prof_summary.py $OUT/trace_moe/run_kernel_stats.csv $OUT/${TAG}_tr
 python3 tools/prof_summary.py $OUT/trace_f64/run_kernel_stats.csv $OUT/${TAG}_f64_leg_kernel_stats.csv "tools/bench_f64_leg.py (RegMean at base size x2, Gram capture D = 768 / 3072 at 54 296 rows x4) under rocprofv3 --kernel-trace --stats"
 grep -E "^(regmean|gram capture)" $OUT/trace_f64.log > $OUT/${TAG}_f64_leg_log.txt
 grep -E '^\{"metric' $OUT/trace_moe.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_all_moe_under_trace.txt
-python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps + merge bench"
+python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "VLM_WGRAD_STREAM=0 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps + merge bench; every launch alone on the chip (the durations the roofline figure agrees with)"
+python3 tools/prof_summary.py $OUT/trace_overlap/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_overlap_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps + merge bench; default schedule (weight-gradient GEMMs on a second stream: overlapping kernels stretch each other's durations)"
+grep -E '^\{"metric' $OUT/trace_overlap.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_under_trace_overlap.txt
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/traffic.txt
 python3 - <<PY
 import collections, csv, glob, json, re

@@ -32,32 +32,35 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output's 2^-9): 1 rcp + 1 exp + 5 fma
 // instead of libm erff's ~40 instructions -- the epilogue of a K=768 GEMM is as long as its main loop otherwise.
-// ez2 returns exp(-z*z), which is also the Gaussian factor of gelu'.
-__device__ __forceinline__ float erf_as(float z, float& ez2) {
-  const float az = fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-  ez2 = __expf(-z * z);
-  float poly = fmaf(t, 1.061405429f, -1.453152027f);
-  poly = fmaf(t, poly, 1.421413741f);
-  poly = fmaf(t, poly, -0.284496736f);
-  poly = fmaf(t, poly, 0.254829592f);
-  const float e = fmaf(-poly * t, ez2, 1.0f);
-  return copysignf(e, z);
+// The forms below are written in x itself (not z = x / sqrt(2)) and carry the cdf's factor 1/2 inside the polynomial: a lone wave
+// pays every vector instruction of the epilogue in full, and this is 14 of them + 2 transcendentals per element
+// where the textbook arrangement took 16 + 2.
+//   half_erf(x) = sign(x) * (1/2 - (a1 t + ... + a5 t^5)/2 * exp(-x^2/2)),  t = 1 / (1 + p |x| / sqrt(2));  cdf = 1/2 + half_erf
+// ez2 returns exp(-x*x/2), the Gaussian factor of gelu'.
+__device__ __forceinline__ float gelu_cdf(float x, float& ez2) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+  ez2 = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
+  float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = fmaf(t, poly, 0.5f * 1.421413741f);
+  poly = fmaf(t, poly, 0.5f * -0.284496736f);
+  poly = fmaf(t, poly, 0.5f * 0.254829592f);
+  const float e = fmaf(-(poly * t), ez2, 0.5f);
+  return 0.5f + copysignf(e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) {
   float ez2;
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
+  return x * gelu_cdf(x, ez2);
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   float ez2;
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
+  const float cdf = gelu_cdf(x, ez2);
   return fmaf(x * 0.39894228040143267794f, ez2, cdf);
 }
 // gelu(x) and gelu'(x) from ONE erf / exp evaluation (VLM_ACT_GELU_DERIV: the forward epilogue saves the derivative, so the
 // backward epilogue is a multiplication instead of 1 rcp + 1 exp + ~14 VALU operations per element)
 __device__ __forceinline__ float gelu_erf_both(float x, float& deriv) {
   float ez2;
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, ez2));
+  const float cdf = gelu_cdf(x, ez2);
   deriv = fmaf(x * 0.39894228040143267794f, ez2, cdf);
   return x * cdf;
 }
@@ -865,13 +868,15 @@ struct big_epilogue_t {
   }
 // AUX == 2 without the residual stream (fc2 dgrad: the saved GELU' factor is this epilogue's only per-element input, 16 B per
 // lane and row): with the factor SAVED by the forward pass the epilogue has next to no arithmetic left, and two input sets in
-// flight made it wait for memory four times per wave tile.  Six of the eight blocks' factors are requested at once after the
-// K loop (96 registers: the fragments and staging sets are dead by then; all eight spilled five), the last two once the first
-// two are used up: one exposed latency per tile; the loop is unrolled so that every set has a static name.
-#define BIG_EPILOGUE_LOOP_DEEP()                                                                                  \
+// flight made it wait for memory four times per wave tile.  AHEAD = 6 of the eight blocks' factors are requested at once after
+// the K loop (96 registers: the fragments and staging sets are dead by then; all eight spilled five), each later one as soon as
+// a set is used up: one exposed latency per tile; the loop is unrolled so that every set has a static name.
+// (The fp32-residual variants with AHEAD = 4, 36 registers per set: no change, 35k cycles either way -- their epilogue runs at the
+// pace of the 655 KB it moves, not of its input latency.)
+#define BIG_EPILOGUE_LOOP_DEEP(AHEAD)                                                                             \
   unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;                                            \
   epil_in_t in8[8];                                                                                                \
-  _Pragma("unroll") for (int b8 = 0; b8 < 6; ++b8) ep.load_inputs(in8[b8], b8);                                    \
+  _Pragma("unroll") for (int b8 = 0; b8 < (AHEAD); ++b8) ep.load_inputs(in8[b8], b8);                              \
   _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                  \
     switch (q) {                                                                                                   \
       case 0: EPIL_DUMP_ROW(acc00, acc01, 0, 0) EPIL_DUMP_ROW(acc00, acc01, 1, 16 * EPIL_PITCH) break;             \
@@ -880,11 +885,9 @@ struct big_epilogue_t {
       default: EPIL_DUMP_ROW(acc10, acc11, 2, 0) EPIL_DUMP_ROW(acc10, acc11, 3, 16 * EPIL_PITCH) break;            \
     }                                                                                                              \
     ep.process(in8[2 * q], 2 * q, 0);                                                                              \
+    if (2 * q + (AHEAD) < 8) ep.load_inputs(in8[2 * q + (AHEAD)], 2 * q + (AHEAD));                                \
     ep.process(in8[2 * q + 1], 2 * q + 1, 16 * EPIL_PITCH);                                                        \
-    if (q == 0) {                                                                                                  \
-      ep.load_inputs(in8[6], 6);                                                                                   \
-      ep.load_inputs(in8[7], 7);                                                                                   \
-    }                                                                                                              \
+    if (2 * q + 1 + (AHEAD) < 8) ep.load_inputs(in8[2 * q + 1 + (AHEAD)], 2 * q + 1 + (AHEAD));                    \
   }
 #define BIG_EPILOGUE_LOOP()                                                                                       \
   unsigned char* wr = wl + (lane & 15) * EPIL_PITCH + (lane >> 4) * 16;                                            \
@@ -992,6 +995,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
     asm volatile("" : "+a"(acc00[i][j]), "+a"(acc01[i][j]), "+a"(acc10[i][j]), "+a"(acc11[i][j]));      \
   }
   constexpr bool DEEP = AUX == 2 && !RES;  // BIG_EPILOGUE_LOOP_DEEP
+  constexpr int AHEAD = 6;
   if constexpr (DEEP) { BIG_PIN_ACC() }
 
   const int nk = p.K / BIG_BK;
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void vlm_gemm_big_kernel(const gem
     GEMM_STAMP(2)
     big_epilogue_t<OUT_F32, RES, AUX> ep(p, wl, mw0, nw0, lane);
     float* ws_row = (p.epi.col_sum_ws && mw0 + 128 <= (uint32_t)p.M) ? p.epi.col_sum_ws + ((size_t)(tm_ws * 2 + wm) * 2) * p.N : nullptr;
-    BIG_EPILOGUE_LOOP_DEEP()
+    BIG_EPILOGUE_LOOP_DEEP(AHEAD)
     ep.finish(lane, ws_row);
   } else {
     // the epilogue's first inputs (bias / scale vectors, the first 16-row block) are requested here, four K steps

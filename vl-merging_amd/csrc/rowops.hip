@@ -112,7 +112,7 @@ struct ls_t {
   float* partials;
 };
 template <int MAXU, bool DY_BF16, bool SCALE = false>
-__global__ __launch_bounds__(ROW_THREADS, (MAXU <= 3 && !SCALE) ? 4 : 2) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
+__global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
                                                              const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, int M, int D,
@@ -122,10 +122,10 @@ __global__ __launch_bounds__(ROW_THREADS, (MAXU <= 3 && !SCALE) ? 4 : 2) void ln
                                                              float* __restrict__ partials, const ls_t ls) {
   __shared__ float red[ROW_WAVES][SCALE ? 4 : 2][MAXU * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 g[MAXU], ag[MAXU], ab[MAXU];
-  f32x4 g2[SCALE ? MAXU : 1], ag2[SCALE ? MAXU : 1], ab2[SCALE ? MAXU : 1];
-  load_vec<MAXU>(gamma, D, lane, g, 1.0f);
-  if (SCALE) load_vec<SCALE ? MAXU : 1>(ls.gamma, D, lane, g2, 1.0f);
+  f32x4 g[SCALE ? 1 : MAXU], ag[MAXU], ab[MAXU];
+  f32x4 g2[1], ag2[SCALE ? MAXU : 1], ab2[SCALE ? MAXU : 1];
+  if (SCALE) g[0] = (f32x4){1.f, 1.f, 1.f, 1.f};
+  else load_vec<SCALE ? 1 : MAXU>(gamma, D, lane, g, 1.0f);
 #pragma unroll
   for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -150,10 +150,12 @@ __global__ __launch_bounds__(ROW_THREADS, (MAXU <= 3 && !SCALE) ? 4 : 2) void ln
     for (int u = 0; u < MAXU; ++u) {
       const int c = lane * 4 + 256 * u;
       if (c < D) {
+        // (SCALE: this LayerNorm's gamma too is re-read per row -- another twelve registers off the loop-carried set)
+        const f32x4 gu = (SCALE && gamma) ? *reinterpret_cast<const f32x4*>(gamma + c) : g[SCALE ? 0 : u];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float xh = (v[u][r] - mean) * rstd;
-          const float gg = d[u][r] * g[u][r];
+          const float gg = d[u][r] * gu[r];
           s1 += gg;
           s2 += gg * xh;
           ag[u][r] += d[u][r] * xh;
@@ -174,11 +176,14 @@ __global__ __launch_bounds__(ROW_THREADS, (MAXU <= 3 && !SCALE) ? 4 : 2) void ln
         if (dres) o += rs[u];
         *reinterpret_cast<f32x4*>(dx + row * lddx + c) = o;
         if (SCALE) {  // the same operations, in the same order, as scale_bwd_kernel on the stored row
+          // (the branch's gamma is re-read per row from the cache: twelve registers held across the loop cost the third workgroup per CU)
+          const int c2 = lane * 4 + 256 * u;
+          g2[0] = ls.gamma ? *reinterpret_cast<const f32x4*>(ls.gamma + c2) : (f32x4){1.f, 1.f, 1.f, 1.f};
           bf16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sd = srow * o[r];
-            const float q = sd * g2[u][r];
+            const float q = sd * g2[0][r];
             ag2[u][r] += sd * yy[u][r];
             h[r] = (bf16_t)q;
             ab2[u][r] += (float)h[r];
@@ -430,7 +435,7 @@ static int layernorm_bwd_impl(const void* dy, int lddy, int dy_is_f32, const flo
   // one round of resident workgroups: D <= 768 runs at 4 waves/SIMD (<= 128 VGPRs) = 4 workgroups per CU
   const int resident = (D <= 768 ? 4 : 2) * (vlm_device_cus() > 0 ? vlm_device_cus() : 256);
   if (g > resident) g = resident;
-  if (sc && g > resident / 2) g = resident / 2;  // the fused form holds two more accumulator sets: two workgroups per CU
+  if (sc && D <= 768 && g > resident * 3 / 4) g = resident * 3 / 4;  // the fused form holds two more accumulator sets: three workgroups per CU (167 registers)
   float* part = (workspace && workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && (dgamma || dbeta)) ? workspace : nullptr;
   dim3 grid(g), block(ROW_THREADS);
   hipStream_t s = (hipStream_t)stream;
