@@ -29,7 +29,11 @@ def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 22 * 617
     shapes = [("qkv fwd", False, False, M, 2304, 768), ("proj fwd", False, False, M, 768, 768),
               ("fc1 fwd", False, False, M, 3072, 768), ("fc2 fwd", False, False, M, 768, 3072),
-              ("fc1 dgrad", False, True, M, 768, 3072), ("fc2 dgrad", False, True, M, 3072, 768),
+              # dgrad as the engine runs it: against the bf16 TRANSPOSED weight shadow (engine.wT16), i.e. both operands
+              # K-contiguous like a forward call (the K-strided-B form these lines used until round 4 is a path no training
+              # step takes: 392 instead of 256 us for fc2 dgrad at M = 54 296)
+              ("fc1 dgrad", False, False, M, 768, 3072), ("fc2 dgrad", False, False, M, 3072, 768),
+              ("qkv dgrad", False, False, M, 768, 2304), ("proj dgrad", False, False, M, 768, 768),
               ("fc1 wgrad", True, True, 3072, 768, M), ("fc2 wgrad", True, True, 768, 3072, M),
               ("qkv wgrad", True, True, 2304, 768, M), ("square 4096", False, False, 4096, 4096, 4096),
               ("text qkv", False, False, 880, 2304, 768)]
