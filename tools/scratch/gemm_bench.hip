@@ -69,17 +69,6 @@ int main(int argc, char** argv) {
       pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); tot += (double)(q[3] - q[0]);
       real += (double)(q[5] - q[4]);
     }
-    {
-      double bnd = 0, epi_issue = 0; int nb = 0;
-      int live = 0;
-      for (int w = 0; w < wgs; ++w) live += hs[(size_t)w * 8 + 3] != 0;
-      for (int w = 0; w < live; ++w) {
-        const unsigned long long* q = &hs[(size_t)w * 8];
-        if (q[6] && q[1] > q[6]) { bnd += (double)(q[1] - q[6]); ++nb; }
-        epi_issue += (double)(q[7] - q[2]);
-      }
-      printf("persistent: tile boundary (end of a tile's epilogue -> next tile's fragments read) %.0f over %d workgroups; epilogue issue (no drain) %.0f\n", nb ? bnd / nb : 0.0, nb, epi_issue / live);
-    }
     printf("stamps (avg per workgroup, s_memtime ticks): prologue %.0f  loop %.0f (%.0f per 32-deep step)  epilogue %.0f  total %.0f ; s_memrealtime ticks %.0f -> memtime/realtime = %.3f\n",
            pro / live, loop / live, loop / live / (K / 32.0), epi / live, tot / live, real / live, tot / real);
   }
