@@ -3,6 +3,9 @@
 #include "vlm_common.h"
 
 #define EW_THREADS 256
+#ifndef EW_NT
+#define EW_NT true
+#endif
 
 static int ew_grid(size_t n_vec) {
   int cus = vlm_device_cus();
@@ -23,10 +26,12 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
                                                            float b2, float eps, float wd, float step_size,
                                                            float grad_scale, int zero_grad) {
   for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * EW_THREADS) {
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    f32x4 gg = reinterpret_cast<f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+    // gradient and moments stream through once per step: non-temporal (EW_NT), so that they do not push the parameters and
+    // their bf16 shadows -- which the next forward pass reads first -- out of the caches
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];  // (nt on the fp32 master as well: inside the noise)
+    f32x4 gg = EW_NT ? __builtin_nontemporal_load(reinterpret_cast<f32x4*>(g) + i) : reinterpret_cast<f32x4*>(g)[i];
+    f32x4 mm = EW_NT ? __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i) : reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = EW_NT ? __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i) : reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float gr = gg[r] * grad_scale;
@@ -38,8 +43,13 @@ __global__ __launch_bounds__(EW_THREADS) void adamw_kernel(float* __restrict__ p
       pp[r] = x;
     }
     reinterpret_cast<f32x4*>(p)[i] = pp;
-    reinterpret_cast<f32x4*>(m)[i] = mm;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (EW_NT) {
+      __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m) + i);
+      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
+    } else {
+      reinterpret_cast<f32x4*>(m)[i] = mm;
+      reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
     if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (pb) {
       bf16x4 h = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};

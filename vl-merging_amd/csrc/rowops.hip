@@ -8,20 +8,26 @@
 // each is what torch autograd derives for those ops.
 #include "vlm_common.h"
 
+#ifndef ROW_NT
+#define ROW_NT true  // last-use rows of the backward row kernels are loaded non-temporally
+#endif
 #define ROW_THREADS 256
 #define ROW_WAVES 4
 
-template <int MAXU, bool IN_BF16>
+// NT: the row is read for the last time (a saved activation in the backward pass): non-temporal load
+template <int MAXU, bool IN_BF16, bool NT = false>
 __device__ __forceinline__ void load_row(const void* base, size_t row, int ld, int D, int lane, f32x4 (&v)[MAXU]) {
 #pragma unroll
   for (int u = 0; u < MAXU; ++u) {
     const int c = lane * 4 + 256 * u;
     if (c < D) {
       if (IN_BF16) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(base) + row * ld + c);
+        const bf16x4* q = reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(base) + row * ld + c);
+        const bf16x4 h = NT ? __builtin_nontemporal_load(q) : *q;
         v[u] = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
       } else {
-        v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * ld + c);
+        const f32x4* q = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * ld + c);
+        v[u] = NT ? __builtin_nontemporal_load(q) : *q;
       }
     } else {
       v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -133,15 +139,15 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void 
   const float invD = 1.0f / (float)D;
   for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
     f32x4 v[MAXU], d[MAXU], rs[MAXU];
-    load_row<MAXU, false>(x, row, ldx, D, lane, v);
-    load_row<MAXU, DY_BF16>(dy, row, lddy, D, lane, d);
+    load_row<MAXU, false, ROW_NT>(x, row, ldx, D, lane, v);
+    load_row<MAXU, DY_BF16>(dy, row, lddy, D, lane, d);  // (nt here too: no gain in the step, ln_bwd alone 101 -> 105 us)
     // the residual-path gradient is fetched with the row, not after the two wave reductions (its latency used to sit
     // between the reduction and the store of every row)
-    if (dres) load_row<MAXU, false>(dres, row, lddres, D, lane, rs);
+    if (dres) load_row<MAXU, false, ROW_NT>(dres, row, lddres, D, lane, rs);
     f32x4 yy[SCALE ? MAXU : 1];
     float srow = 1.0f;
     if (SCALE) {
-      load_row<SCALE ? MAXU : 1, true>(ls.y, row, ls.ldy, D, lane, yy);
+      load_row<SCALE ? MAXU : 1, true, ROW_NT>(ls.y, row, ls.ldy, D, lane, yy);
       if (ls.row_scale) srow = ls.row_scale[row];
     }
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(ROW_THREADS) void scale_bwd_kernel(const float* __r
   for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
     f32x4 d[MAXU], yy[MAXU];
     load_row<MAXU, false>(dx, row, lddx, D, lane, d);
-    load_row<MAXU, true>(y, row, ldy, D, lane, yy);
+    load_row<MAXU, true, ROW_NT>(y, row, ldy, D, lane, yy);
     const float rs = row_scale ? row_scale[row] : 1.0f;
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
