@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE (/root/reference) in this container.
 
-Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr model_base irtr_merged_base train_tiny ckpt recall batch downstream vlmo_resize schedule)
+Run:  python tests/golden/make_golden.py [what ...]     (what in: index merge merge_base model irtr model_base irtr_merged_base train_tiny ckpt recall batch downstream vlmo_resize schedule configs)
 Outputs land next to this file.  Fixtures are DATA (inputs derive from oracle/detweights.py seeds,
 expected outputs are what the reference computed); no reference source is stored.
 """
@@ -909,6 +909,56 @@ def gold_downstream():
     np.savez_compressed(os.path.join(HERE, "downstream_tiny_ufo.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- sacred configuration surface
+def gold_configs():
+    """Every @ex.config / @ex.named_config function of the reference's src/vilt/config.py evaluated the way sacred does
+    (the function's locals are the entries; names with a leading underscore are not), captured as JSON: the default
+    config and each named config's own entries.  sacred is not installed: the stub Experiment only collects the functions."""
+    import importlib.util
+
+    class Experiment:
+        def __init__(self, name):
+            self.default, self.named = None, {}
+
+        def config(self, fn):
+            self.default = fn
+            return fn
+
+        def named_config(self, fn):
+            self.named[fn.__name__] = fn
+            return fn
+
+    saved = sys.modules.get("sacred")
+    sys.modules["sacred"] = types.SimpleNamespace(Experiment=Experiment)
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_vilt_config", "/root/reference/src/vilt/config.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if saved is None:
+            del sys.modules["sacred"]
+        else:
+            sys.modules["sacred"] = saved
+
+    def entries(fn):
+        got = {}
+
+        def prof(frame, event, arg):
+            if event == "return" and frame.f_code is fn.__code__:
+                got.update(frame.f_locals)
+        sys.setprofile(prof)
+        try:
+            fn()
+        finally:
+            sys.setprofile(None)
+        return {k: v for k, v in got.items() if not k.startswith("_")}
+
+    out = {"default": entries(mod.ex.default), "named": {n: entries(f) for n, f in mod.ex.named.items()}}
+    with open(os.path.join(HERE, "named_configs.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("configs: default %d keys, %d named configs" % (len(out["default"]), len(out["named"])))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["index", "merge", "merge_base", "model", "irtr"]
     torch.manual_seed(0)
@@ -916,4 +966,4 @@ if __name__ == "__main__":
         {"index": gold_index, "merge": gold_merge, "merge_base": gold_merge_base, "model": gold_model,
          "irtr": gold_irtr, "model_base": gold_model_base, "irtr_merged_base": gold_irtr_merged_base,
          "train_tiny": gold_train_tiny, "regmean_base": gold_regmean_base, "vlmo_resize": gold_vlmo_resize, "schedule": gold_schedule,
-         "gram_base": gold_gram_base, "ckpt_written_here": gold_ckpt_written_here, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream}[w]()
+         "gram_base": gold_gram_base, "ckpt_written_here": gold_ckpt_written_here, "ckpt": gold_ckpt, "recall": gold_recall, "batch": gold_batch, "downstream": gold_downstream, "configs": gold_configs}[w]()

@@ -39,8 +39,9 @@ def test_failing_rank_fails_the_launcher():
 
 def test_hung_ranks_are_ended_by_the_wall_clock_limit_and_stderr_is_tagged():
     # all ranks alive, none progressing (a collective that never completes): the launcher's own limit ends the job
+    # (20 s: a rank's `import torch` takes longer than 3 s on a loaded box, and the tags below need the ranks to have started)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
-                       timeout=120, cwd=ROOT, env=_env(VLM_BENCH_DRY_RUN="1", VLM_BENCH_TEST_HANG="1", VLM_BENCH_TIMEOUT_S="3"))
+                       timeout=300, cwd=ROOT, env=_env(VLM_BENCH_DRY_RUN="1", VLM_BENCH_TEST_HANG="1", VLM_BENCH_TIMEOUT_S="20"))
     assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
     assert "VLM_BENCH_TIMEOUT_S" in r.stderr
     assert "[rank 0] hanging on purpose" in r.stderr and "[rank 1] hanging on purpose" in r.stderr

@@ -214,3 +214,22 @@ def test_reference_artefacts_load(tmp_path, cfgmod, vm):
                 "callbacks": {collections.OrderedDict: 1}}, cp)
     assert torch.equal(ck.load_ckpt(cp)["w"], torch.ones(3))
     assert torch.equal(ck.load_file(cp)["state_dict"]["w"], torch.ones(3))
+
+
+def test_every_named_config_of_the_reference_key_for_key(pkg):
+    """config.py:25-711 of the reference: the default config and all 30 named configs, each entry equal to what the reference's
+    own sacred functions produce (tests/golden/named_configs.json, written by `make_golden.py configs` from /root/reference)."""
+    import json
+    C = importlib.import_module("vl_merging_amd.vilt.config")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "named_configs.json")) as f:
+        gold = json.load(f)
+    assert C.default_config() == gold["default"]
+    assert sorted(C.NAMED_CONFIGS) == sorted(gold["named"]) and len(gold["named"]) == 30
+    for name, want in gold["named"].items():
+        assert C.NAMED_CONFIGS[name]() == want, name
+        merged = dict(gold["default"])
+        merged.update(want)
+        assert C.make_config(name) == merged, name
+    # the README's merged-model evaluations (README.md:205-231) parse: later words win, like sacred
+    cfg = C.parse_cli(["with", "task_finetune_vqa_square_randaug_base_image384_ufo", "ufo", "image_size=480", "merge_weights=True"])
+    assert cfg["loss_names"]["vqa"] == 1 and cfg["use_ufo"] and cfg["image_size"] == 480 and cfg["lr_mult"] == 10

@@ -205,7 +205,8 @@ def main(argv):
         """Endless stream of this rank's micro-batches: epochs of the train split, or the one synthetic batch."""
         nonlocal epoch, in_epoch
         if data is None:
-            b = synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
+            b = synthetic_batch(B, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev,
+                                loss_names=cfg["loss_names"], vqav2_label_size=cfg["vqav2_label_size"])
             b = b if cfg["tasks"] is not None else b["vl"]
             while True:
                 yield b

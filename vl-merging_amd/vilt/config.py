@@ -1,5 +1,5 @@
-"""Configuration surface of the reference (src/vilt/config.py): same keys, same defaults, same named configs for
-the hot path, and sacred's `with <named_config ...> key=value ...` command-line grammar (later entries win,
+"""Configuration surface of the reference (src/vilt/config.py): same keys, same defaults, ALL of its named configs, and
+sacred's `with <named_config ...> key=value ...` command-line grammar (later entries win,
 config.py:611 "need to be added at the end").  sacred itself is not required.
 """
 import ast
@@ -50,38 +50,155 @@ def named_config(fn):
     return fn
 
 
-@named_config
-def task_mlm_itm_ifm_square_randaug_base_vl():  # config.py:499-532
-    return dict(exp_name="mlm_itm_ifm_square_randaug_base_vl", train_transform_keys=["square_transform_randaug"],
-                tasks=["vl"], datasets=[["sbu", "gcc", "coco", "vg"]],
-                loss_names=_loss_names({"itm": 1, "mlm": 1, "ifm": 1}), batch_size=512, max_epoch=10, max_steps=None,
-                warmup_steps=0.1, draw_false_image=0, learning_rate=2e-4, val_transform_keys=["square_transform"],
-                val_check_interval=1.0, image_size=224, patch_size=16, vlffn_start_layer_index=10,
-                use_sharded_training=False, vit="vit_base_patch16_224", max_vl_text_len=40, max_text_len=40)
+# ---- task configs (config.py:171-609) ---------------------------------------------------------------------------------------
+# Every named config of the reference, entry for entry (tests/test_host_cpu.py compares each with the reference's own sacred
+# function evaluated by tests/golden/make_golden.py configs -> named_configs.json).  The site-specific `data_roots` /
+# `discrete_vae_weight_path` strings are part of that contract; `data_root=<dir>` on the command line is what run.py reads.
+_RANDAUG = dict(train_transform_keys=["square_transform_randaug"], val_transform_keys=["square_transform"])
+_CODE224 = "/storage/linjli/data/vilt/pretrain_arrows_code224/"
 
 
-@named_config
-def task_test_vit_tiny_mlm_itm_ifm_square_randaug_base_vl():  # config.py:535-570
-    d = task_mlm_itm_ifm_square_randaug_base_vl()
-    d.update(exp_name="test_vit_tiny", vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3)
+def _task(exp_name, datasets, losses, vit, image_size=224, vlffn=10, **more):
+    d = dict(_RANDAUG, exp_name=exp_name, datasets=datasets, loss_names=_loss_names(losses), vit=vit, image_size=image_size,
+             patch_size=16, vlffn_start_layer_index=vlffn)
+    d.update(more)
     return d
 
 
-@named_config
-def task_finetune_irtr_coco_square_randaug_base_image384():  # config.py:478-496
-    return dict(exp_name="finetune_irtr_coco_square_randaug_base_image384", datasets=["coco"],
-                train_transform_keys=["square_transform_randaug"], val_transform_keys=["square_transform"],
-                loss_names=_loss_names({"irtr": 1.0}), batch_size=1024, max_epoch=20, max_steps=None, warmup_steps=0.1,
-                get_recall_metric=True, draw_false_text=0, learning_rate=2e-5, image_size=384, patch_size=16,
-                vlffn_start_layer_index=10, use_sharded_training=False, vit="vit_base_patch16_384")
+def _finetune(exp_name, datasets, losses, vit, **more):  # the fine-tuning recipes: steps from the epochs, 10 % warm-up
+    return _task(exp_name, datasets, losses, vit, **dict(dict(max_steps=None, warmup_steps=0.1, use_sharded_training=False), **more))
+
+
+_LARGE = dict(hidden_size=1024, num_heads=16, num_layers=24, vlffn=21)
 
 
 @named_config
-def task_finetune_irtr_f30k_square_randaug_base_image384():  # config.py:433-451
-    d = task_finetune_irtr_coco_square_randaug_base_image384()
-    d.update(exp_name="finetune_irtr_f30k_square_randaug_base_image384", datasets=["f30k"], max_epoch=40,
-             learning_rate=5e-5)
-    return d
+def task_mlm_itm_ifm_square_randaug_base():  # config.py:171-186
+    return _task("mlm_itm_ifm_square_randaug_base", ["coco", "vg", "sbu", "gcc"], {"itm": 1, "mlm": 1, "ifm": 1},
+                 "vit_base_patch16_224", batch_size=1024, max_epoch=10, max_image_len=196, max_text_len_of_initckpt=196)
+
+
+def _nlvr2(tag, size, lr):  # config.py:189-226
+    return _finetune("finetune_nlvr2_square_randaug_base" + tag, ["nlvr2"], {"nlvr2": 1}, "vit_base_patch16_%d" % size,
+                     image_size=size, batch_size=128, max_epoch=10, draw_false_image=0, learning_rate=lr)
+
+
+@named_config
+def task_finetune_nlvr2_square_randaug_base():
+    return _nlvr2("", 224, 1e-4)
+
+
+@named_config
+def task_finetune_nlvr2_square_randaug_base_image384():
+    return _nlvr2("_image384", 384, 5e-5)
+
+
+def _vqa(tag, lr, vit="vit_base_patch16_384", **more):  # config.py:229-249, 294-340 (image_size stays 224 in all three)
+    return _finetune("finetune_vqa_square_randaug_" + tag, ["vqa"], {"vqa": 1}, vit, batch_size=512, max_epoch=10,
+                     draw_false_image=0, learning_rate=lr, val_check_interval=1.0, lr_mult=10, use_moe=False, **more)
+
+
+@named_config
+def task_finetune_vqa_square_randaug_base_image384():
+    return _vqa("base_image384", 1e-4)
+
+
+@named_config
+def task_finetune_vqa_square_randaug_base_image384_ufo():
+    return _vqa("base_image384_ufo", 3e-5)
+
+
+@named_config
+def task_finetune_vqa_square_randaug_large_image384_ufo():
+    return _vqa("large_image384_ufo", 3e-5, vit="vit_large_patch16_384", **_LARGE)
+
+
+@named_config
+def task_all_in_one_pretraining():  # config.py:252-291
+    return _finetune("all_in_one_pretraining", [["imagenet"], ["bookcorpus", "wikipedia"], ["webvid", "sbu", "gcc", "coco", "vg"]],
+                     {"image_only_mim": 1, "text_only_mlm": 1, "mim": 1, "itm": 1, "mlm": 1, "ifm": 1}, "vit_base_patch16_224",
+                     train_transform_keys=["square_transform_randaug_mim"], val_transform_keys=["square_transform_mim"],
+                     tasks=["v", "l", "vl"],
+                     data_roots=[["/storage/v-yilinsung/imagenet-22k/"],
+                                 ["/storage/v-yilinsung/huggingface/bookcorpus/", "/storage/v-yilinsung/huggingface/wikipedia_20200501_en/"],
+                                 ["/storage/linjli/data/mtp_vlp_ray/pretrain/composite/"] + [_CODE224] * 4],
+                     discrete_vae_weight_path="/storage/v-yilinsung/dall_e_tokenizer_weight", batch_size=512, max_epoch=10,
+                     draw_false_image=0, learning_rate=1e-4, val_check_interval=1.0, use_moe=False, random_initialization=True,
+                     max_vl_text_len=40)
+
+
+def _imagenet(size, lr, mult, **more):  # config.py:343-387 (both exp_names end in _ufo, both name the 384 ViT)
+    return _finetune("finetune_imagenet_square_randaug_base_image%d_ufo" % size, ["imagenet1k"], {"img_cls": 1},
+                     "vit_base_patch16_384", image_size=size, batch_size=512, max_epoch=100, draw_false_image=0,
+                     learning_rate=lr, val_check_interval=1.0, lr_mult=mult, use_moe=False, **more)
+
+
+@named_config
+def task_finetune_imagenet_square_randaug_base_image384():
+    return _imagenet(384, 1e-3, 10)
+
+
+@named_config
+def task_finetune_imagenet_square_randaug_base_image224():
+    return _imagenet(224, 3e-3, 1, warmup_steps=0.2, weight_decay=0.05)
+
+
+def _irtr(tag, dataset, size, epochs, lr, losses=None, vit=None, **more):  # config.py:390-496
+    return _finetune("finetune_irtr_" + tag, [dataset], losses or {"irtr": 1.0}, vit or "vit_base_patch16_%d" % size,
+                     image_size=size, batch_size=1024, max_epoch=epochs, get_recall_metric=True, draw_false_text=0,
+                     learning_rate=lr, **more)
+
+
+@named_config
+def task_finetune_irtr_f30k_square_randaug_base():
+    return _irtr("f30k_square_randaug_base", "f30k", 224, 10, 5e-5)
+
+
+@named_config
+def task_finetune_irtr_msrvtt_frame_square_randaug_base():
+    return _irtr("msrvtt_frame_square_randaug_base", "msrvtt", 224, 10, 5e-5, losses={"irtr": 1.0, "ifm": 1.0, "itm": 1.0},
+                 use_moe=False)
+
+
+@named_config
+def task_finetune_irtr_f30k_square_randaug_base_image384():
+    return _irtr("f30k_square_randaug_base_image384", "f30k", 384, 40, 5e-5)
+
+
+@named_config
+def task_finetune_irtr_f30k_square_randaug_large_image384():
+    return _irtr("f30k_square_randaug_large_image384", "f30k", 384, 10, 5e-5, vit="vit_large_patch16_384", **_LARGE)
+
+
+@named_config
+def task_finetune_irtr_coco_square_randaug_base_image384():  # BASELINE configs[4]
+    return _irtr("coco_square_randaug_base_image384", "coco", 384, 20, 2e-5)
+
+
+def _vl_pretrain(exp_name, datasets, roots, dvae, vit="vit_base_patch16_224", **more):  # config.py:499-609
+    return _finetune(exp_name, [datasets], {"itm": 1, "mlm": 1, "ifm": 1}, vit, tasks=["vl"], data_roots=[roots],
+                     discrete_vae_weight_path=dvae, batch_size=512, max_epoch=10, draw_false_image=0, learning_rate=2e-4,
+                     val_check_interval=1.0, max_vl_text_len=40, max_text_len=40, **more)
+
+
+_TINY = dict(vit="vit_tiny_patch16_224", hidden_size=192, num_heads=3)
+
+
+@named_config
+def task_mlm_itm_ifm_square_randaug_base_vl():  # BASELINE configs[1] / [2]
+    return _vl_pretrain("mlm_itm_ifm_square_randaug_base_vl", ["sbu", "gcc", "coco", "vg"], [_CODE224] * 4,
+                        "/storage/v-yilinsung/dall_e_tokenizer_weight")
+
+
+@named_config
+def task_test_vit_tiny_mlm_itm_ifm_square_randaug_base_vl():
+    return _vl_pretrain("vit_tiny_mlm_itm_ifm_square_randaug_base_vl", ["f30k"], ["/workspace/dataset/dataset/flickr30k/"], "",
+                        **_TINY)
+
+
+@named_config
+def task_vit_tiny_pretraining():
+    return _vl_pretrain("vit_tiny_pretraining", ["sbu", "gcc", "coco", "vg"], [_CODE224] * 4, "", **_TINY)
 
 
 def _step(max_epoch, max_steps, warmup=None):
