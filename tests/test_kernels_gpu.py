@@ -853,3 +853,60 @@ def test_l2_normalize_matches_autograd(pkg):
     (yb * w).sum().backward()
     assert_close(ya, yb, 1e-6, 1e-7, "l2 forward")
     assert_close(a.grad, b.grad, 1e-2, 1e-4, "l2 backward")
+
+
+def test_layernorm_bwd_scale_with_a_frozen_layernorm_keeps_the_layerscale_sums(ops):
+    """A frozen LayerNorm (no dgamma / dbeta) in front of a trainable LayerScale: the fused call still parks the LayerScale's
+    partials as a fold job (the library reports the grid whenever either set was written), and the next reservation of the
+    batch does not overlap the region they sit in."""
+    M, D = 1000, 192
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    x = torch.randn(M, D, device="cuda", generator=gen)
+    g = torch.ones(D, device="cuda")
+    stats = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x, g, torch.zeros(D, device="cuda"), 1e-6, torch.empty(M, D, device="cuda", dtype=torch.bfloat16), stats)
+    dy = bf(torch.randn(M, D, device="cuda", generator=gen))
+    y = bf(torch.randn(M, D, device="cuda", generator=gen))
+    sg = torch.randn(D, device="cuda", generator=gen) * 0.1
+
+    def run(fused):
+        dx = torch.empty(M, D, device="cuda"); sdy = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        dsg, dsb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        other = [torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")]
+        fb = ops.FoldBatch(x.device, D)
+        if fused:
+            ops.layernorm_bwd_scale(dy, x, stats, g, dx, None, None, None, y=y, sgamma=sg, row_scale=None, sdy=sdy,
+                                    dsgamma=dsg, dsbias=dsb, fold=fb)
+        else:
+            ops.layernorm_bwd(dy, x, stats, g, dx, fold=fb)
+            ops.layerscale_bwd(dx, y, sg, None, sdy, dsg, dsb, fold=fb)
+        # a further job of the same batch must land in a region of its own
+        ops.layernorm_bwd(dy, x, stats, g, torch.empty(M, D, device="cuda"), dgamma=other[0], dbeta=other[1], fold=fb)
+        fb.flush()
+        torch.cuda.synchronize()
+        return dx, sdy, dsg, dsb, other
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float(b[2].abs().max()) > 0 and float(b[3].abs().max()) > 0
+    assert_close(b[2], a[2], 1e-5, 1e-4 * math.sqrt(M), "dsgamma")
+    assert_close(b[3], a[3], 1e-5, 1e-4 * math.sqrt(M), "dsbias")
+    for u, v in zip(a[4], b[4]):
+        assert_close(v, u, 1e-5, 1e-4 * math.sqrt(M), "the following job's sums")
+
+
+def test_cross_entropy_counts_only_the_rows_the_kernels_score(pkg, ops):
+    """A label outside [0, V) (which F.cross_entropy rejects with a device assert) gets neither loss nor gradient from the row
+    kernels; it must not inflate the mean's denominator either."""
+    engine = importlib.import_module("vl_merging_amd.engine")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    rows, V = 16, 200
+    buf = torch.zeros(rows, 256, device="cuda", dtype=torch.bfloat16)
+    buf[:, :V] = torch.randn(rows, V, device="cuda", generator=gen).to(torch.bfloat16)
+    logits = buf[:, :V]
+    labels = torch.randint(0, V, (rows,), device="cuda", generator=gen)
+    good = engine.cross_entropy(logits[:12], labels[:12])
+    labels_bad = labels.clone()
+    labels_bad[12:] = torch.tensor([V, V + 7, -5, 100000], device="cuda")
+    mixed = engine.cross_entropy(logits, labels_bad)
+    assert abs(float(mixed) - float(good)) <= 1e-6 * max(1.0, abs(float(good)))

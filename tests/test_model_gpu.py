@@ -784,3 +784,35 @@ def test_dense_bias_is_cached_on_the_table_version(mods, golden_dir):
     built, hits, o4 = sweep(2)
     assert built == k and hits == k
     assert not torch.equal(o4[0], o3[0])
+
+
+def test_dense_bias_cache_dies_with_its_model(mods, golden_dir):
+    """The cross-pass cache hangs off the model's FlatParams: a model freed and rebuilt in the same process (sequential
+    evaluations of merged checkpoints) starts with an empty cache whatever ids and device pointers the allocator recycles,
+    and a temporary index (name None in get_rel_pos_bias) never enters it."""
+    import gc
+    eng = importlib.import_module("vl_merging_amd.engine")
+    batch = gpu_batch(det_batch(2, 224, 40, 1024, seed=78))
+    st = eng._DENSE_STATS
+    feats, serials = [], []
+    for scale in (1.0, 2.0):
+        model = build(mods, "ufo", "tiny_ufo", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})
+        with torch.no_grad():
+            model.relative_position_bias_table.mul_(scale)
+        flat = model.relative_position_bias_table._vlm_flat
+        assert flat.dense_cache == {}
+        serials.append(flat.serial)
+        b0 = st["built"]
+        with torch.no_grad():
+            feats.append(model.infer(batch, mask_text=False)["cls_feats"].clone())
+        assert st["built"] > b0 and len(flat.dense_cache) > 0
+        # a temporary index: same values as the model's buffer, a fresh tensor -> never cached
+        tmp = model.text_imag_relative_position_index.clone()
+        n0 = len(flat.dense_cache)
+        rp = model.get_rel_pos_bias(tmp)
+        assert rp.cache_tag is None and rp.cache is None and len(flat.dense_cache) == n0
+        del model, flat, rp
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert serials[0] != serials[1]
+    assert not torch.equal(feats[0], feats[1])

@@ -466,7 +466,7 @@ static int layernorm_bwd_impl(const void* dy, int lddy, int dy_is_f32, const flo
   VLM_CHECK_LAUNCH();
   if (deferred_blocks) {
     if (!part && (dgamma || dbeta)) return VLM_ERR_ARG;  // deferral needs the partial workspace
-    *deferred_blocks = part ? g : 0;
+    *deferred_blocks = (part || ls.partials) ? g : 0;     // either set of partials: a frozen LayerNorm still leaves the LayerScale's
   } else {
     if (part) {
       hipLaunchKernelGGL(colreduce_kernel, dim3((2 * D + 255) / 256, 32), dim3(256), 0, s, part, g, D, dgamma, dbeta);

@@ -11,8 +11,10 @@ Design (MI355X-first, not a port of the reference's module-by-module autograd):
   * weight gradients are accumulated straight into the flat gradient buffer by the wgrad GEMM epilogue
     (weights are shared by up to six passes per training step).
 """
+import itertools
 import math
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -39,6 +41,9 @@ def touch(*params):
 
 def _touch_expert(e):
     touch(e.n1w, e.n1b, e.qkvw, e.qb, e.vb, e.projw, e.projb, e.n2w, e.n2b, e.fc1w, e.fc1b, e.fc2w, e.fc2b)
+
+
+_FLAT_SERIAL = itertools.count()
 
 
 class FlatParams:
@@ -73,6 +78,8 @@ class FlatParams:
         # never by looking at gradient VALUES: a DropPath draw that drops a branch for the whole batch gives an exact-zero
         # gradient that the reference still treats as a gradient (weight decay applies)
         self.touched = set()
+        self.serial = next(_FLAT_SERIAL)  # process-unique (id() of a freed FlatParams can come back)
+        self.dense_cache = {}             # RelPos.dense_for: this model's dense bias tables, see make_relpos
         dev = self.params[0].device
         pad = 64 * 4096  # tail slack: K-strided GEMM operands may be addressed a few rows past a ragged weight
         self.flat_p = torch.zeros(off + pad, device=dev, dtype=F32)
@@ -276,13 +283,14 @@ class RelPos:
     """What the attention kernel needs instead of the reference's dense [H*L, N, N] bias (vilt_module.py:1061):
     the transposed table (autograd-connected), the int16 index in index coordinates and its transpose."""
 
-    def __init__(self, bias_t, index16, index16_t, holder, cache_tag=None):
+    def __init__(self, bias_t, index16, index16_t, holder, cache_tag=None, cache=None):
         self.bias_t = bias_t          # [H*L, R] fp32, requires grad in training
         self.index = index16          # int16 [NP, ld]
         self.index_t = index16_t
         self.holder = holder          # _TableT ctx holder: accumulates d(bias_t)
         self._dense = {}              # (n0, n1, pos1, mode) -> ops.DenseBias, built on first use inside the pass
         self.cache_tag = cache_tag    # identifies (table contents, index) across passes, or None: no cross-pass cache
+        self.cache = cache            # the owning FlatParams' dict (dies with the model), or None
 
     def dense_for(self, seq, mode):
         """Tiled fp16 bias of all layers and heads for this pass geometry and attention mode (2 launches of vlm_bias_dense):
@@ -292,19 +300,19 @@ class RelPos:
         key = (seq.n0, seq.n1, seq.pos1, mode)
         d = self._dense.get(key)
         if d is None:
-            ck = self.cache_tag + key if self.cache_tag is not None else None
-            d = _DENSE_CACHE.get(ck) if ck is not None else None
+            ck = self.cache_tag + key if self.cache_tag is not None and self.cache is not None else None
+            cache = self.cache
+            d = cache.get(ck) if ck is not None else None
             if d is None:
                 with torch.no_grad():
                     d = ops.bias_dense(self.bias_t.detach(), self.index, seq, mode)
                 _DENSE_STATS["built"] += 1
                 if ck is not None:
-                    stale = [k for k in _DENSE_CACHE if k[:2] == ck[:2] and k[2:4] != ck[2:4]]  # same table, older contents
-                    for k in stale:
-                        del _DENSE_CACHE[k]
-                    while len(_DENSE_CACHE) >= 8:
-                        del _DENSE_CACHE[next(iter(_DENSE_CACHE))]
-                    _DENSE_CACHE[ck] = d
+                    for k in [k for k in cache if k[:2] != ck[:2]]:  # older contents of this model's table
+                        del cache[k]
+                    while len(cache) >= 8:
+                        del cache[next(iter(cache))]
+                    cache[ck] = d
             else:
                 _DENSE_STATS["hits"] += 1
             self._dense[key] = d
@@ -332,11 +340,15 @@ class _TableT(torch.autograd.Function):
         return (acc + g).t(), None
 
 
-_DENSE_CACHE = {}  # (id(flat), id(table), flat.version, table._version, index ptr, n0, n1, pos1, mode) -> ops.DenseBias
+# The cross-pass cache of dense bias tables lives ON the model's FlatParams (`flat.dense_cache`: it dies with the model and a
+# rebuilt model starts empty -- a module-global keyed by id() / data_ptr() could hit on a recycled id after a model was freed),
+# keyed by (flat.version, table._version, index tag, n0, n1, pos1, mode) -> ops.DenseBias.
 _DENSE_STATS = {"built": 0, "hits": 0}
 
 
-def make_relpos(table, index16, index16_t):
+def make_relpos(table, index16, index16_t, index_tag=None):
+    """`index_tag` names the index buffer for the cross-pass cache (the model's own buffers: their _idx_cache key); None -- a
+    temporary index whose storage the allocator may hand to a different index next -- switches the cache off."""
     holder = {}
     bias_t = _TableT.apply(table, holder)
     if torch.is_grad_enabled() and table.requires_grad:
@@ -344,8 +356,9 @@ def make_relpos(table, index16, index16_t):
     flat = getattr(table, "_vlm_flat", None)
     # flat.version follows optimizer steps / reloads (raw-pointer writes), table._version follows in-place torch edits;
     # a model whose masters are marked dirty has pending edits: no cache for that pass
-    tag = (id(flat), id(table), flat.version, table._version, index16.data_ptr()) if flat is not None and not flat.dirty else None
-    return RelPos(bias_t, index16, index16_t, holder, tag)
+    ok = flat is not None and not flat.dirty and index_tag is not None
+    tag = (flat.version, table._version, index_tag) if ok else None
+    return RelPos(bias_t, index16, index16_t, holder, tag, flat.dense_cache if ok else None)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -786,7 +799,7 @@ class _LinearFn(torch.autograd.Function):
         M, K = x2.shape
         gy2 = gy.reshape(M, N)
         if (not ctx.gelu and gy2.dtype == BF16 and gy2.stride() == (Np, 1) and gy2.storage_offset() == 0
-                and _PADDED_GRADS.pop(gy2.data_ptr(), None) == (M, Np)):
+                and _is_padded_grad(gy2, M, Np)):
             # the fused cross-entropy's gradient: already the zero-padded bf16 [M, Np] operand (registered by _CrossEntropyFn)
             dy = torch.as_strided(gy2, (M, Np), (Np, 1))
         else:
@@ -857,7 +870,12 @@ def l2_normalize(x):
     return _L2NormFn.apply(x)
 
 
-_PADDED_GRADS = {}  # data_ptr -> (rows, padded columns) of gradient buffers born zero-padded (consumed once by _LinearFn.backward)
+_PADDED_GRADS = {}  # data_ptr -> (weakref to the buffer, rows, padded columns) of gradient buffers born zero-padded (consumed once by _LinearFn.backward)
+
+
+def _is_padded_grad(g, M, Np):
+    ent = _PADDED_GRADS.pop(g.data_ptr(), None)
+    return ent is not None and ent[0]() is not None and ent[1:] == (M, Np)
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -868,7 +886,9 @@ class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, ignore_index):
         loss_rows, lse = ops.cross_entropy_fwd(logits, labels, ignore_index)
-        count = (labels != ignore_index).sum().to(F32)
+        # the kernels' own validity rule (a label outside [0, V) gets neither loss nor gradient, where torch raises a device
+        # assert): such rows must not sit in the denominator either
+        count = ((labels != ignore_index) & (labels >= 0) & (labels < logits.shape[1])).sum().to(F32)
         ctx.save_for_backward(logits, labels, lse, count)
         ctx.ignore_index = ignore_index
         return loss_rows.sum() / count  # no counted row: 0 / 0 = nan, like F.cross_entropy
@@ -880,7 +900,9 @@ class _CrossEntropyFn(torch.autograd.Function):
         d = ops.cross_entropy_bwd(logits, labels, lse, scale, ctx.ignore_index)
         if len(_PADDED_GRADS) > 64:
             _PADDED_GRADS.clear()  # entries nobody consumed (a caller that is not _LinearFn): never grow
-        _PADDED_GRADS[d.data_ptr()] = (d.shape[0], (d.shape[1] + 63) // 64 * 64)
+        # the marker is tied to the padded buffer OBJECT: while it lives its memory cannot be handed to another tensor, and once
+        # it is gone (the gradient was re-materialised by autograd) a recycled pointer finds a dead reference, not a match
+        _PADDED_GRADS[d.data_ptr()] = (weakref.ref(d._base), d.shape[0], d._base.shape[1])
         return d, None, None
 
 

@@ -210,25 +210,22 @@ class FoldBatch:
             ws = _ROW_WS[key] = torch.empty(self.MAX * self.region, device=device, dtype=F32)
         self.ws = ws
         self.jobs = []
+        self.taken = 0  # regions handed out since the last flush (a region whose job turned out empty stays taken)
         self.multi_stream = False  # set by a caller whose row kernels run on more than one stream between two flushes
 
     def next_region(self):
-        if len(self.jobs) >= self.MAX:
-            if self.multi_stream:
-                raise L.VlmError("FoldBatch overflow while its producers run on several streams (a mid-way fold would "
-                                 "read partials of launches the folding stream is not ordered behind)")
-            self.flush()
-        i = len(self.jobs)
-        return self.ws[i * self.region:(i + 1) * self.region]
+        return self.next_regions(1)[0]
 
     def next_regions(self, n):
         """n consecutive free regions (a fused row kernel parks one job per column-sum pair): all reserved BEFORE the launch,
         because making room (flush) after the first was taken would fold a region the launch has not written yet."""
-        if len(self.jobs) + n > self.MAX:
+        if self.taken + n > self.MAX:
             if self.multi_stream:
-                raise L.VlmError("FoldBatch overflow while its producers run on several streams")
+                raise L.VlmError("FoldBatch overflow while its producers run on several streams (a mid-way fold would "
+                                 "read partials of launches the folding stream is not ordered behind)")
             self.flush()
-        i = len(self.jobs)
+        i = self.taken
+        self.taken += n
         return [self.ws[(i + k) * self.region:(i + k + 1) * self.region] for k in range(n)]
 
     def add(self, region, nblocks, D, out0, out1):
@@ -236,6 +233,7 @@ class FoldBatch:
             self.jobs.append((region, nblocks, D, out0, out1))
 
     def flush(self):
+        self.taken = 0
         if not self.jobs:
             return
         arr = (L.FoldJob * len(self.jobs))()
@@ -284,8 +282,10 @@ def layernorm_bwd_scale(dy, x, stats, gamma, dx, dres, dgamma, dbeta, *, y, sgam
                                              ctypes.byref(sc), ctypes.byref(nb) if fold is not None else None, L.stream_ptr())
     L.check(rc, "vlm_layernorm_bwd_scale")
     if fold is not None:
-        fold.add(ws, nb.value, D, dgamma, dbeta)
-        fold.add(ws2, nb.value, D, dsgamma, dsbias)
+        # nb = the grid whenever EITHER partial set was written: a frozen LayerNorm (no dgamma / dbeta) still leaves the
+        # LayerScale's partials in ws2
+        fold.add(ws, nb.value if (dgamma is not None or dbeta is not None) else 0, D, dgamma, dbeta)
+        fold.add(ws2, nb.value if (dsgamma is not None or dsbias is not None) else 0, D, dsgamma, dsbias)
     return dx
 
 

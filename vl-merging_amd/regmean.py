@@ -31,18 +31,21 @@ class _Solves:
     followed by the MFMA-f64 product."""
 
     N_STREAMS = 4
+    MAX_JOBS = 256
 
     def __init__(self, device):
         self.device = device
         self.main = torch.cuda.current_stream(device)
         self.streams = [torch.cuda.Stream(device) for _ in range(self.N_STREAMS)]
-        self.status = torch.zeros(64, device=device, dtype=torch.int32)
+        # sized up front and NEVER reallocated while factorisations are in flight (their verdicts land through the raw pointer):
+        # a merge has 12 layers x 4 weights = 48 solves
+        self.status = torch.zeros(self.MAX_JOBS, device=device, dtype=torch.int32)
         self.jobs = []  # (what, num (solved in place), den copy, status index)
 
     def submit(self, num, den, what):
         i = len(self.jobs)
-        if i >= self.status.numel():
-            self.status = torch.cat([self.status, torch.zeros_like(self.status)])
+        if i >= self.MAX_JOBS:
+            raise RuntimeError("regmean: more than %d solves in one merge" % self.MAX_JOBS)
         st = self.streams[i % self.N_STREAMS]
         st.wait_stream(self.main)  # num / den were produced on the caller's stream
         with torch.cuda.stream(st):

@@ -330,7 +330,7 @@ class ViLTransformerSS(nn.Module):
             if name is None:
                 return engine.make_relpos(self.relative_position_bias_table, *pair)
             self._idx_cache[key] = pair
-        return engine.make_relpos(self.relative_position_bias_table, *self._idx_cache[key])
+        return engine.make_relpos(self.relative_position_bias_table, *self._idx_cache[key], index_tag=key)
 
     # ---- embeddings ----------------------------------------------------------------------------------------------------
     def _text_rows(self, text_ids, text_masks):
