@@ -203,8 +203,9 @@ def cpu_merge_baseline():
 
 def cpu_baseline():
     """The oracle (parity-pinned CPU restatement of the reference) on this host's cores: base_vl ufo, 224x224, B=2,
-    mlm+itm+ifm fwd+bwd (BASELINE configs[0]): 2 warm-up + 5 timed iterations, median and
-    spread; CPU model and thread count stated; plus the merge oracle (cpu_merge_baseline)."""
+    mlm+itm+ifm fwd+bwd (BASELINE configs[0]) at the best of a short thread-count sweep, median and spread; CPU model and
+    thread count stated; plus the merge oracle (cpu_merge_baseline).  The `_`-prefixed entries (the oracle's loss, weights
+    and batch) feed parity_gates() and are dropped from the JSON line."""
     from oracle import vlmo_ref as R
     pkg_vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
     torch.manual_seed(0)
@@ -252,21 +253,38 @@ def cpu_baseline():
     b = synthetic_batch(2, 224, 40, V, 1234, "cpu")["vl"]
     batch = dict(b)
     batch["image"] = b["image"][0]
-    times = []
-    for it in range(7):
+
+    def iteration():
         t0 = time.perf_counter()
         out = R.pretrain_step(sd, a, idx, batch)
         out["total_loss"].backward()
         for v in sd.values():
             v.grad = None
-        if it >= 2:
-            times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0, float(out["total_loss"].detach())
+
+    # Thread count: torch's default (every logical CPU) oversubscribes a B = 2 problem on a 128-thread host and the figure
+    # moved +-60 % between boxes.  One timed iteration per candidate after a common warm-up, then the median of
+    # four iterations at the best count -- <= 8 iterations in all.
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (16, 32, 64, ncpu) if c <= ncpu} or {ncpu})
+    torch.set_num_threads(cands[0])
+    _, oracle_loss = iteration()  # warm-up (allocator, oneDNN primitives); its loss is the parity gate's reference value
+    sweep = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        sweep[c], _ = iteration()
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]] + [iteration()[0] for _ in range(3)]
     per_iter = sorted(times)[len(times) // 2]
-    res = {"value": 2.0 / per_iter, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-           "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(),
+    res = {"value": 2.0 / per_iter, "unit": "samples/s", "cores": best, "kind": "port",
+           "cpu_model": _cpu_model(), "logical_cpus": ncpu,
            "seconds_per_iteration": {"median": per_iter, "min": min(times), "max": max(times)},
-           "sample": "oracle/vlmo_ref.py pretrain_step fwd+bwd, base_vl ufo 224^2 T=40 B=2 (BASELINE configs[0]), "
-                     "5 timed iterations after 2 warm-ups, fp32, torch CPU threads = cores"}
+           "thread_sweep_seconds": {str(c): sweep[c] for c in cands},
+           "sample": "oracle/vlmo_ref.py pretrain_step fwd+bwd, base_vl ufo 224^2 T=40 B=2 (BASELINE configs[0]), fp32: one "
+                     "warm-up, one iteration per thread count in %r, then the median of 4 at the best count (%d threads)"
+                     % (cands, best),
+           "_oracle_loss": oracle_loss, "_sd": sd, "_batch": b}
     try:
         res["merge"] = cpu_merge_baseline()
     except Exception as e:  # the baseline must never take the GPU number down with it
@@ -274,52 +292,128 @@ def cpu_baseline():
     return res
 
 
-def secondary_benches(dev, cfgmod, vm, vu, steps=4, warm=2):
-    """The other BASELINE configs on ONE GPU, after the timed region (rank 0, N = 1 only; < 60 s together):
-    configs[2] all_moe B=22 per-GPU step, configs[4] irtr on ufo B=20 per-GPU step, configs[3]'s task-vector merge, RegMean at base
-    size (fp64 MFMA GEMMs + Cholesky solve) and the Gram capture SYRK, the last two against the fp64 MFMA roofline."""
+TASKS = {
+    # task -> (named configs in front of the arch, default per-GPU batch, algorithmic FLOP per sample at 384^2,
+    #          BASELINE configs index per arch, workload text)
+    "pretrain": (("task_mlm_itm_ifm_square_randaug_base_vl", "step200k"), 22, 1835.1e9, {"ufo": 1, "all_moe": 2},
+                 "task_mlm_itm_ifm"),
+    "irtr": (("task_finetune_irtr_coco_square_randaug_base_image384",), 20, 353.5e9, {"ufo": 4, "all_moe": 4},
+             "task_finetune_irtr_coco"),
+}
+
+
+class TrainLeg:
+    """One data-parallel training workload of BASELINE.json built the way run.py builds it: model -> engine -> fused AdamW +
+    schedule -> gradient reducer (buckets overlapped with backward) -> one synthetic batch per rank.  `step()` is one
+    fwd + bwd + (all-reduce) + AdamW + schedule step; every rank of the job builds the same leg and steps it together."""
+
+    def __init__(self, mods, task, arch, B, image_size, rank, world, dev, force_dist=False):
+        cfgmod, vm, vu, ddp = mods["cfg"], mods["vm"], mods["vu"], mods["ddp"]
+        names, _, _, _, _ = TASKS[task]
+        over = dict(image_size=image_size, vit="vit_base_patch16_%d" % image_size, per_gpu_batchsize=B, num_gpus=world)
+        if task == "pretrain":
+            over["vl_mlm_prob"] = 0.25
+        self.cfg = cfg = cfgmod.make_config(*names, arch, **over)
+        torch.manual_seed(0)
+        self.model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).to(dev)
+        self.model.train()
+        self.model.setup_engine()
+        (self.opt,), (self.sch,) = vu.set_schedule(self.model, max_steps=cfg["max_steps"] or 100000)
+        # VLM_GRAD_COMM=bf16: gradients travel as bf16 (half the xGMI bytes); VLM_GRAD_COLLECTIVE=rs_ag: reduce-scatter +
+        # all-gather instead of one all-reduce per bucket.  Defaults: fp32, all-reduce (what the reference's DDP does).
+        self.reducer = ddp.FlatGradReducer(
+            self.model, force_collectives=force_dist, sharded=os.environ.get("VLM_SHARDED", "0") != "0",  # ddp_sharded (run.py:231-232)
+            comm_dtype=torch.bfloat16 if os.environ.get("VLM_GRAD_COMM", "fp32") == "bf16" else None,
+            collective=os.environ.get("VLM_GRAD_COLLECTIVE", "allreduce"))
+        # the embeddings' all-reduce overlaps the AdamW update of everything else (same wiring as run.py)
+        self.reducer.attach(self.opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
+        b = synthetic_batch(B, image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
+        self.batch = b if cfg["tasks"] is not None else b["vl"]  # vilt_module.py:1485: {"vl": batch} only with `tasks`
+        self.B, self.world, self.dist = B, world, (world > 1 or force_dist)
+
+    def step(self):
+        self.reducer.begin_step()
+        loss = self.model.training_step(self.batch, 0)
+        loss.backward()
+        self.reducer.finish_backward()
+        self.opt.step()
+        self.sch["scheduler"].step()
+        return loss
+
+    def fence(self):
+        if self.dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, dev, per_step=None):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between two barrier + synchronize fences; the time is the MAX
+        over the ranks.  per_step(i): hook in front of timed step i (the headline leg switches its GEMM timer there)."""
+        loss = None
+        for _ in range(warmup):
+            loss = self.step()
+        self.fence()
+        self.reducer.measure = True
+        t0 = time.perf_counter()
+        for it in range(steps):
+            if per_step is not None:
+                per_step(it)
+            loss = self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt, loss
+
+    def close(self):
+        self.reducer.begin_step()  # drains a deferred tail nobody waited for
+        torch.cuda.synchronize()
+        del self.model, self.opt, self.sch, self.reducer, self.batch
+        torch.cuda.empty_cache()
+
+
+def secondary_train_legs(mods, dev, rank, world, headline, force_dist=False, steps=4, warm=2):
+    """The other data-parallel BASELINE configs, run by EVERY rank after the timed region (configs[2] all_moe B = 22 and
+    configs[4] irtr on ufo B = 20 at 384^2, whichever is not the headline): whole-job samples/s over `steps` timed steps after
+    `warm` warm-ups, fenced and MAX-reduced like the headline -- one `bench.py --gpus N` gives all three DP numbers."""
+    out = {}
+    for key, task, arch in (("ufo_b22", "pretrain", "ufo"), ("all_moe_b22", "pretrain", "all_moe"), ("irtr_ufo_b20", "irtr", "ufo")):
+        if (task, arch) == headline:
+            continue
+        B = TASKS[task][1]
+        err = torch.zeros(1, device=dev)
+        try:
+            leg = TrainLeg(mods, task, arch, B, 384, rank, world, dev, force_dist)
+        except Exception as e:  # a secondary leg must never take the headline number down with it
+            out[key] = {"error": repr(e)}
+            err += 1
+            leg = None
+        if world > 1:  # a rank that could not build the leg must not leave its peers in the leg's collectives
+            dist.all_reduce(err)
+        if float(err) > 0:
+            out.setdefault(key, {"error": "another rank failed to build this leg"})
+            if leg is not None:
+                leg.close()
+            continue
+        dt, _ = leg.timed(steps, warm, dev)
+        out[key] = {"samples_per_s": B * world * steps / dt, "ms_per_step": dt / steps * 1e3, "batch": B, "n_gpus": world,
+                    "steps": steps, "warmup": warm, "exposed_comm_ms_per_step": leg.reducer.exposed_wait_ms() / steps,
+                    "workload": "BASELINE configs[%d]" % TASKS[task][3][arch]}
+        leg.close()
+    return out
+
+
+def secondary_benches(dev):
+    """configs[3]'s other legs on ONE GPU (rank 0, N = 1 only: the merge is 'replicas only'): the task-vector
+    merge, RegMean at base size (fp64 MFMA GEMMs + Cholesky solve) and the Gram capture SYRK, the last two against the fp64
+    MFMA roofline."""
     import statistics
     ops = importlib.import_module("vl_merging_amd.ops")
     M = importlib.import_module("vl_merging_amd.merge")
     bm = importlib.import_module("vl_merging_amd.bench_merge")
     rg = importlib.import_module("vl_merging_amd.regmean")
     out = {}
-
-    def timed_steps(step):
-        for _ in range(warm):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
-
-    def train_leg(key, names, batch_of, B, **over):
-        try:
-            cfg = cfgmod.make_config(*names, image_size=384, vit="vit_base_patch16_384", per_gpu_batchsize=B, num_gpus=1, **over)
-            torch.manual_seed(0)
-            model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).to(dev)
-            model.train()
-            model.setup_engine()
-            (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"] or 1000)
-            batch = batch_of(synthetic_batch(B, 384, cfg["max_text_len"], cfg["vocab_size"], 1234, dev))
-
-            def step():
-                loss = model.training_step(batch, 0)
-                loss.backward()
-                opt.step()
-                sch["scheduler"].step()
-
-            dt = timed_steps(step)
-            out[key] = {"samples_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B, "steps": steps, "warmup": warm}
-            del model, opt, sch, batch
-        except Exception as e:  # a secondary leg must never take the headline number down with it
-            out[key] = {"error": repr(e)}
-        torch.cuda.empty_cache()
-
-    train_leg("all_moe_b22", ("task_mlm_itm_ifm_square_randaug_base_vl", "step200k", "all_moe"), lambda b: b, 22, vl_mlm_prob=0.25)
-    train_leg("irtr_ufo_b20", ("task_finetune_irtr_coco_square_randaug_base_image384", "ufo"), lambda b: b["vl"], 20)
 
     def ev_median(fn, reps=5, warmup=2):
         for _ in range(warmup):
@@ -485,8 +579,55 @@ def dry_run(args, rank, world):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        _, _, _, cfg_index, task_text = TASKS[args.task]
         print(json.dumps({"metric": "dry run (launcher + rendezvous only)", "value": None, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "dry_run": True}))
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "task": task_text, "arch": args.arch,
+                          "per_gpu_batchsize": args.batch, "baseline_config": cfg_index[args.arch]}))
+
+
+def parity_gates(dev, mods, cpu, merge_check):
+    """The checks that stand beside the numbers in the JSON line: (a) the merged buffer bench_merge
+    has just timed against oracle/merge_oracle.py on a slice of its tensors, bit for bit; (b) the loss of one configs[0] step
+    (base_vl ufo 224^2 B = 2, eval mode: B = 2 forces the hard negatives) on the GPU against the oracle's loss on the same
+    weights and batch -- the oracle step cpu_baseline() runs anyway.  The oracle is the CHECKER here, never the thing timed."""
+    out = {}
+    if merge_check is not None:
+        try:
+            import numpy as np
+            from oracle import merge_oracle as mo
+            sub, got, cfg, layers = merge_check
+            ref = mo.merge_weights({k: v.cpu().numpy() for k, v in sub.items()}, cfg, layers=layers)
+            bad = [k for k, v in got.items() if v.cpu().numpy().tobytes() != np.asarray(ref[k]).tobytes()]
+            out["merge"] = "bit-exact" if not bad else "MISMATCH: " + ", ".join(bad[:3])
+            out["merge_checked"] = "%d merged tensors of layers 0 and 11 (%d bytes) against oracle/merge_oracle.py" % (
+                len(got), sum(v.numel() * 4 for v in got.values()))
+        except Exception as e:
+            out["merge"] = "error: " + repr(e)
+    if cpu is not None and cpu.get("_sd") is not None:
+        try:
+            cfgmod, vm = mods["cfg"], mods["vm"]
+            cfg = cfgmod.make_config("task_mlm_itm_ifm_square_randaug_base_vl", "ufo", per_gpu_batchsize=2, num_gpus=1)
+            torch.manual_seed(0)
+            model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+            info = model.load_state_dict({k: v.detach() for k, v in cpu["_sd"].items()}, strict=False)
+            model = model.to(dev).eval()
+            model.setup_engine()
+            b = cpu["_batch"]
+            batch = {k: ([v[0].to(dev)] if k == "image" else v.to(dev)) for k, v in b.items()}
+            with torch.no_grad():
+                got = float(model.training_step({"vl": batch}, 0))
+            want = cpu["_oracle_loss"]
+            out.update(step_loss_gpu=got, step_loss_oracle=want, step_loss_err=abs(got - want), step_loss_tol=3e-2,
+                       step_loss_ok=bool(abs(got - want) <= 3e-2),
+                       step="BASELINE configs[0]: base_vl ufo 224^2 T=40 B=2 mlm+itm+ifm, eval mode, same weights and batch; "
+                            "bf16 MFMA engine vs fp32 oracle (tolerance as tests/test_model_gpu.py: losses 3e-2)",
+                       step_unloaded_keys=len(info.missing_keys))
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["step_loss_err"] = None
+            out["step_error"] = repr(e)
+    return out
 
 
 def main():
@@ -494,8 +635,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--task", default="pretrain", choices=sorted(TASKS),
+                    help="pretrain = task_mlm_itm_ifm (BASELINE configs[1] ufo / [2] all_moe); irtr = task_finetune_irtr_coco "
+                         "(configs[4]: `--gpus 8 --task irtr` is that config as BASELINE.json words it, per-GPU batch 20)")
     ap.add_argument("--arch", default="ufo", choices=["ufo", "all_moe"])
-    ap.add_argument("--batch", type=int, default=22)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 22 pretrain, 20 irtr)")
     ap.add_argument("--image-size", type=int, default=384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-merge", action="store_true")
@@ -504,9 +648,11 @@ def main():
                     help="bracket the GEMM launches of every n-th timed step with HIP events (all 8 steps cost 3 %% of "
                          "the step: 2x1000 event records; every 4th keeps that under 1 %%)")
     ap.add_argument("--no-calibrate", action="store_true", help="skip the attainable-peak probes")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs' legs (all_moe, irtr, task vector, "
-                                                                "RegMean, Gram capture)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs' legs (the other two DP "
+                                                                "workloads at this N; at N = 1 also task vector, RegMean, Gram capture)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = TASKS[args.task][1]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:])
@@ -541,75 +687,38 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     ge.import_package()
-    cfgmod = importlib.import_module("vl_merging_amd.vilt.config")
-    vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
-    vu = importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils")
+    mods = {"cfg": importlib.import_module("vl_merging_amd.vilt.config"),
+            "vm": importlib.import_module("vl_merging_amd.vilt.modules.vilt_module"),
+            "vu": importlib.import_module("vl_merging_amd.vilt.modules.vilt_utils"),
+            "ddp": importlib.import_module("vl_merging_amd.ddp")}
     ops = importlib.import_module("vl_merging_amd.ops")
-    ddp = importlib.import_module("vl_merging_amd.ddp")
     L_ = importlib.import_module("vl_merging_amd._lib")
+    eng = importlib.import_module("vl_merging_amd.engine")
 
-    cfg = cfgmod.make_config("task_mlm_itm_ifm_square_randaug_base_vl", "step200k", args.arch,
-                             image_size=args.image_size, vit="vit_base_patch16_%d" % args.image_size,
-                             per_gpu_batchsize=args.batch, num_gpus=world, vl_mlm_prob=0.25)
-    torch.manual_seed(0)
-    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg)).to(dev)
-    model.train()
-    model.setup_engine()
-    (opt,), (sch,) = vu.set_schedule(model, max_steps=cfg["max_steps"])
-    # VLM_GRAD_COMM=bf16: gradients travel as bf16 (half the xGMI bytes); VLM_GRAD_COLLECTIVE=rs_ag: reduce-scatter + all-gather
-    # instead of one all-reduce per bucket.  Defaults: fp32, all-reduce (what the reference's DDP does).
-    reducer = ddp.FlatGradReducer(model, force_collectives=force_dist,
-                                  sharded=os.environ.get("VLM_SHARDED", "0") != "0",  # ddp_sharded (run.py:231-232)
-                                  comm_dtype=torch.bfloat16 if os.environ.get("VLM_GRAD_COMM", "fp32") == "bf16" else None,
-                                  collective=os.environ.get("VLM_GRAD_COLLECTIVE", "allreduce"))
-    # the embeddings' all-reduce overlaps the AdamW update of everything else (same wiring as run.py)
-    reducer.attach(opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
-    batch = synthetic_batch(args.batch, args.image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
+    leg = TrainLeg(mods, args.task, args.arch, args.batch, args.image_size, rank, world, dev, force_dist)
+    reducer = leg.reducer
     timer = GemmTimer(ops)
     timer.install()
-
-    def step():
-        reducer.begin_step()
-        loss = model.training_step(batch, 0)
-        loss.backward()
-        reducer.finish_backward()
-        opt.step()
-        sch["scheduler"].step()
-        return loss
-
-    def fence():
-        if world > 1 or force_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        loss = step()
-    fence()
     use_timer = rank == 0 and not args.no_gemm_timer
-    reducer.measure = True
-    t0 = time.perf_counter()
     # The steps whose GEMM launches are bracketed run with the weight-gradient side stream OFF: a launch that shares the chip
     # with another stream's kernel takes longer for reasons that are not its own, and the roofline figure is the kernel's own
     # duration.  (They stay inside the timed region: `value` pays for them.)
-    eng = importlib.import_module("vl_merging_amd.engine")
     side_default = eng._WGRAD["enabled"]
-    for it in range(args.steps):
+
+    def per_step(it):
         timer.on = use_timer and it % max(1, args.gemm_timer_every) == 0
         eng._WGRAD["enabled"] = side_default and not timer.on
-        loss = step()
+
+    dt, loss = leg.timed(args.steps, args.warmup, dev, per_step)
     eng._WGRAD["enabled"] = side_default
-    fence()
-    dt = time.perf_counter() - t0
     timer.on = False
     exposed_comm_ms = reducer.exposed_wait_ms() / max(1, args.steps)
     loss_val = float(loss.detach())
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
     total_samples = args.batch * world * args.steps
     value = total_samples / dt
+    _, _, flop384, cfg_index, task_text = TASKS[args.task]
 
+    out = None
     if rank == 0:
         gs = timer.summary()
         out = {
@@ -617,51 +726,69 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "base_vl %s %d^2 patch16 T=40 per_gpu_batchsize=%d task_mlm_itm_ifm fwd+bwd+AdamW, "
-                                   "train mode (BASELINE configs[%d])" % (args.arch, args.image_size, args.batch,
-                                                                          1 if args.arch == "ufo" else 2),
+            "config": {"workload": "base_vl %s %d^2 patch16 T=40 per_gpu_batchsize=%d %s fwd+bwd+AdamW, "
+                                   "train mode (BASELINE configs[%d])" % (args.arch, args.image_size, args.batch, task_text,
+                                                                          cfg_index[args.arch]),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss_val},
             # time the compute stream waits for the tail of the gradient all-reduce (rank 0), per step
             "exposed_comm_ms_per_step": exposed_comm_ms,
             "grad_comm": {"dtype": "bf16" if reducer.comm_dtype is not None else "fp32", "collective": reducer.collective,
                           "sharded_optimizer": reducer.sharded, "bytes_per_step": int(reducer.flat.numel) * (2 if reducer.comm_dtype is not None else 4),
                           "buckets": reducer.bucket_plan(),
-                          "cu_budget": L_.get_lib().vlm_device_cus()},  # VLM_GEMM_CUS: CUs the GEMM grids plan for (RCCL takes the rest)
+                          "cu_budget": L_.get_lib().vlm_device_cus(),  # VLM_GEMM_CUS: CUs the GEMM grids plan for (RCCL takes the rest)
+                          "wgrad_side_stream": bool(side_default)},
         }
-        flop_per_sample = FLOP_PER_SAMPLE_384 if args.image_size == 384 else 657.5e9
+        if args.image_size == 384:
+            flop_per_sample = flop384
+        else:
+            flop_per_sample = 657.5e9 if args.task == "pretrain" else 3 * 41.98e9  # 224^2
         out["model_tflops"] = value * flop_per_sample / 1e12 / world
         if gs:
+            n_timed = len(range(0, args.steps, max(1, args.gemm_timer_every)))
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(GEMM_KERNELS, GEMM_HELPERS),
                                "traffic_unit": "HBM-side bytes per vlm_gemm_bf16 call, launch-weighted over the kernels "
-                                               "that serve it (rocprofv3 PMC, profiles/r04_pmc_traffic.json)",
+                                               "that serve it (rocprofv3 PMC, the newest profiles/r*_pmc_traffic.json)",
                                "kernel": "vlm_gemm_bf16 (+ _grouped / vlm_gemm_wgrad_grouped for all_moe): " + " / ".join(GEMM_KERNELS),
                                "note": "peak = nominal dense bf16; a loop of nothing but independent MFMAs reaches 1515 "
                                        "TFLOP/s on this chip (clock drops to 1.45 GHz: DESIGN.md 4.1); the bracketed steps run "
                                        "with the weight-gradient side stream off (every launch alone on the chip)",
-                               "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
-                               "timed_steps": len(range(0, args.steps, max(1, args.gemm_timer_every))),
-                               "gemm_share_of_step": gs["seconds"] / (dt / args.steps *
-                                                                      len(range(0, args.steps, max(1, args.gemm_timer_every))))}
+                               "launches": gs["launches"], "avg_launch_us": gs["avg_us"], "timed_steps": n_timed,
+                               "gemm_share_of_step": gs["seconds"] / (dt / args.steps * n_timed)}
         if not args.no_calibrate:
             out["attainable"] = calibrate(dev)
+    leg.close()
+    del leg, reducer
+
+    secondary = {}
+    if not args.no_secondary and args.image_size == 384:
+        # every rank takes part: the other two data-parallel BASELINE workloads at this world size
+        secondary.update(secondary_train_legs(mods, dev, rank, world, (args.task, args.arch), force_dist))
+    if rank == 0:
+        merge_check = None
         if not args.no_merge:
             bm = importlib.import_module("vl_merging_amd.bench_merge")
-            del model, opt
-            torch.cuda.empty_cache()
-            m = bm.run()
+            m = bm.run(check_layers=(0, 11))
+            merge_check = m.pop("check")
             out["merge"] = {"metric": "all_moe->ufo interpolation merge, base size, fp32", "GBps": m["GBps"],
                             "seconds_median": m["seconds_median"], "algorithmic_bytes": m["algorithmic_bytes"],
                             "roofline": {"bound": "hbm", "achieved": m["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                          "frac": m["GBps"] / HBM_PEAK_GBPS,
                                          "traffic": pmc_traffic("vlm_merge_kernel"), "kernel": "vlm_merge_kernel"}}
-        if not args.no_secondary and world == 1 and not force_dist and args.arch == "ufo":
-            out["secondary"] = secondary_benches(dev, cfgmod, vm, vu)
+        if not args.no_secondary and world == 1 and not force_dist and args.image_size == 384:
+            secondary.update(secondary_benches(dev))
+        if secondary:
+            out["secondary"] = secondary
+        cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                cpu = cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if merge_check is not None or cpu is not None:
+            out["parity"] = parity_gates(dev, mods, cpu, merge_check)
+        if cpu is not None:
+            out["cpu_baseline"] = {k: v for k, v in cpu.items() if not k.startswith("_")}
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

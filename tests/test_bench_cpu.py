@@ -24,6 +24,19 @@ def test_gpus2_spawns_two_ranks_and_relays_rank0_line():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dry_run"] is True
 
 
+def test_every_dp_config_of_baseline_has_a_command_line():
+    """BASELINE.json configs[4] is `--gpus 8 --task irtr` (per-GPU batch 20 by default), configs[2] `--arch all_moe`: the
+    launcher hands the task through to its ranks (dry run at two ranks)."""
+    for argv, want in ((["--task", "irtr"], ("task_finetune_irtr_coco", "ufo", 20, 4)),
+                       (["--arch", "all_moe"], ("task_mlm_itm_ifm", "all_moe", 22, 2)),
+                       ([], ("task_mlm_itm_ifm", "ufo", 22, 1))):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + argv, capture_output=True,
+                           text=True, timeout=300, cwd=ROOT, env=_env(VLM_BENCH_DRY_RUN="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert (d["task"], d["arch"], d["per_gpu_batchsize"], d["baseline_config"]) == want and d["n_gpus"] == 2
+
+
 def test_gpus_must_agree_with_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, cwd=ROOT, env=_env(VLM_BENCH_DRY_RUN="1", WORLD_SIZE="1", RANK="0"))

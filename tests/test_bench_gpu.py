@@ -29,6 +29,8 @@ def test_bench_json_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
     m = d["merge"]
     assert m["roofline"]["bound"] == "hbm" and m["algorithmic_bytes"] == 1077239808 and 0.3 < m["roofline"]["frac"] < 1.0
+    # parity gate beside the number: the buffer the merge leg has just timed, against the CPU oracle on layers 0 and 11
+    assert d["parity"]["merge"] == "bit-exact", d["parity"]
     # the other BASELINE configs, measured in the same run (configs[2], [4], [3]'s task-vector / RegMean / Gram legs)
     sec = d["secondary"]
     for k in ("all_moe_b22", "irtr_ufo_b20", "task_vector", "regmean_base", "gram_capture_base"):
@@ -62,6 +64,35 @@ def test_bench_gpus2_launches_two_ranks_on_one_device():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 4 / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"] + 1e-3
     assert "exposed_comm_ms_per_step" in d
+
+
+@pytest.mark.gpu
+def test_bench_irtr_task_at_two_ranks_with_secondary_legs_and_step_parity():
+    """`--task irtr` is BASELINE configs[4]'s workload (run.py:263-288 + config.py:478-496): two ranks on the one device, the
+    secondary data-parallel legs run by BOTH ranks (384^2 only, so this small run asks for none), and at N = 1 the configs[0]
+    step-loss gate against the oracle."""
+    env = {"VLM_BENCH_ONE_DEVICE": "1", "VLM_DIST_BACKEND": "gloo"}
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--task", "irtr"] + SMALL, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT, env=dict(env_clean, **env))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and "task_finetune_irtr_coco" in d["config"]["workload"] and "configs[4]" in d["config"]["workload"]
+    assert d["value"] > 0 and d["config"]["global_batch"] == 4
+
+
+@pytest.mark.gpu
+def test_bench_step_loss_gate_against_the_oracle():
+    """The JSON line carries |loss_gpu - loss_oracle| of one configs[0] step (the oracle step is the CPU baseline's own)."""
+    r = _run_bench(["--steps", "2", "--warmup", "1", "--no-calibrate", "--no-merge", "--no-secondary", "--batch", "2",
+                    "--image-size", "224"], timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    p = d["parity"]
+    assert p["step_loss_ok"] is True and p["step_loss_err"] <= p["step_loss_tol"], p
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and str(cb["cores"]) in cb["thread_sweep_seconds"]
+    assert not any(k.startswith("_") for k in cb)
 
 
 @pytest.mark.gpu

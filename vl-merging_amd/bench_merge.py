@@ -33,11 +33,14 @@ def synthetic_all_moe_blocks(seed=0):
     return sd
 
 
-def run(reps=20, warmup=3, ratio=0.5):
+def run(reps=20, warmup=3, ratio=0.5, check_layers=None):
+    """`check_layers`: also return, under "check", (the inputs of those layers, the merged tensors of those layers as they
+    stand in the output buffers AFTER the last timed launch, the merge config) so that the caller can compare what was timed
+    with a checker of its own (bench.py: the CPU oracle; this package never imports one)."""
     sd = synthetic_all_moe_blocks()
     cfg = dict(vlffn_start_layer_index=10, only_activate_used_experts=False, merge_ratio=ratio, loss_names={})
     plans = []
-    M.merge_weights(sd, cfg, plan_out=plans)
+    merged = M.merge_weights(sd, cfg, plan_out=plans)
     plan = plans[0]
     assert plan.bytes_read + plan.bytes_written == ALGO_BYTES
     for _ in range(warmup):
@@ -53,8 +56,15 @@ def run(reps=20, warmup=3, ratio=0.5):
         e1.synchronize()
         times.append(e0.elapsed_time(e1) * 1e-3)
     med = statistics.median(times)
-    return {"kernel": "vlm_merge_kernel", "seconds_median": med, "seconds_min": min(times),
-            "algorithmic_bytes": ALGO_BYTES, "GBps": ALGO_BYTES / med / 1e9, "reps": reps}
+    res = {"kernel": "vlm_merge_kernel", "seconds_median": med, "seconds_min": min(times),
+           "algorithmic_bytes": ALGO_BYTES, "GBps": ALGO_BYTES / med / 1e9, "reps": reps}
+    if check_layers is not None:
+        def layer(k):
+            return int(k.split(".")[2])
+        res["check"] = ({k: v for k, v in sd.items() if layer(k) in check_layers},
+                        {k: v for k, v in merged.items() if "transformer.blocks." in k and layer(k) in check_layers}, cfg,
+                        tuple(check_layers))
+    return res
 
 
 if __name__ == "__main__":
