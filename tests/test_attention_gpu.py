@@ -99,6 +99,7 @@ CASES = [
     dict(B=3, n0=40, n1=0, H=3),
     dict(B=1, n0=12, n1=70, H=1),
     dict(B=2, n0=40, n1=577, H=12),
+    dict(B=2, n0=40, n1=901, H=2),   # 480^2 (the reference's VQA geometry, README.md:194-223): 941 positions, 8 stationary tiles
 ]
 
 
@@ -296,3 +297,60 @@ def test_attention_with_an_image_keep_mask(ops, L, sep):
     assert float(img[:, -37:, D:].abs().max()) == 0.0
     a, b = dbias_t[layer * H:(layer + 1) * H], tab.grad.t()[layer * H:(layer + 1) * H]
     assert bool(((a - b).abs() <= 2e-2 * float(b.abs().max()) + 2e-2 * b.abs()).all())
+
+
+def test_attention_480_geometry_with_the_reference_index_and_ragged_masks(ops, L, pkg, golden_dir):
+    """N = 941 (480^2, 30 x 30 patches) at the benchmark's batch of 22 with ragged text masks, on the REFERENCE's own index
+    (index_buffers.npz `text_imag_relative_position_index_480`, R = 3 878 rows): forward, dQ / dK / dV and the bias-table gradient
+    against the fp32 restatement -- the int16 offsets (4 R = 15 512), the histogram's LDS bound and the tiling at 8 stationary
+    tiles are exercised, not only argued."""
+    import os
+    import numpy as np
+    vm = importlib.import_module("vl_merging_amd.vilt.modules.vilt_module")
+    z = np.load(os.path.join(golden_dir, "index_buffers.npz"))
+    ref_idx = torch.from_numpy(z["text_imag_relative_position_index_480"]).long()
+    B, n0, n1, H = 22, 40, 901, 2
+    R = int(ref_idx.max()) + 1
+    assert R == 59 * 59 + 3 + 392 + 2
+    c = build_case(B, n0, n1, H, seed=480)
+    m16, m16t = vm._index16(ref_idx.float(), n0)          # the model's own conversion (index coordinates, x 4)
+    g = torch.Generator(device="cuda"); g.manual_seed(481)
+    c["table"] = torch.randn(R, 2 * H, device="cuda", generator=g)
+    c["R"] = R
+    pos1 = c["pos1"]
+    NP = pos1 + n1
+    idx = torch.zeros(NP, (NP + 3) // 4 * 4, dtype=torch.int16, device="cuda")
+    pos = torch.cat([torch.arange(n0), pos1 + torch.arange(n1)]).cuda()
+    idx[pos[:, None], pos[None, :]] = ref_idx.to(torch.int16).cuda()
+    c["idx"] = idx
+    assert torch.equal(m16.cuda()[pos][:, pos].long(), 4 * ref_idx.cuda()) and torch.equal(m16t.cuda()[pos][:, pos].long(), 4 * ref_idx.cuda().t())
+    seq = ops.Seq(B, n0, n1)
+    rows, D, layer = seq.rows, c["D"], 1
+    out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(H, rows, device="cuda")
+    bias_t = c["table"].t().contiguous()
+    kw = dict(bias_t=bias_t, head_row0=layer * H, rel_index=m16.cuda().contiguous(), rel_index_t=m16t.cuda().contiguous(),
+              keep0=c["keep0"], mode=L.ATTN_JOINT)
+    ops.attention_fwd(c["qkv"], out, lse, seq, H, **kw)
+    dout = torch.randn(rows, D, device="cuda", generator=g).to(torch.bfloat16)
+    dqkv = torch.zeros(rows, 3 * D, device="cuda", dtype=torch.bfloat16)
+    dbias_t = torch.zeros_like(bias_t)
+    ops.attention_bwd(c["qkv"], out, dout, lse, dqkv, seq, H, dbias_t=dbias_t, **kw)
+    torch.cuda.synchronize()
+    q32 = c["qkv"].float().requires_grad_(True)
+    tab = c["table"].clone().requires_grad_(True)
+    cc = dict(c); cc["table"] = tab
+    ref_o, _, _ = reference(cc, layer, False, qkv=q32)
+    vmax = float(c["qkv"].float().abs().max())
+    err = (out.float() - ref_o.detach()).abs()
+    assert bool((err <= 2e-2 * vmax + 1e-2 * ref_o.detach().abs()).all()), "forward max err %.4g" % float(err.max())
+    (ref_o * dout.float()).sum().backward()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        a, b = dqkv[:, sl].float(), q32.grad[:, sl]
+        e = (a - b).abs()
+        assert bool((e <= 3e-2 * float(b.abs().max()) + 3e-2 * b.abs()).all()), "%s max err %.4g" % (name, float(e.max()))
+    a, b = dbias_t[layer * H:(layer + 1) * H], tab.grad.t()[layer * H:(layer + 1) * H]
+    e = (a - b).abs()
+    assert bool((e <= 2e-2 * float(b.abs().max()) + 2e-2 * b.abs()).all()), "dbias max err %.4g (ref max %.4g)" % (
+        float(e.max()), float(b.abs().max()))
+    assert float(dbias_t[:H].abs().max()) == 0.0

@@ -63,7 +63,8 @@ def test_state_dict_keys_match_reference(cfgmod, vm, golden_dir, arch, tag, loss
 
 def test_index_buffers_bit_exact(vm, golden_dir):
     z = np.load(os.path.join(golden_dir, "index_buffers.npz"))
-    for tag, g in (("224", 14), ("384", 24)):
+    # 480: README.md:194-223 of the reference runs VQA with image_size=480 (a 30 x 30 window on the 384 ViT, N = 941)
+    for tag, g in (("224", 14), ("384", 24), ("480", 30)):
         idx, nrel, _, allrel = vm.build_relative_position_indices((g, g), 40, 196, 40)
         assert nrel == (2 * g - 1) ** 2 + 3 and allrel == nrel + 392 + 2
         for k, v in idx.items():
