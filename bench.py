@@ -31,6 +31,15 @@ HBM_PEAK_GBPS = 8000.0
 F64_MFMA_PEAK_TFLOPS = 78.6     # the Gram / RegMean leg's roofline (v_mfma_f64_16x16x4_f64)
 
 
+_T0 = time.time()
+
+
+def _phase(msg):
+    """Progress on stderr (the ONE JSON line owns stdout): which leg the run is in and how long it has been going."""
+    sys.stderr.write("[bench %7.1f s] %s\n" % (time.time() - _T0, msg))
+    sys.stderr.flush()
+
+
 def synthetic_batch(*a, **kw):
     """The synthetic batch of SURVEY.md 8(d): lives in the package (vl_merging_amd.synthetic) so that run.py does not import the
     benchmark; kept here as the name the tests and tools call."""
@@ -268,11 +277,13 @@ def cpu_baseline():
     ncpu = os.cpu_count() or 1
     cands = sorted({c for c in (16, 32, 64, ncpu) if c <= ncpu} or {ncpu})
     torch.set_num_threads(cands[0])
+    _phase("cpu baseline: warm-up iteration at %d threads (candidates %r)" % (cands[0], cands))
     _, oracle_loss = iteration()  # warm-up (allocator, oneDNN primitives); its loss is the parity gate's reference value
     sweep = {}
     for c in cands:
         torch.set_num_threads(c)
         sweep[c], _ = iteration()
+        _phase("cpu baseline: %d threads %.1f s per iteration" % (c, sweep[c]))
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     times = [sweep[best]] + [iteration()[0] for _ in range(3)]
@@ -285,6 +296,7 @@ def cpu_baseline():
                      "warm-up, one iteration per thread count in %r, then the median of 4 at the best count (%d threads)"
                      % (cands, best),
            "_oracle_loss": oracle_loss, "_sd": sd, "_batch": b}
+    _phase("cpu baseline: merge oracle")
     try:
         res["merge"] = cpu_merge_baseline()
     except Exception as e:  # the baseline must never take the GPU number down with it
@@ -300,6 +312,22 @@ TASKS = {
     "irtr": (("task_finetune_irtr_coco_square_randaug_base_image384",), 20, 353.5e9, {"ufo": 4, "all_moe": 4},
              "task_finetune_irtr_coco"),
 }
+
+
+def _standin_env(world):
+    """VLM_DDP_STANDIN="cus[:lds_kb[:gbps]]" (world size 1 only): every gradient bucket's collective is replaced by its
+    single-GPU stand-in -- k workgroups holding a CU each + a copy of the bucket on the communication stream
+    (ddp.FlatGradReducer(standin=...), tools/contention_sweep.py -> profiles/r05_contention.json)."""
+    v = os.environ.get("VLM_DDP_STANDIN", "")
+    if not v or world > 1:
+        return None
+    parts = v.split(":")
+    st = {"cus": int(parts[0])}
+    if len(parts) > 1:
+        st["lds_kb"] = int(parts[1])
+    if len(parts) > 2:
+        st["gbps"] = float(parts[2])
+    return st
 
 
 class TrainLeg:
@@ -324,7 +352,7 @@ class TrainLeg:
         self.reducer = ddp.FlatGradReducer(
             self.model, force_collectives=force_dist, sharded=os.environ.get("VLM_SHARDED", "0") != "0",  # ddp_sharded (run.py:231-232)
             comm_dtype=torch.bfloat16 if os.environ.get("VLM_GRAD_COMM", "fp32") == "bf16" else None,
-            collective=os.environ.get("VLM_GRAD_COLLECTIVE", "allreduce"))
+            collective=os.environ.get("VLM_GRAD_COLLECTIVE", "allreduce"), standin=_standin_env(world))
         # the embeddings' all-reduce overlaps the AdamW update of everything else (same wiring as run.py)
         self.reducer.attach(self.opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
         b = synthetic_batch(B, image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
@@ -695,6 +723,8 @@ def main():
     L_ = importlib.import_module("vl_merging_amd._lib")
     eng = importlib.import_module("vl_merging_amd.engine")
 
+    if rank == 0:
+        _phase("building %s %s B=%d %d^2 at world %d" % (args.task, args.arch, args.batch, args.image_size, world))
     leg = TrainLeg(mods, args.task, args.arch, args.batch, args.image_size, rank, world, dev, force_dist)
     reducer = leg.reducer
     timer = GemmTimer(ops)
@@ -709,7 +739,11 @@ def main():
         timer.on = use_timer and it % max(1, args.gemm_timer_every) == 0
         eng._WGRAD["enabled"] = side_default and not timer.on
 
+    if rank == 0:
+        _phase("timed region: %d warm-up + %d steps" % (args.warmup, args.steps))
     dt, loss = leg.timed(args.steps, args.warmup, dev, per_step)
+    if rank == 0:
+        _phase("timed region done: %.2f ms per step" % (dt / args.steps * 1e3))
     eng._WGRAD["enabled"] = side_default
     timer.on = False
     exposed_comm_ms = reducer.exposed_wait_ms() / max(1, args.steps)
@@ -736,7 +770,7 @@ def main():
                           "sharded_optimizer": reducer.sharded, "bytes_per_step": int(reducer.flat.numel) * (2 if reducer.comm_dtype is not None else 4),
                           "buckets": reducer.bucket_plan(),
                           "cu_budget": L_.get_lib().vlm_device_cus(),  # VLM_GEMM_CUS: CUs the GEMM grids plan for (RCCL takes the rest)
-                          "wgrad_side_stream": bool(side_default)},
+                          "wgrad_side_stream": bool(side_default), "standin": reducer.standin},
         }
         if args.image_size == 384:
             flop_per_sample = flop384
@@ -763,10 +797,13 @@ def main():
     secondary = {}
     if not args.no_secondary and args.image_size == 384:
         # every rank takes part: the other two data-parallel BASELINE workloads at this world size
+        if rank == 0:
+            _phase("secondary data-parallel legs")
         secondary.update(secondary_train_legs(mods, dev, rank, world, (args.task, args.arch), force_dist))
     if rank == 0:
         merge_check = None
         if not args.no_merge:
+            _phase("merge leg")
             bm = importlib.import_module("vl_merging_amd.bench_merge")
             m = bm.run(check_layers=(0, 11))
             merge_check = m.pop("check")
@@ -776,17 +813,21 @@ def main():
                                          "frac": m["GBps"] / HBM_PEAK_GBPS,
                                          "traffic": pmc_traffic("vlm_merge_kernel"), "kernel": "vlm_merge_kernel"}}
         if not args.no_secondary and world == 1 and not force_dist and args.image_size == 384:
+            _phase("secondary merge legs (task vector, RegMean, Gram capture)")
             secondary.update(secondary_benches(dev))
         if secondary:
             out["secondary"] = secondary
         cpu = None
         if not args.no_cpu_baseline and world == 1:
+            _phase("CPU baseline (oracle on the host cores)")
             try:
                 cpu = cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         if merge_check is not None or cpu is not None:
+            _phase("parity gates")
             out["parity"] = parity_gates(dev, mods, cpu, merge_check)
+        _phase("done")
         if cpu is not None:
             out["cpu_baseline"] = {k: v for k, v in cpu.items() if not k.startswith("_")}
     if world > 1 or force_dist:

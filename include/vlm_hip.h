@@ -33,7 +33,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 7
+#define VLM_ABI_VERSION 8
 int vlm_abi_version(void);
 /* Number of compute units grid sizing and split-K slice counts plan for, or negative error: the current device's count,
  * or the smaller budget set by VLM_GEMM_CUS=n (environment, read once) / vlm_set_cu_budget(n) -- room for RCCL's kernels
@@ -41,6 +41,10 @@ int vlm_abi_version(void);
  * order (the number of K slices of a wgrad). */
 int vlm_device_cus(void);
 int vlm_set_cu_budget(int cus);
+/* Measurement tool (no reference counterpart; run.py:263-288's DDP gets its contention from NCCL): `workgroups` workgroups of
+ * `threads` threads that each allocate `lds_bytes` of LDS and spin for `microseconds` on `stream` -- the single-GPU stand-in for
+ * the compute units a gradient collective's kernels hold during backward (ddp.FlatGradReducer(standin=...)). */
+int vlm_debug_occupy(int workgroups, int threads, int lds_bytes, int microseconds, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Checkpoint merge (K12/K13/K14-bias): modules/vilt_module.py:533-638 (merge_weights),
@@ -226,6 +230,32 @@ int vlm_colreduce_batch(const vlm_fold_job_t* jobs_host, int n_jobs, void* strea
 int vlm_layerscale_bwd(const float* dx, int lddx, const void* y_bf16, int ldy, const float* gamma,
                        const float* row_scale, int M, int D, void* dy_bf16, int lddy, float* dgamma, float* dbias,
                        float* workspace, size_t workspace_bytes, int* deferred_blocks, void* stream);
+/* LayerScale folded into the branch's output projection (vision_transformer.py:489-491, :586, :603:
+ * x = x + drop_path(gamma * branch(x)), the branch ending in attn.proj / mlp.fc2).  gamma (.) (a W^T + b) = a W'^T + b' with
+ * W' = diag(gamma) W and b' = gamma (.) b, so the forward / dgrad / wgrad GEMMs run on folded operands and the saved copy of
+ * the branch output (and the O(M N) pass over it) goes.  One job = one weight:
+ *   vlm_layerscale_fold:    shadow[n,k] = bf16(gamma[n] weight[n,k]);  bias_out[n] = gamma[n] bias[n]      (after every update)
+ *   vlm_layerscale_finish:  with the RAW sums raw_w = g^T a (= dL/dW') and raw_b = colsum(g) (= dL/db'), g = bf16(row_scale dx):
+ *                           dweight[n,:] += gamma[n] raw_w[n,:];  dbias[n] += gamma[n] raw_b[n];
+ *                           dgamma[n] += sum_k weight[n,k] raw_w[n,k] + bias[n] raw_b[n]   (atomic: experts share gamma);
+ *                           raw_w, raw_b are ZEROED (the call composes with gradient accumulation).
+ * gamma NULL = ones; bias / bias_out / raw_b / dbias / dgamma may be NULL; weight, raw_w, dweight 16-byte aligned, K % 4 == 0. */
+#define VLM_MAX_LAYERSCALE_JOBS 32
+typedef struct {
+  const float* weight;  /* fp32 master [N, K] */
+  const float* gamma;   /* [N] */
+  const float* bias;    /* [N] or NULL */
+  void* shadow;         /* fold: bf16 [N, K] out */
+  float* bias_out;      /* fold: [N] out or NULL */
+  float* raw_w;         /* finish: [N, K] in, zeroed */
+  float* raw_b;         /* finish: [N] in, zeroed, or NULL */
+  float* dweight;       /* finish: [N, K] accumulate */
+  float* dbias;         /* finish: [N] accumulate or NULL */
+  float* dgamma;        /* finish: [N] accumulate (atomic) or NULL */
+  int32_t N, K;
+} vlm_layerscale_job_t;
+int vlm_layerscale_fold(const vlm_layerscale_job_t* jobs_host, int n_jobs, void* stream);
+int vlm_layerscale_finish(const vlm_layerscale_job_t* jobs_host, int n_jobs, void* stream);
 /* out[n] += sum_m a[m,n] (bf16 a; N % 8 == 0): bias gradients of qkv / fc1 / heads. */
 int vlm_colsum_bf16(const void* a, int lda, int M, int N, float* out, void* stream);
 

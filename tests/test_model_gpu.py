@@ -89,6 +89,19 @@ def feat_close(got, ref, what, tol=1.7e-2):
     assert err <= tol * scale, "%s: max err %.4g vs scale %.4g" % (what, err, scale)
 
 
+def grad_elementwise_close(got, ref, name, tol_small=0.06, tol=0.05):
+    """Element-wise check of a sampled gradient tensor against the reference's: max |got - ref| relative to the tensor's
+    largest entry.  Bound = 3 x the largest error measured over the goldens (1.6 % at the tiny width: bf16 activations between
+    all kernels against the reference's fp32 CPU run); the measured value lands in parity_errors.json like the features'."""
+    err = float((got - ref).abs().max())
+    mx = float(ref.abs().max())
+    floor = 2.5e-4 if ref.numel() == 1 else 1e-6  # near-zero scalar (logit scale) gradients: see grad_norm_ok
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    rec = MEASURED.setdefault(test, {})
+    rec["grad elementwise max rel"] = max(rec.get("grad elementwise max rel", 0.0), max(0.0, err - floor) / (mx + 1e-30))
+    assert err <= (tol_small if mx <= 0.05 else tol) * mx + floor, (name, err, mx)
+
+
 @pytest.mark.parametrize("arch", ["ufo", "all_moe"])
 def test_infer_matches_reference_golden(mods, golden_dir, arch):
     gold = np.load(os.path.join(golden_dir, f"model_tiny_{arch}.npz"))
@@ -148,10 +161,7 @@ def test_training_step_matches_reference_golden(mods, golden_dir, arch):
             n = key[len("step/grad/"):]
             ref = torch.from_numpy(gold[key])
             got = named[n].grad.float().cpu()
-            err = float((got - ref).abs().max())
-            mx = float(ref.abs().max())
-            floor = 1e-4 if ref.numel() == 1 else 1e-6  # near-zero scalar (logit scale) gradients: see grad_norm_ok
-            assert err <= (0.2 if mx <= 0.05 else 0.15) * mx + floor, (n, err, mx)
+            grad_elementwise_close(got, ref, n)
 
 
 @pytest.mark.parametrize("arch", ["ufo", "all_moe"])
@@ -469,10 +479,7 @@ def test_base_width_matches_reference_golden(mods, golden_dir, arch):
             got = named[n].grad.float().cpu()
             if n == "relative_position_bias_table":
                 got = got[::8]
-            err = float((got - ref).abs().max())
-            mx = float(ref.abs().max())
-            floor = 2.5e-4 if ref.numel() == 1 else 1e-6  # near-zero scalar gradients: see grad_norm_ok
-            assert err <= (0.2 if mx <= 0.05 else 0.15) * mx + floor, (n, err, mx)
+            grad_elementwise_close(got, ref, n)
 
 
 def test_tolerances_are_stated_next_to_amp(golden_dir):

@@ -82,6 +82,15 @@ class AttnDesc(ctypes.Structure):
     ]
 
 
+class LayerScaleJob(ctypes.Structure):
+    _fields_ = [("weight", c_void_p), ("gamma", c_void_p), ("bias", c_void_p), ("shadow", c_void_p), ("bias_out", c_void_p),
+                ("raw_w", c_void_p), ("raw_b", c_void_p), ("dweight", c_void_p), ("dbias", c_void_p), ("dgamma", c_void_p),
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
+MAX_LAYERSCALE_JOBS = 32
+
+
 class VlmError(RuntimeError):
     pass
 
@@ -93,6 +102,9 @@ SIGNATURES = {
     "vlm_abi_version": (c_int, []),
     "vlm_device_cus": (c_int, []),
     "vlm_set_cu_budget": (c_int, [c_int]),
+    "vlm_debug_occupy": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
+    "vlm_layerscale_fold": (c_int, [ctypes.POINTER(LayerScaleJob), c_int, c_void_p]),
+    "vlm_layerscale_finish": (c_int, [ctypes.POINTER(LayerScaleJob), c_int, c_void_p]),
     "vlm_merge_plan_bytes": (c_size_t, [c_int, c_u64]),
     "vlm_merge_plan_upload": (c_int, [ctypes.POINTER(MergeJob), c_int, c_void_p, c_size_t, c_void_p]),
     "vlm_merge_run": (c_int, [c_void_p, c_void_p]),

@@ -33,6 +33,8 @@ struct attn_bwd_params_t {
   float* dv_colsum[2];    // same for dV (v_bias gradient)
 };
 
+#include "attention_bwd_dkvb.h"
+
 // ----------------------------------------------------------------------------------------------------- dQ kernel
 // Query-stationary: workgroup = 128 query positions of one (sample, head), lane <-> query, streams 64-key tiles.
 // Per 32-key block (exponent units, see attention_fwd.hip):
@@ -805,6 +807,40 @@ static void att_dbias_items(const attn_params_t& p, int& pairs, int& groups) {
   }
 }
 
+// ---- the fused dK / dV / bias-gradient launch (attention_bwd_dkvb.h): which form, how many sample groups -----------------------
+struct dkvb_plan_t {
+  int W;             // waves per workgroup (8: two per SIMD; 4 when the panel leaves room for four slots only); 0: does not apply
+  int panel_blocks, groups, items;
+  size_t lds;
+};
+static dkvb_plan_t dkvb_plan(const attn_params_t& p) {
+  dkvb_plan_t pl = {0, 0, 1, 0, 0};
+  static const int enabled = []() {  // VLM_ATT_BWD_FUSED=0: the round-2..4 pair attn_bwd_dkv_kernel + attn_bwd_dbias16_kernel (A/B)
+    const char* e = getenv("VLM_ATT_BWD_FUSED");
+    return e ? atoi(e) : 1;
+  }();
+  if (!enabled || !p.bias_t || !p.dense_t || !p.idx) return pl;
+  for (int W = 8; W >= 4; W -= 4) {
+    int pb;
+    const size_t lds = dkvb_lds_bytes(p, W, pb);
+    if (lds) { pl.W = W; pl.panel_blocks = pb; pl.lds = lds; break; }
+  }
+  if (!pl.W) return pl;
+  const dkvb_geom_t gm = dkvb_geom(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
+  const int nkb = gm.nkb[0] + gm.nkb[1];
+  int cus = vlm_device_cus();
+  if (cus <= 0) cus = 256;
+  // one workgroup per CU (the panel): sample groups only where heads x key blocks leave CUs idle (small models)
+  int g = cus / (nkb * p.H > 0 ? nkb * p.H : 1);
+  if (g < 1) g = 1;
+  const int per_round = pl.W;  // a group should hold at least one full round of samples
+  if (g > (p.seq.B + per_round - 1) / per_round) g = (p.seq.B + per_round - 1) / per_round;
+  if (g < 1) g = 1;
+  pl.groups = g;
+  pl.items = nkb * p.H * g;
+  return pl;
+}
+
 extern "C" size_t vlm_attention_bwd_ws_floats(const vlm_attn_desc_t* d, int with_dbias) {
   attn_params_t p;
   if (att_fill_params(d, p) != VLM_OK) return 0;
@@ -813,7 +849,10 @@ extern "C" size_t vlm_attention_bwd_ws_floats(const vlm_attn_desc_t* d, int with
   if (with_dbias && p.bias_t) {
     int pairs, groups;
     att_dbias_items(p, pairs, groups);
-    n += (size_t)pairs * p.H * groups * p.R;
+    size_t items = (size_t)pairs * p.H * groups;
+    const dkvb_plan_t pl = dkvb_plan(p);
+    if (pl.W && (size_t)pl.items > items) items = (size_t)pl.items;  // either form's per-item histograms fit
+    n += items * p.R;
   }
   return n;
 }
@@ -864,7 +903,29 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
 
   const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
   dim3 grid(att_grid_size(nt, p.seq.B, p.H)), block(ATT_THREADS);
-  if (p.bias_t) {
+  const dkvb_plan_t pl = want_dbias ? dkvb_plan(p) : dkvb_plan_t{0, 0, 1, 0, 0};
+  if (pl.W) {
+    // dQ (+ delta), then dK / dV and the bias-table gradient in ONE launch: 7 MFMA products per score instead of 9
+    bp.nstat = nullptr;  // (the 16-wave kernel's C operands are not needed)
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
+    VLM_CHECK_LAUNCH();
+    const size_t need = hr + (size_t)pl.items * p.R;
+    bp.dbias_part = ws_floats >= need ? delta_ws + hr : nullptr;
+    static bool attr_set[2] = {false, false};  // dynamic LDS beyond 64 KB has to be asked for once per kernel
+    if (pl.W == 8) {
+      if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkvb_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[0] = true; }
+      hipLaunchKernelGGL((attn_bwd_dkvb_kernel<8>), dim3((unsigned)((pl.items + 7) / 8 * 8)), dim3(512), pl.lds, s, bp, pl.groups, pl.panel_blocks);
+    } else {
+      if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkvb_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[1] = true; }
+      hipLaunchKernelGGL((attn_bwd_dkvb_kernel<4>), dim3((unsigned)((pl.items + 7) / 8 * 8)), dim3(256), pl.lds, s, bp, pl.groups, pl.panel_blocks);
+    }
+    if (bp.dbias_part) {
+      VLM_CHECK_LAUNCH();
+      const dkvb_geom_t gm = dkvb_geom(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
+      hipLaunchKernelGGL(attn_dbias_fold_kernel, dim3((p.R + 255) / 256, p.H), dim3(256), 0, s, bp.dbias_part, p.R, p.H, pl.groups,
+                         gm.nkb[0] + gm.nkb[1], dbias_t, p.head_row0);
+    }
+  } else if (p.bias_t) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
     VLM_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, s, bp);

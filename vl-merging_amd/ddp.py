@@ -45,7 +45,7 @@ class _WireHandle(_Works):
 
 class FlatGradReducer:
     def __init__(self, model, process_group=None, force_collectives=False, sharded=False, comm_dtype=None,
-                 collective="allreduce"):
+                 collective="allreduce", standin=None):
         """force_collectives: issue the all-reduces even at world size 1 (a single-GPU smoke test of the RCCL path).
         comm_dtype: None / torch.float32 -> the fp32 gradients travel as they are (what Lightning's DDP does with the
         reference's fp32 master gradients); torch.bfloat16 -> every bucket is cast into a bf16 wire buffer, reduced there
@@ -59,7 +59,13 @@ class FlatGradReducer:
         bucket), FusedAdamW keeps m / v only for those chunks and updates only them, and the updated fp32 parameters are
         ALL-GATHERED bucket by bucket after the step.  Same bytes on the wire as one all-reduce (reduce-scatter +
         all-gather is how RCCL's ring all-reduce is built), 1/W of the optimizer state and of the AdamW traffic."""
-        self.force = force_collectives
+        # standin (measurement tool, world size 1 only; DESIGN.md 6): dict(cus=k, lds_kb=.., gbps=..) -- every bucket's
+        # collective is REPLACED by what it would cost this GPU's other streams: k workgroups that hold a CU each for the time
+        # the bucket's bytes need at `gbps` per GPU (vlm_debug_occupy), and a device copy of the bucket (the HBM traffic of the
+        # local reduction), both on the communication stream behind the same waits a real collective has.
+        self.standin = dict(standin) if standin else None
+        self._standin_buf = None
+        self.force = force_collectives or bool(self.standin)
         self.sharded = bool(sharded)
         self.comm_dtype = comm_dtype if comm_dtype in (torch.bfloat16,) else None
         if collective not in ("allreduce", "rs_ag"):
@@ -169,6 +175,8 @@ class FlatGradReducer:
     def _reduce(self, lo, hi):
         """The gradient collective of one bucket (async): all-reduce, or reduce-scatter into the rank's own chunk.
         Returns an object with .wait() that makes the CURRENT stream see the reduced fp32 gradients of [lo, hi)."""
+        if self.standin is not None:
+            return self._standin_reduce(lo, hi)
         nccl = dist.get_backend(self.group) == "nccl"
         if self.comm_dtype is not None and not (self.sharded and self.world > 1):
             if self._wire is None:
@@ -186,6 +194,25 @@ class FlatGradReducer:
             # in the own chunk (the other chunks are ignored by the sharded optimizer)
             return dist.all_reduce(buf, group=self.group, async_op=True)
         return _Works(self._collect(buf, lo, hi, nccl))
+
+    def _standin_reduce(self, lo, hi):
+        from . import ops
+        st = self.standin
+        nbytes = (hi - lo) * 4
+        # a ring all-reduce over W ranks moves 2 (W - 1) / W of the bucket per GPU; W = 8 assumed
+        usec = int(2.0 * 7.0 / 8.0 * nbytes / (float(st.get("gbps", 300.0)) * 1e3)) + 1
+        if self._standin_buf is None or self._standin_buf.numel() < hi - lo:
+            self._standin_buf = torch.empty(max(hi - lo for lo, hi in self.buckets()), device=self.flat.flat_g.device,
+                                            dtype=torch.float32)
+        ops.debug_occupy(int(st.get("cus", 16)), 512, int(st.get("lds_kb", 64)) * 1024, usec)
+        self._standin_buf[:hi - lo].copy_(self.flat.flat_g[lo:hi])
+        ev = torch.cuda.Event()
+        ev.record()
+
+        class _Ev:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_event(ev)
+        return _Ev()
 
     def _collect(self, buf, lo, hi, nccl):
         """all-reduce of `buf` (the bucket [lo, hi) in its wire dtype) as one or two RCCL calls."""

@@ -636,3 +636,10 @@ def attention_bwd(qkv, out, dout, lse, dqkv, seq, H, *, bias_t=None, head_row0=0
                                        ctypes.byref(cs) if cs is not None else None, L.stream_ptr())
     L.check(rc, "vlm_attention_bwd")
     return dqkv
+
+
+def debug_occupy(workgroups, threads, lds_bytes, microseconds):
+    """Measurement tool: `workgroups` workgroups holding `lds_bytes` of LDS each spin for `microseconds` on the current stream
+    (vlm_debug_occupy; ddp.FlatGradReducer(standin=...))."""
+    L.check(L.get_lib().vlm_debug_occupy(int(workgroups), int(threads), int(lds_bytes), int(microseconds), L.stream_ptr()),
+            "vlm_debug_occupy")
