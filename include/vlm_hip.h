@@ -201,7 +201,8 @@ int vlm_layernorm_bwd(const void* dy, int lddy, int dy_is_f32, const float* x, i
  * operations in the same order as the two calls, bit for bit.  workspace / workspace_bytes in `scale`: its own partial
  * region (a second fold job when deferred: [deferred_blocks][2][D], dgamma then dbias). */
 typedef struct {
-  const void* y;          /* bf16 [M, D]: the branch's saved output (incl. its bias) */
+  const void* y;          /* bf16 [M, D]: the branch's saved output (incl. its bias); NULL = the LayerScale is folded into the
+                             branch's projection (vlm_layerscale_fold): gamma and dgamma must be NULL too, dy = bf16(row_scale dx) */
   int32_t ldy;
   const float* gamma;     /* LayerScale vector [D] or NULL (ones) */
   const float* row_scale; /* DropPath row factors [M] or NULL */
@@ -226,7 +227,8 @@ typedef struct {
 } vlm_fold_job_t;
 int vlm_colreduce_batch(const vlm_fold_job_t* jobs_host, int n_jobs, void* stream);
 /* Backward of x_new = x + row_scale[m]*gamma[n]*y[m,n] (vision_transformer.py:586,:603) w.r.t. the branch:
- *   dy = bf16(row_scale*gamma*dx); dgamma[n] += sum_m row_scale*dx*y; dbias[n] += sum_m dy. */
+ *   dy = bf16(row_scale*gamma*dx); dgamma[n] += sum_m row_scale*dx*y; dbias[n] += sum_m dy.
+ * y_bf16 NULL (dgamma NULL): only dy and its column sums -- the folded form of vlm_layerscale_fold (gamma normally NULL). */
 int vlm_layerscale_bwd(const float* dx, int lddx, const void* y_bf16, int ldy, const float* gamma,
                        const float* row_scale, int M, int D, void* dy_bf16, int lddy, float* dgamma, float* dbias,
                        float* workspace, size_t workspace_bytes, int* deferred_blocks, void* stream);

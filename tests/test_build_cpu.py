@@ -41,7 +41,7 @@ def resources():
 
 def test_big_gemm_accumulators_stay_in_agprs(resources):
     big = {k: v for k, v in resources.items() if "vlm_gemm_big_kernel" in k}
-    assert len(big) == 10, sorted(big)  # six plain + the four GROUPED variants a block uses
+    assert len(big) == 11, sorted(big)  # six plain + the five GROUPED variants a block uses (round 5: + residual without aux)
     for name, r in big.items():
         assert r["AGPRs"] == 256, (name, r)            # the 4 x 64 accumulator registers of a 128x128 wave tile
         assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (name, r)
@@ -62,5 +62,7 @@ def test_attention_kernels_keep_their_occupancy(resources):
     occ = {k: v["Occupancy"] for k, v in resources.items() if "attn_" in k and "kernel" in k}
     assert occ, "no attention kernels recorded"
     for name, o in occ.items():
+        if "attn_bwd_dkvb_kernelILi4E" in name:
+            continue  # the four-wave form of the fused dK/dV + bias-gradient kernel (480^2 panels): one wave per SIMD by design
         if "attn_fwd_kernel" in name or "attn_bwd_dq" in name or "attn_bwd_dkv" in name or "attn_bwd_dbias" in name:
             assert o >= 2, (name, o)

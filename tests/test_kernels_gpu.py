@@ -910,3 +910,45 @@ def test_cross_entropy_counts_only_the_rows_the_kernels_score(pkg, ops):
     labels_bad[12:] = torch.tensor([V, V + 7, -5, 100000], device="cuda")
     mixed = engine.cross_entropy(logits, labels_bad)
     assert abs(float(mixed) - float(good)) <= 1e-6 * max(1.0, abs(float(good)))
+
+
+@pytest.mark.parametrize("M,N,K,with_rs", [(700, 192, 192, True), (1300, 768, 3072, False), (300, 768, 768, True)])
+def test_layerscale_fold_and_finish_match_autograd(pkg, ops, M, N, K, with_rs):
+    """LayerScale folded into the branch's output projection (csrc/layerscale.hip; vision_transformer.py:489-491, :586, :603):
+    forward x + rs * (a W'^T + b') with W' = diag(gamma) W, b' = gamma * b; backward from the RAW sums G = g^T a, s = colsum(g),
+    g = bf16(rs * dx):  dW = gamma G,  db = gamma s,  dgamma = sum_k W G + b s  -- against torch autograd of the unfolded
+    x + rs * gamma * (a W^T + b) in fp32 (tolerances: the operands are bf16 in the kernels)."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(M + N)
+    W = torch.randn(N, K, device="cuda", generator=gen) * 0.05
+    b = torch.randn(N, device="cuda", generator=gen) * 0.1
+    gamma = 0.1 + 0.05 * torch.randn(N, device="cuda", generator=gen)
+    a = bf(torch.randn(M, K, device="cuda", generator=gen))
+    x = torch.randn(M, N, device="cuda", generator=gen)
+    dx = torch.randn(M, N, device="cuda", generator=gen)
+    rs = ((torch.rand(M, device="cuda", generator=gen) > 0.3).float() / 0.7) if with_rs else None
+    # ---- reference
+    Wr, br, gr = W.clone().requires_grad_(True), b.clone().requires_grad_(True), gamma.clone().requires_grad_(True)
+    y = a.float() @ Wr.t() + br
+    out_ref = x + (rs[:, None] if rs is not None else 1.0) * gr * y
+    (out_ref * dx).sum().backward()
+    # ---- folded path
+    shadow = torch.empty(N, K, device="cuda", dtype=torch.bfloat16)
+    bfold = torch.empty(N, device="cuda")
+    ops.layerscale_fold([dict(weight=W, gamma=gamma, bias=b, shadow=shadow, bias_out=bfold)])
+    assert torch.equal(shadow, (gamma[:, None] * W).to(torch.bfloat16)) and torch.equal(bfold, gamma * b)
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm(a, shadow, out, bias=bfold, row_scale=rs, residual=x)
+    assert_close(out, out_ref.detach(), 2e-2, 2e-2 * float((out_ref.detach() - x).abs().max()), "folded forward")
+    g = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    raw_w = torch.zeros(N, K, device="cuda"); raw_b = torch.zeros(N, device="cuda")
+    ops.layerscale_bwd(dx, None, None, rs, g, None, raw_b)
+    want_g = ((rs[:, None] if rs is not None else 1.0) * dx).to(torch.bfloat16)
+    assert torch.equal(g, want_g)
+    ops.gemm(g, a, raw_w, ta=True, tb=True, accumulate=True)
+    dW = torch.full((N, K), 0.25, device="cuda"); db = torch.full((N,), -0.5, device="cuda"); dg = torch.full((N,), 2.0, device="cuda")
+    ops.layerscale_finish([dict(weight=W, gamma=gamma, bias=b, raw_w=raw_w, raw_b=raw_b, dweight=dW, dbias=db, dgamma=dg)])
+    torch.cuda.synchronize()
+    assert float(raw_w.abs().max()) == 0.0 and float(raw_b.abs().max()) == 0.0  # zeroed: composes with accumulation
+    assert_close(dW - 0.25, Wr.grad, 2e-2, 1e-2 * float(Wr.grad.abs().max()), "dW")
+    assert_close(db + 0.5, br.grad, 2e-2, 1e-2 * float(br.grad.abs().max()), "db")
+    assert_close(dg - 2.0, gr.grad, 2e-2, 1e-2 * float(gr.grad.abs().max()), "dgamma")

@@ -1370,8 +1370,8 @@ static int launch_gemm_big_variant(const gemm_params_t& p, bool c_is_f32, hipStr
   }
   if (c_is_f32 && aux != 2) {
     if (res && aux) return launch_gemm_big<true, true, 1, GROUPED>(p, s);
+    if (res) return launch_gemm_big<true, true, 0, GROUPED>(p, s);  // round 5: the folded-LayerScale residual epilogue saves no aux
     if (GROUPED) return 1;
-    if (res) return launch_gemm_big<true, true, 0>(p, s);
     if (aux == 0) return launch_gemm_big<true, false, 0>(p, s);
   }
   return 1;

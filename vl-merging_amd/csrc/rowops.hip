@@ -117,7 +117,9 @@ struct ls_t {
   float* dbias;
   float* partials;
 };
-template <int MAXU, bool DY_BF16, bool SCALE = false>
+// SCALE == 2 (round 5): that LayerScale is folded into the branch's output projection (layerscale.hip) -- ls.y / ls.gamma are
+// absent, only dy = bf16(row_scale * dx) and its column sums are taken with the row (one more accumulator set instead of two).
+template <int MAXU, bool DY_BF16, int SCALE = 0>
 __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void ln_bwd_kernel(const void* __restrict__ dy, int lddy,
                                                              const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ stats,
@@ -129,13 +131,15 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void 
   __shared__ float red[ROW_WAVES][SCALE ? 4 : 2][MAXU * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 g[SCALE ? 1 : MAXU], ag[MAXU], ab[MAXU];
-  f32x4 g2[1], ag2[SCALE ? MAXU : 1], ab2[SCALE ? MAXU : 1];
+  f32x4 g2[1], ag2[SCALE == 1 ? MAXU : 1], ab2[SCALE ? MAXU : 1];
   if (SCALE) g[0] = (f32x4){1.f, 1.f, 1.f, 1.f};
   else load_vec<SCALE ? 1 : MAXU>(gamma, D, lane, g, 1.0f);
 #pragma unroll
   for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < (SCALE ? MAXU : 1); ++u) ag2[u] = ab2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < (SCALE ? MAXU : 1); ++u) ab2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < (SCALE == 1 ? MAXU : 1); ++u) ag2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float invD = 1.0f / (float)D;
   for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
     f32x4 v[MAXU], d[MAXU], rs[MAXU];
@@ -144,10 +148,10 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void 
     // the residual-path gradient is fetched with the row, not after the two wave reductions (its latency used to sit
     // between the reduction and the store of every row)
     if (dres) load_row<MAXU, false, ROW_NT>(dres, row, lddres, D, lane, rs);
-    f32x4 yy[SCALE ? MAXU : 1];
+    f32x4 yy[SCALE == 1 ? MAXU : 1];
     float srow = 1.0f;
     if (SCALE) {
-      load_row<SCALE ? MAXU : 1, true, ROW_NT>(ls.y, row, ls.ldy, D, lane, yy);
+      if (SCALE == 1) load_row<SCALE == 1 ? MAXU : 1, true, ROW_NT>(ls.y, row, ls.ldy, D, lane, yy);
       if (ls.row_scale) srow = ls.row_scale[row];
     }
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
@@ -184,13 +188,13 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void 
         if (SCALE) {  // the same operations, in the same order, as scale_bwd_kernel on the stored row
           // (the branch's gamma is re-read per row from the cache: twelve registers held across the loop cost the third workgroup per CU)
           const int c2 = lane * 4 + 256 * u;
-          g2[0] = ls.gamma ? *reinterpret_cast<const f32x4*>(ls.gamma + c2) : (f32x4){1.f, 1.f, 1.f, 1.f};
+          g2[0] = (SCALE == 1 && ls.gamma) ? *reinterpret_cast<const f32x4*>(ls.gamma + c2) : (f32x4){1.f, 1.f, 1.f, 1.f};
           bf16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sd = srow * o[r];
             const float q = sd * g2[0][r];
-            ag2[u][r] += sd * yy[u][r];
+            if (SCALE == 1) ag2[SCALE == 1 ? u : 0][r] += sd * yy[SCALE == 1 ? u : 0][r];
             h[r] = (bf16_t)q;
             ab2[u][r] += (float)h[r];
           }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(ROW_THREADS, MAXU <= 3 ? (SCALE ? 3 : 4) : 2) void 
     for (int u = 0; u < (SCALE ? MAXU : 1); ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        red[wave][SCALE ? 2 : 0][u * 256 + lane * 4 + r] = ag2[u][r];
+        red[wave][SCALE ? 2 : 0][u * 256 + lane * 4 + r] = SCALE == 1 ? ag2[SCALE == 1 ? u : 0][r] : 0.f;
         red[wave][SCALE ? 3 : 1][u * 256 + lane * 4 + r] = ab2[u][r];
       }
   }
@@ -316,7 +320,9 @@ extern "C" int vlm_colreduce_batch(const vlm_fold_job_t* jobs, int n_jobs, void*
 // forward was x_new = x + rs[m]*gamma[n]*y[m,n]  (y = branch output incl. its bias, saved in bf16)
 //   dy[m,n]   = rs[m]*gamma[n]*dx[m,n]          (bf16, feeds the dgrad/wgrad GEMMs)
 //   dgamma[n] += sum_m rs[m]*dx[m,n]*y[m,n]  ;  dbias[n] += sum_m dy[m,n]
-template <int MAXU>
+// CAST (y == NULL, round 5): the LayerScale is folded into the branch's output projection (layerscale.hip) -- only
+// dy = bf16(rs * dx) and its column sums remain (6 instead of 8 B per element, one accumulator set).
+template <int MAXU, bool CAST = false>
 __global__ __launch_bounds__(ROW_THREADS) void scale_bwd_kernel(const float* __restrict__ dx, int lddx,
                                                                 const bf16_t* __restrict__ y, int ldy,
                                                                 const float* __restrict__ gamma,
@@ -327,14 +333,16 @@ __global__ __launch_bounds__(ROW_THREADS) void scale_bwd_kernel(const float* __r
                                                                 float* __restrict__ partials) {
   __shared__ float red[ROW_WAVES][2][MAXU * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 g[MAXU], ag[MAXU], ab[MAXU];
+  f32x4 g[MAXU], ag[CAST ? 1 : MAXU], ab[MAXU];
   load_vec<MAXU>(gamma, D, lane, g, 1.0f);
 #pragma unroll
-  for (int u = 0; u < MAXU; ++u) ag[u] = ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < MAXU; ++u) ab[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < (CAST ? 1 : MAXU); ++u) ag[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (size_t row = (size_t)blockIdx.x * ROW_WAVES + wave; row < (size_t)M; row += (size_t)gridDim.x * ROW_WAVES) {
-    f32x4 d[MAXU], yy[MAXU];
+    f32x4 d[MAXU], yy[CAST ? 1 : MAXU];
     load_row<MAXU, false>(dx, row, lddx, D, lane, d);
-    load_row<MAXU, true, ROW_NT>(y, row, ldy, D, lane, yy);
+    if (!CAST) load_row<CAST ? 1 : MAXU, true, ROW_NT>(y, row, ldy, D, lane, yy);
     const float rs = row_scale ? row_scale[row] : 1.0f;
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(ROW_THREADS) void scale_bwd_kernel(const float* __r
         for (int r = 0; r < 4; ++r) {
           const float sd = rs * d[u][r];
           const float o = sd * g[u][r];
-          ag[u][r] += sd * yy[u][r];
+          if (!CAST) ag[CAST ? 0 : u][r] += sd * yy[CAST ? 0 : u][r];
           h[r] = (bf16_t)o;
           ab[u][r] += (float)h[r];  // the bias gradient the GEMMs see is the rounded dy
         }
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(ROW_THREADS) void scale_bwd_kernel(const float* __r
   for (int u = 0; u < MAXU; ++u)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      red[wave][0][u * 256 + lane * 4 + r] = ag[u][r];
+      red[wave][0][u * 256 + lane * 4 + r] = CAST ? 0.f : ag[CAST ? 0 : u][r];
       red[wave][1][u * 256 + lane * 4 + r] = ab[u][r];
     }
   __syncthreads();
@@ -441,13 +449,14 @@ static int layernorm_bwd_impl(const void* dy, int lddy, int dy_is_f32, const flo
   // one round of resident workgroups: D <= 768 runs at 4 waves/SIMD (<= 128 VGPRs) = 4 workgroups per CU
   const int resident = (D <= 768 ? 4 : 2) * (vlm_device_cus() > 0 ? vlm_device_cus() : 256);
   if (g > resident) g = resident;
-  if (sc && D <= 768 && g > resident * 3 / 4) g = resident * 3 / 4;  // the fused form holds two more accumulator sets: three workgroups per CU (167 registers)
+  if (sc && D <= 768 && g > resident * 3 / 4) g = resident * 3 / 4;  // the fused forms hold one or two more accumulator sets: three workgroups per CU (140 / 167 registers)
   float* part = (workspace && workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && (dgamma || dbeta)) ? workspace : nullptr;
   dim3 grid(g), block(ROW_THREADS);
   hipStream_t s = (hipStream_t)stream;
   ls_t ls = {};
   if (sc) {
-    if (!sc->y || !sc->dy || (sc->ldy & 3) || (sc->lddy & 3)) return VLM_ERR_ARG;
+    if (!sc->dy || (sc->y && (sc->ldy & 3)) || (sc->lddy & 3)) return VLM_ERR_ARG;
+    if (!sc->y && (sc->gamma || sc->dgamma)) return VLM_ERR_ARG;  // the folded form (y == NULL) has no column scale of its own
     const bool want = sc->dgamma || sc->dbias;
     float* part2 = (sc->workspace && sc->workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && want) ? sc->workspace : nullptr;
     if (deferred_blocks && want && !part2) return VLM_ERR_ARG;  // deferral needs both partial workspaces
@@ -456,8 +465,9 @@ static int layernorm_bwd_impl(const void* dy, int lddy, int dy_is_f32, const flo
   }
 #define LN_BWD(U, B)                                                                                                             \
   do {                                                                                                                           \
-    if (sc) hipLaunchKernelGGL((ln_bwd_kernel<U, B, true>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
-    else hipLaunchKernelGGL((ln_bwd_kernel<U, B, false>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
+    if (sc && sc->y) hipLaunchKernelGGL((ln_bwd_kernel<U, B, 1>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
+    else if (sc) hipLaunchKernelGGL((ln_bwd_kernel<U, B, 2>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<U, B, 0>), grid, block, 0, s, dy, lddy, x, ldx, stats, gamma, M, D, dres, lddres, dx, lddx, dgamma, dbeta, part, ls); \
   } while (0)
   if (D <= 256) { if (dy_is_f32) LN_BWD(1, false); else LN_BWD(1, true); }
   else if (D <= 768) { if (dy_is_f32) LN_BWD(3, false); else LN_BWD(3, true); }
@@ -502,15 +512,21 @@ extern "C" int vlm_layerscale_bwd(const float* dx, int lddx, const void* y, int 
                                   float* dbias, float* workspace, size_t workspace_bytes, int* deferred_blocks,
                                   void* stream) {
   if (M == 0) return VLM_OK;
-  if (!dx || !y || !dy || M < 0 || D <= 0 || (D & 3) || (lddx & 3) || (ldy & 3) || (lddy & 3)) return VLM_ERR_ARG;
+  if (!dx || !dy || M < 0 || D <= 0 || (D & 3) || (lddx & 3) || (y && (ldy & 3)) || (lddy & 3)) return VLM_ERR_ARG;
+  if (!y && dgamma) return VLM_ERR_ARG;  // y == NULL: the folded form, dy = bf16(row_scale * gamma * dx) and its column sums only
   if (D > 1024) return VLM_ERR_UNSUPPORTED;
   int g = row_grid(M);
   if (g > 1536) g = 1536;
   float* part = (workspace && workspace_bytes >= (size_t)g * 2 * D * sizeof(float) && (dgamma || dbias)) ? workspace : nullptr;
   dim3 grid(g), block(ROW_THREADS);
   hipStream_t s = (hipStream_t)stream;
-#define SC_BWD(U) hipLaunchKernelGGL((scale_bwd_kernel<U>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M, \
-                                    D, (bf16_t*)dy, lddy, dgamma, dbias, part)
+#define SC_BWD(U)                                                                                                                    \
+  do {                                                                                                                               \
+    if (y) hipLaunchKernelGGL((scale_bwd_kernel<U, false>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M,   \
+                              D, (bf16_t*)dy, lddy, dgamma, dbias, part);                                                            \
+    else hipLaunchKernelGGL((scale_bwd_kernel<U, true>), grid, block, 0, s, dx, lddx, (const bf16_t*)y, ldy, gamma, row_scale, M,      \
+                            D, (bf16_t*)dy, lddy, dgamma, dbias, part);                                                              \
+  } while (0)
   if (D <= 256) SC_BWD(1);
   else if (D <= 768) SC_BWD(3);
   else SC_BWD(4);

@@ -259,6 +259,9 @@ class FlatGradReducer:
         if self.counting or self.accumulate:
             return
         if self.seen[layer] == self.expected[layer]:
+            # folded LayerScale (engine.FlatParams.finish_layerscale): the block's raw sums become the gradients of W, b and
+            # gamma BEFORE its slice travels (the transform is linear, but a sharded rank only ever sees its own chunk of the sum)
+            self.flat.finish_layerscale(layer)
             self._launch(*self.block_slices[layer])
             if layer == self.last_layer:
                 for lo, hi in self.late_slices:

@@ -127,8 +127,77 @@ class FlatParams:
         self._tr_table, self._tr_tiles = ops.transpose_table(pairs) if pairs else (None, 0)
 
     def refresh_transposed(self):
+        self.refresh_folded()  # (the transposes are taken from the folded shadows)
         if getattr(self, "_tr_tiles", 0):
             ops.transpose_tiles(self._tr_table, self._tr_tiles)
+
+    # ---- LayerScale folded into the branch's output projection (csrc/layerscale.hip) ----------------------------------------
+    def enable_layerscale_fold(self, entries):
+        """entries: (layer, weight, bias or None, gamma) per output projection whose branch is scaled by `gamma`
+        (vision_transformer.py:489-491, :586, :603: attn.proj with gamma_1, mlp.fc2 with gamma_2, every expert).
+        From now on the weight's bf16 shadows hold diag(gamma) W, `bias._vlm_folded` holds gamma * b, the wgrad GEMMs
+        accumulate the RAW dL/dW' into `weight._vlm_raw` (and the row kernels colsum(g) into `bias._vlm_raw`), and
+        finish_layerscale() turns the raw sums into the gradients of W, b and gamma."""
+        if self.flat_b is None or not entries:
+            return
+        seen, total = set(), 0
+        uniq = []
+        for layer, w, b, g in entries:
+            if id(w) in seen:
+                continue
+            seen.add(id(w))
+            uniq.append((layer, w, b, g))
+            total += (w.numel() + ALIGN - 1) // ALIGN * ALIGN + 2 * ((w.shape[0] + ALIGN - 1) // ALIGN * ALIGN)
+        buf = torch.zeros(total, device=self.flat_p.device, dtype=F32)
+        off = 0
+        self._ls_jobs = {}
+
+        def take(n, shape):
+            nonlocal off
+            t = buf[off:off + n].view(shape)
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+            return t
+
+        for layer, w, b, g in uniq:
+            w._vlm_raw = take(w.numel(), w.shape)
+            raw_b = take(w.shape[0], (w.shape[0],))
+            folded_b = take(w.shape[0], (w.shape[0],))
+            if b is not None:
+                b._vlm_raw, b._vlm_folded = raw_b, folded_b
+            w._vlm_ls_gamma = g
+            self._ls_jobs.setdefault(layer, []).append(dict(
+                weight=w.data, gamma=g.data, bias=b.data if b is not None else None, shadow=w._vlm_bf16,
+                bias_out=folded_b if b is not None else None, raw_w=w._vlm_raw, raw_b=raw_b if b is not None else None,
+                dweight=w.grad, dbias=b.grad if b is not None else None, dgamma=g.grad))
+        self._ls_buf = buf
+        self.ls_pending = set()
+
+    def refresh_folded(self):
+        jobs = getattr(self, "_ls_jobs", None)
+        if jobs:
+            ops.layerscale_fold([j for layer in sorted(jobs) for j in jobs[layer]])
+
+    def finish_layerscale(self, layer=None):
+        """Raw sums -> gradients for `layer` (all pending layers when None), on the weight-gradient stream (behind the wgrad
+        GEMMs that wrote the raw sums; the gradient reducer's buckets and the optimizer wait for that stream anyway)."""
+        pend = getattr(self, "ls_pending", None)
+        if not pend:
+            return
+        layers = sorted(pend) if layer is None else ([layer] if layer in pend else [])
+        if not layers:
+            return
+        jobs = [j for i in layers for j in self._ls_jobs.get(i, ())]
+        side = wgrad_stream()
+        if side is None:
+            ops.layerscale_finish(jobs)
+        else:
+            side.wait_stream(torch.cuda.current_stream())  # the row kernels' column sums (raw_b) come from the main stream
+            with torch.cuda.stream(side):
+                ops.layerscale_finish(jobs)
+            if not _WGRAD["pending"]:  # outside a backward pass nobody is going to join the side stream for us
+                torch.cuda.current_stream().wait_stream(side)
+        for i in layers:
+            pend.discard(i)
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -540,7 +609,49 @@ def _qkv_bias(e):
 _FUSE_LN_SCALE = os.environ.get("VLM_FUSE_LN_SCALE", "1") != "0"
 
 
+# LayerScale folded into attn.proj / mlp.fc2 (csrc/layerscale.hip, FlatParams.enable_layerscale_fold): the residual epilogues of
+# the two forward GEMMs lose their column scale and their bf16 copy of the branch output, the LayerScale backward shrinks to a
+# cast (+ column sums), and dgamma comes from the weight gradient.  VLM_FOLD_LAYERSCALE=0: the round-1..4 form (A/B).
+_FOLD_LS = os.environ.get("VLM_FOLD_LAYERSCALE", "1") != "0"
+
+
+def _folded(ranges):
+    return _FOLD_LS and all(getattr(e.projw, "_vlm_raw", None) is not None and getattr(e.fc2w, "_vlm_raw", None) is not None
+                            for _, _, e in ranges)
+
+
+def _fb(b):
+    return b._vlm_folded if b is not None else None
+
+
+def _rb(b):
+    return b._vlm_raw if b is not None else None
+
+
+def _arm_layerscale_finish(flat):
+    """End of the running backward pass: raw sums -> gradients for every block the pass touched (a block whose bucket the
+    gradient reducer has sent already was finished there)."""
+    if getattr(flat, "_ls_armed", False):
+        return
+    flat._ls_armed = True
+
+    def done():
+        flat._ls_armed = False
+        flat.finish_layerscale()
+        sync_wgrad()  # the gradients are written on the side stream: whoever reads .grad next on this stream sees them
+
+    torch.autograd.Variable._execution_engine.queue_callback(done)
+
+
 def _ln2_bwd_scale1(dln, x1, st2, e, dx1, dx2, y1, g1, rs1, dy1, fold):
+    if y1 is None:  # folded LayerScale: dy1 = bf16(rs1 * dx1) and its column sums (the raw proj-bias gradient)
+        if _FUSE_LN_SCALE and x1.shape[1] <= 768:
+            ops.layernorm_bwd_scale(dln, x1, st2, e.n2w, dx1, dx2, e.n2w.grad, e.n2b.grad, y=None, sgamma=None, row_scale=rs1,
+                                    sdy=dy1, dsgamma=None, dsbias=_rb(e.projb), fold=fold)
+        else:
+            ops.layernorm_bwd(dln, x1, st2, e.n2w, dx1, dres=dx2, dgamma=e.n2w.grad, dbeta=e.n2b.grad, fold=fold)
+            ops.layerscale_bwd(dx1, None, None, rs1, dy1, None, _rb(e.projb), fold=fold)
+        return
     if _FUSE_LN_SCALE and x1.shape[1] <= 768:  # (wider rows: the fused kernel's four accumulator sets spill)
         ops.layernorm_bwd_scale(dln, x1, st2, e.n2w, dx1, dx2, e.n2w.grad, e.n2b.grad, y=y1, sgamma=g1, row_scale=rs1, sdy=dy1,
                                 dsgamma=g1.grad, dsbias=e.projb.grad, fold=fold)
@@ -585,36 +696,43 @@ class _BlockFn(torch.autograd.Function):
                           rel_index_t=rp.index_t if rp is not None else None, keep0=pc.keep0, keep1=pc.keep1,
                           mode=plan.mode, bias_dense=rp.dense_for(pc.seq, plan.mode) if rp is not None else None)
         x1 = torch.empty(M, D, device=dev, dtype=F32)
-        y1 = torch.empty(M, D, device=dev, dtype=BF16)
+        folded = _folded(plan.ranges)
+        # folded: W' = diag(gamma) W and b' = gamma * b are the GEMM operands -- no column scale, no saved branch output
+        y1 = torch.empty(M, D, device=dev, dtype=BF16) if not folded else None
         ln2 = torch.empty(M, D, device=dev, dtype=BF16)
         st2 = torch.empty(M, 2, device=dev, dtype=F32)
         h = torch.empty(M, Fdim, device=dev, dtype=BF16)
         a = torch.empty(M, Fdim, device=dev, dtype=BF16)
         x2 = torch.empty(M, D, device=dev, dtype=F32)
-        y2 = torch.empty(M, D, device=dev, dtype=BF16)
+        y2 = torch.empty(M, D, device=dev, dtype=BF16) if not folded else None
+        cs1, cs2 = (None, None) if folded else (plan.gamma1, plan.gamma2)
+        pb = (lambda e: _fb(e.projb)) if folded else (lambda e: e.projb)
+        fb2 = (lambda e: _fb(e.fc2b)) if folded else (lambda e: e.fc2b)
         if grouped:
             rg = plan.ranges
-            ops.gemm_grouped(o, [(r0, r1, w16(e.projw), e.projb, None) for r0, r1, e in rg], x1, col_scale=plan.gamma1,
+            ops.gemm_grouped(o, [(r0, r1, w16(e.projw), pb(e), None) for r0, r1, e in rg], x1, col_scale=cs1,
                              row_scale=rs1, residual=x, aux=y1)
             for r0, r1, e in rg:
                 ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
             ops.gemm_grouped(ln2, [(r0, r1, w16(e.fc1w), e.fc1b, None) for r0, r1, e in rg], a,
                              act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h)
-            ops.gemm_grouped(a, [(r0, r1, w16(e.fc2w), e.fc2b, None) for r0, r1, e in rg], x2, col_scale=plan.gamma2,
+            ops.gemm_grouped(a, [(r0, r1, w16(e.fc2w), fb2(e), None) for r0, r1, e in rg], x2, col_scale=cs2,
                              row_scale=rs2, residual=x1, aux=y2)
         else:
             with _ExpertStreams(plan.ranges) as es:  # each expert's proj -> LayerNorm -> fc1 -> fc2 chain is independent
                 for idx, (r0, r1, e) in enumerate(plan.ranges):
                     with es.on(idx):
-                        ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=e.projb, col_scale=plan.gamma1,
-                                 row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1], aux=y1[r0:r1])
+                        ops.gemm(o[r0:r1], w16(e.projw), x1[r0:r1], bias=pb(e), col_scale=cs1,
+                                 row_scale=rs1[r0:r1] if rs1 is not None else None, residual=x[r0:r1],
+                                 aux=y1[r0:r1] if y1 is not None else None)
                         ops.layernorm_fwd(x1[r0:r1], e.n2w, e.n2b, plan.eps, ln2[r0:r1], st2[r0:r1])
                         # h = gelu'(pre-activation) (VLM_GELU_SAVE_DERIV, default): the forward epilogue has erf and exp in
                         # hand anyway, and the fc2-dgrad epilogue of the backward pass becomes a multiplication
                         ops.gemm(ln2[r0:r1], w16(e.fc1w), a[r0:r1], bias=e.fc1b,
                                  act=L.ACT_GELU_DERIV if _SAVE_DERIV else L.ACT_GELU, aux=h[r0:r1])
-                        ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=e.fc2b, col_scale=plan.gamma2,
-                                 row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1], aux=y2[r0:r1])
+                        ops.gemm(a[r0:r1], w16(e.fc2w), x2[r0:r1], bias=fb2(e), col_scale=cs2,
+                                 row_scale=rs2[r0:r1] if rs2 is not None else None, residual=x1[r0:r1],
+                                 aux=y2[r0:r1] if y2 is not None else None)
         if pc.gram is not None:
             # Gram cache: the LayerNorm outputs enter in fp32 (re-computed here, capture runs are not timed), like the
             # fp32 activations the reference's hooks see; the attention output and the GELU output exist only as the bf16
@@ -634,7 +752,9 @@ class _BlockFn(torch.autograd.Function):
                 pc.gram.add(gn.get("fc2"), a[r0:r1])
         ctx.plan, ctx.pc, ctx.hook = plan, pc, hook
         ctx.has_bias = bias_t is not None
-        ctx.save_for_backward(x, st1, ln1, qkv, o, lse, y1, x1, st2, ln2, h, a, y2,
+        ctx.folded = folded
+        ctx.save_for_backward(x, st1, ln1, qkv, o, lse, y1 if y1 is not None else x.new_empty(0), x1, st2, ln2, h, a,
+                              y2 if y2 is not None else x.new_empty(0),
                               rs1 if rs1 is not None else x.new_empty(0), rs2 if rs2 is not None else x.new_empty(0),
                               bias_t if bias_t is not None else x.new_empty(0))
         return x2
@@ -652,6 +772,14 @@ class _BlockFn(torch.autograd.Function):
         Fdim = h.shape[1]
         dx2 = dx2.contiguous()
         g1, g2 = plan.gamma1, plan.gamma2
+        folded = ctx.folded
+        if folded:
+            y1 = y2 = None
+            flat = plan.ranges[0][2].projw._vlm_flat
+            _arm_layerscale_finish(flat)
+        # folded: the wgrad GEMMs and the row kernels' column sums write the RAW sums (dL/dW', dL/db'); finish_layerscale turns
+        # them into the gradients of W, b and gamma once the block's last backward pass of the step has run
+        wg = (lambda w: w._vlm_raw) if folded else (lambda w: w.grad)
         touch(g1, g2)
         for _, _, e in plan.ranges:
             _touch_expert(e)
@@ -675,30 +803,37 @@ class _BlockFn(torch.autograd.Function):
             act_bwd = L.ACT_MUL_AUX if _SAVE_DERIV else L.ACT_GELU_BWD
             for r0, r1, e in rg:
                 rr = slice(r0, r1)
-                ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad,
-                                   fold=fold)
+                if folded:
+                    ops.layerscale_bwd(dx2[rr], None, None, rs2[rr] if rs2 is not None else None, dy2[rr], None, _rb(e.fc2b), fold=fold)
+                else:
+                    ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad, e.fc2b.grad,
+                                       fold=fold)
             ops.gemm_grouped(dy2, [(r0, r1, wT16(e.fc2w), None, e.fc1b.grad if fuse_b1 else None) for r0, r1, e in rg], dh,
                              act=act_bwd, aux=h, col_sum_fold=fold if fuse_b1 else None)
             if not fuse_b1:
                 for r0, r1, e in rg:
                     ops.colsum(dh[r0:r1], e.fc1b.grad)
             with _Side(dy2, a, dh, ln2):
-                ops.gemm_wgrad_grouped(dy2, a, [(r0, r1, e.fc2w.grad) for r0, r1, e in rg])
+                ops.gemm_wgrad_grouped(dy2, a, [(r0, r1, wg(e.fc2w)) for r0, r1, e in rg])
                 ops.gemm_wgrad_grouped(dh, ln2, [(r0, r1, e.fc1w.grad) for r0, r1, e in rg])
             ops.gemm_grouped(dh, [(r0, r1, wT16(e.fc1w), None, None) for r0, r1, e in rg], dln)
             for r0, r1, e in rg:
                 rr = slice(r0, r1)
-                _ln2_bwd_scale1(dln[rr], x1[rr], st2[rr], e, dx1[rr], dx2[rr], y1[rr], g1, rs1[rr] if rs1 is not None else None,
-                                dy1[rr], fold)
+                _ln2_bwd_scale1(dln[rr], x1[rr], st2[rr], e, dx1[rr], dx2[rr], y1[rr] if y1 is not None else None, g1,
+                                rs1[rr] if rs1 is not None else None, dy1[rr], fold)
             ops.gemm_grouped(dy1, [(r0, r1, wT16(e.projw), None, None) for r0, r1, e in rg], do)
             with _Side(dy1, o):
-                ops.gemm_wgrad_grouped(dy1, o, [(r0, r1, e.projw.grad) for r0, r1, e in rg])
+                ops.gemm_wgrad_grouped(dy1, o, [(r0, r1, wg(e.projw)) for r0, r1, e in rg])
         with _ExpertStreams(plan.ranges) as es:  # (grouped: nothing left for the per-expert chains -- no side stream either)
             for idx, (r0, r1, e) in enumerate(plan.ranges if not grouped else ()):
                 rr = slice(r0, r1)
                 with es.on(idx):
-                    ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad,
-                                       e.fc2b.grad, fold=fold)
+                    if folded:
+                        ops.layerscale_bwd(dx2[rr], None, None, rs2[rr] if rs2 is not None else None, dy2[rr], None, _rb(e.fc2b),
+                                           fold=fold)
+                    else:
+                        ops.layerscale_bwd(dx2[rr], y2[rr], g2, rs2[rr] if rs2 is not None else None, dy2[rr], g2.grad,
+                                           e.fc2b.grad, fold=fold)
                     # fc1 bias gradient = column sums of dh: per-tile sums from the epilogue that produces dh, folded with
                     # the block's other column partials (no atomics, no second pass over dh); without a fold batch: colsum
                     _dgrad(dy2[rr], e.fc2w, dh[rr], act=L.ACT_MUL_AUX if _SAVE_DERIV else L.ACT_GELU_BWD, aux=h[rr],
@@ -706,14 +841,14 @@ class _BlockFn(torch.autograd.Function):
                     if not fuse_b1:
                         ops.colsum(dh[rr], e.fc1b.grad)
                     with _Side(dy2, a, dh, ln2):
-                        ops.gemm(dy2[rr], a[rr], e.fc2w.grad, ta=True, tb=True, accumulate=True)
+                        ops.gemm(dy2[rr], a[rr], wg(e.fc2w), ta=True, tb=True, accumulate=True)
                         ops.gemm(dh[rr], ln2[rr], e.fc1w.grad, ta=True, tb=True, accumulate=True)
                     _dgrad(dh[rr], e.fc1w, dln[rr])
-                    _ln2_bwd_scale1(dln[rr], x1[rr], st2[rr], e, dx1[rr], dx2[rr], y1[rr], g1,
+                    _ln2_bwd_scale1(dln[rr], x1[rr], st2[rr], e, dx1[rr], dx2[rr], y1[rr] if y1 is not None else None, g1,
                                     rs1[rr] if rs1 is not None else None, dy1[rr], fold)
                     _dgrad(dy1[rr], e.projw, do[rr])
                     with _Side(dy1, o):
-                        ops.gemm(dy1[rr], o[rr], e.projw.grad, ta=True, tb=True, accumulate=True)
+                        ops.gemm(dy1[rr], o[rr], wg(e.projw), ta=True, tb=True, accumulate=True)
         dqkv = torch.empty(M, 3 * D, device=dev, dtype=BF16)
         dln1 = torch.empty(M, D, device=dev, dtype=BF16)
         rp = pc.relpos
@@ -754,6 +889,8 @@ class _BlockFn(torch.autograd.Function):
                                       dbeta=e.n1b.grad, fold=fold)
         if fold is not None:
             fold.flush()
+        if folded:
+            flat.ls_pending.add(plan.layer)
         if ctx.hook is not None:
             ctx.hook(plan.layer)
         dbias = None

@@ -273,7 +273,7 @@ def layernorm_bwd_scale(dy, x, stats, gamma, dx, dres, dgamma, dbeta, *, y, sgam
     else:
         ws, ws2 = _row_workspace(x.device, D), _row_workspace(x.device, D, slot=1)
     sc = L.LayerScale()
-    sc.y, sc.ldy, sc.gamma, sc.row_scale = L.ptr(y), _ld(y), L.ptr(sgamma), L.ptr(row_scale)
+    sc.y, sc.ldy, sc.gamma, sc.row_scale = L.ptr(y), _ld(y) if y is not None else 0, L.ptr(sgamma), L.ptr(row_scale)
     sc.dy, sc.lddy, sc.dgamma, sc.dbias = L.ptr(sdy), _ld(sdy), L.ptr(dsgamma), L.ptr(dsbias)
     sc.workspace, sc.workspace_bytes = L.ptr(ws2), ws2.numel() * 4
     rc = L.get_lib().vlm_layernorm_bwd_scale(L.ptr(dy), _ld(dy), int(dy.dtype == F32), L.ptr(x), _ld(x), L.ptr(stats),
@@ -290,11 +290,13 @@ def layernorm_bwd_scale(dy, x, stats, gamma, dx, dres, dgamma, dbeta, *, y, sgam
 
 
 def layerscale_bwd(dx, y, gamma, row_scale, dy, dgamma=None, dbias=None, fold=None):
+    """y None (then gamma / dgamma None too): the LayerScale is folded into the branch's projection (layerscale_fold): only
+    dy = bf16(row_scale * dx) and its column sums (the raw bias gradient) remain."""
     L.require_cuda(dx, y, gamma, row_scale, dy, dgamma, dbias)
     M, D = dx.shape
     ws = fold.next_region() if fold is not None else _row_workspace(dx.device, D)
     nb = ctypes.c_int(0)
-    rc = L.get_lib().vlm_layerscale_bwd(L.ptr(dx), _ld(dx), L.ptr(y), _ld(y), L.ptr(gamma), L.ptr(row_scale), M, D,
+    rc = L.get_lib().vlm_layerscale_bwd(L.ptr(dx), _ld(dx), L.ptr(y), _ld(y) if y is not None else 0, L.ptr(gamma), L.ptr(row_scale), M, D,
                                         L.ptr(dy), _ld(dy), L.ptr(dgamma), L.ptr(dbias), L.ptr(ws), ws.numel() * 4,
                                         ctypes.byref(nb) if fold is not None else None, L.stream_ptr())
     L.check(rc, "vlm_layerscale_bwd")
@@ -643,3 +645,32 @@ def debug_occupy(workgroups, threads, lds_bytes, microseconds):
     (vlm_debug_occupy; ddp.FlatGradReducer(standin=...))."""
     L.check(L.get_lib().vlm_debug_occupy(int(workgroups), int(threads), int(lds_bytes), int(microseconds), L.stream_ptr()),
             "vlm_debug_occupy")
+
+
+def _layerscale_jobs(jobs):
+    """jobs: dicts with the fields of vlm_layerscale_job_t (tensors or None); yields ctypes arrays of <= 32 jobs."""
+    for i in range(0, len(jobs), L.MAX_LAYERSCALE_JOBS):
+        chunk = jobs[i:i + L.MAX_LAYERSCALE_JOBS]
+        arr = (L.LayerScaleJob * len(chunk))()
+        for a, j in zip(arr, chunk):
+            w = j["weight"]
+            L.require_cuda(w, *[v for v in j.values() if torch.is_tensor(v)])
+            for f in ("weight", "gamma", "bias", "shadow", "bias_out", "raw_w", "raw_b", "dweight", "dbias", "dgamma"):
+                t = j.get(f)
+                setattr(a, f, t.data_ptr() if t is not None else None)
+            a.N, a.K = w.shape[0], w.shape[1]
+        yield arr, len(chunk)
+
+
+def layerscale_fold(jobs):
+    """W' = diag(gamma) W as the bf16 GEMM shadow, b' = gamma * b (vlm_layerscale_fold): dicts with weight, gamma, bias, shadow,
+    bias_out."""
+    for arr, n in _layerscale_jobs(jobs):
+        L.check(L.get_lib().vlm_layerscale_fold(arr, n, L.stream_ptr()), "vlm_layerscale_fold")
+
+
+def layerscale_finish(jobs):
+    """Raw sums of the folded GEMMs -> gradients of W, b and gamma; the raw buffers are zeroed (vlm_layerscale_finish): dicts with
+    weight, gamma, bias, raw_w, raw_b, dweight, dbias, dgamma."""
+    for arr, n in _layerscale_jobs(jobs):
+        L.check(L.get_lib().vlm_layerscale_finish(arr, n, L.stream_ptr()), "vlm_layerscale_finish")

@@ -232,6 +232,15 @@ class ViLTransformerSS(nn.Module):
         self._flat = engine.FlatParams(self, order_key=vilt_utils.flat_order_key)
         if os.environ.get("VLM_TRANSPOSED_SHADOWS", "1") != "0":  # A/B switch for measurements
             self._flat.enable_transposed(lambda n: n.startswith("transformer.blocks.") and n.endswith(".weight"))
+        if os.environ.get("VLM_FOLD_LAYERSCALE", "1") != "0":  # A/B switch for measurements
+            # gamma_1 / gamma_2 folded into attn.proj / mlp.fc2 of every expert (vision_transformer.py:489-491, :586, :603)
+            entries = []
+            for blk in self.transformer.blocks:
+                for mod, gamma in ((blk.attn, blk.gamma_1), (blk.mlp, blk.gamma_2)):
+                    for m in (mod.values() if isinstance(mod, nn.ModuleDict) else [mod]):
+                        lin = m.proj if hasattr(m, "proj") else m.fc2
+                        entries.append((blk.layer_number, lin.weight, lin.bias, gamma))
+            self._flat.enable_layerscale_fold(entries)
         self._flat.refresh_shadow()
         self._grad_hook = grad_hook
         return self._flat

@@ -251,8 +251,9 @@ class FusedAdamW:
 
     def step(self):
         self.step_count += 1
-        engine.sync_wgrad()
         f = self.flat
+        f.finish_layerscale()  # (normally done at the end of backward / before a bucket left: nothing pending)
+        engine.sync_wgrad()
         if not f.touched <= self._active:  # a pass reached parameters no earlier step had (first step, new task set)
             self._discover_active()
 
