@@ -338,6 +338,12 @@ int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* status, void* s
 int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* B, int ldb, int rows, int c0, void* stream);
 int vlm_cholesky_f64(double* A, int n, int* status, void* stream);
 int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, int ld, int rows, void* stream);
+/* The same factorisation / solve for `count` (<= 64) matrices of ONE shape in lock step: every block step is ONE launch over all of
+ * them (RegMean's 36 solves of 768^2 and 12 of 3072^2, vilt_module.py:432-434: ~420 launches instead of ~5 000).  A_list / chol_list /
+ * rhs_list: HOST arrays of device pointers; status: device int[count], zero on entry, verdict per matrix as in vlm_cholesky_f64.
+ * Per matrix bit-identical to the unbatched calls. */
+int vlm_cholesky_f64_batched(double* const* A_list, int count, int n, int* status, void* stream);
+int vlm_solve_spd_right_f64_batched(double* const* chol_list, int n, double* const* rhs_list, int ld, int rows, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention (K4 + K7 + K7b): softmax(scale*Q K^T + bias[h] + key mask) V, head_dim = 64.

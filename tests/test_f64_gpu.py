@@ -81,3 +81,38 @@ def test_cholesky_rejects_indefinite(ops, pkg):
     s[70, 70] = -1.0
     with pytest.raises(L.VlmError):
         ops.cholesky_(s)
+
+
+def test_batched_cholesky_and_solve_are_the_single_calls_bit_for_bit(ops):
+    """vlm_cholesky_f64_batched / vlm_solve_spd_right_f64_batched (RegMean's solves of one shape in lock step, vilt_module.py:432-434):
+    per matrix the same kernels in the same order as the single-matrix calls -- identical bits; a non-SPD member reports its pivot
+    and leaves the others alone."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    n, rows, count = 200, 70, 5
+    mats, rhs = [], []
+    for i in range(count):
+        x = torch.randn(n + 40, n, device="cuda", dtype=torch.float64, generator=gen)
+        mats.append((x.t() @ x).contiguous())
+        rhs.append(torch.randn(rows, n, device="cuda", dtype=torch.float64, generator=gen))
+    mats[3] = mats[3] - 1e3 * torch.eye(n, device="cuda", dtype=torch.float64)  # indefinite
+    single_c, single_x = [], []
+    for i in range(count):
+        st = torch.zeros(1, device="cuda", dtype=torch.int32)
+        c = ops.cholesky_(mats[i].clone(), status=st)
+        single_c.append((c, int(st.item())))
+        single_x.append(ops.solve_spd_right_(rhs[i].clone(), c))
+    status = torch.zeros(count, device="cuda", dtype=torch.int32)
+    bc = ops.cholesky_batched_([m.clone() for m in mats], status)
+    bx = ops.solve_spd_right_batched_([r.clone() for r in rhs], bc)
+    torch.cuda.synchronize()
+    verdict = status.tolist()
+    for i in range(count):
+        assert verdict[i] == single_c[i][1]
+        if i == 3:
+            assert verdict[i] > 0
+            continue
+        assert verdict[i] == 0
+        assert torch.equal(torch.tril(bc[i]), torch.tril(single_c[i][0])), i
+        assert torch.equal(bx[i], single_x[i]), i
+        want = rhs[i] @ torch.linalg.inv(mats[i])
+        assert float((bx[i] - want).abs().max()) <= 1e-8 * float(want.abs().max())

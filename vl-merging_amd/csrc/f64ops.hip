@@ -117,9 +117,9 @@ extern "C" int vlm_gram_f64(const void* x, int ldx, int M, int D, int x_is_f32, 
 // C[M][N] = alpha * op(A) op(B) + beta * C, fp64, row-major; op(A)[i][k] = ta ? A[k][i] : A[i][k], op(B)[k][j] = tb ?
 // B[j][k] : B[k][j].  A may be fp32 (a_is_f32: the fp32 checkpoint weights of RegMean enter without a host-side cast).
 template <typename TA_>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
-                                                       int lda, const double* __restrict__ B, int ldb, double beta,
-                                                       double* __restrict__ C, int ldc) {
+__device__ __forceinline__ void gemm_f64_body(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
+                                              int lda, const double* __restrict__ B, int ldb, double beta,
+                                              double* __restrict__ C, int ldc) {
   __shared__ double sa[F64_KC][F64_TILE + 1], sb[F64_KC][F64_TILE + 1];
   const int i0 = blockIdx.y * F64_TILE, j0 = blockIdx.x * F64_TILE;
   f64x4 acc[2][2];
@@ -144,6 +144,27 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int ta, int tb, int M, in
           *c = alpha * acc[a][b][r] + (beta != 0.0 ? beta * *c : 0.0);
         }
       }
+}
+
+template <typename TA_>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
+                                                       int lda, const double* __restrict__ B, int ldb, double beta,
+                                                       double* __restrict__ C, int ldc) {
+  gemm_f64_body<TA_>(ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+// Batched forms (round 5): the 36 + 12 independent solves of a RegMean merge have two shapes; ONE launch performs the same block
+// step for every matrix of a shape (blockIdx.z / .y / .x = the matrix, pointers from a kernel-argument table) -- the chain of
+// ~5 000 dependent 64-wide block launches, dealt over four streams, becomes ~420 launches that fill the chip.
+#define VLM_F64_MAX_BATCH 64
+struct f64_tab_t {
+  double* p[VLM_F64_MAX_BATCH];
+};
+__global__ __launch_bounds__(256) void gemm_f64_batched_kernel(int ta, int tb, int M, int N, int K, double alpha, const f64_tab_t A,
+                                                               size_t offA, int lda, const f64_tab_t B, size_t offB, int ldb,
+                                                               double beta, const f64_tab_t C, size_t offC, int ldc) {
+  gemm_f64_body<double>(ta, tb, M, N, K, alpha, A.p[blockIdx.z] + offA, lda, B.p[blockIdx.z] + offB, ldb, beta,
+                        C.p[blockIdx.z] + offC, ldc);
 }
 
 extern "C" int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32,
@@ -200,7 +221,7 @@ __device__ __forceinline__ double f64_readlane(double v, int lane) {
   return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(64) void potrf_block_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ status) {
+__device__ __forceinline__ void potrf_block_body(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ status) {
   const int t = threadIdx.x;
   double a[64];
 #pragma unroll
@@ -231,6 +252,13 @@ __global__ __launch_bounds__(64) void potrf_block_kernel(double* __restrict__ A,
   }
 }
 
+__global__ __launch_bounds__(64) void potrf_block_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ status) {
+  potrf_block_body(A, lda, j0, nb, status);
+}
+__global__ __launch_bounds__(64) void potrf_block_batched_kernel(const f64_tab_t A, int lda, int j0, int nb, int* __restrict__ status) {
+  potrf_block_body(A.p[blockIdx.x], lda, j0, nb, status + blockIdx.x);
+}
+
 extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* status, void* stream) {
   if (nb == 0) return VLM_OK;
   if (!A || nb < 0 || nb > 64 || j0 < 0 || lda < j0 + nb) return VLM_ERR_ARG;
@@ -250,8 +278,8 @@ extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* stat
 // workgroups fill the chip, the row is read and written as one coalesced 512-B piece.  (History: a runtime-indexed `double v[64]`
 // per thread lived in scratch memory, 201 us per launch; fully unrolled in registers it was instruction-fetch bound, 62 us.)
 // A ragged block (nb < 64) is padded with the identity.
-__global__ __launch_bounds__(256) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
-                                                         double* __restrict__ Bm, int ldb, int rows, int c0) {
+__device__ __forceinline__ void trsm_block_body(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
+                                                double* __restrict__ Bm, int ldb, int rows, int c0) {
   __shared__ double s[64][65];
   __shared__ double invd[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,6 +311,15 @@ __global__ __launch_bounds__(256) void trsm_block_kernel(const double* __restric
     }
   }
   if (lane < nb) x[lane] = b;
+}
+
+__global__ __launch_bounds__(256) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
+                                                         double* __restrict__ Bm, int ldb, int rows, int c0) {
+  trsm_block_body(L, ldl, l0, nb, trans, Bm, ldb, rows, c0);
+}
+__global__ __launch_bounds__(256) void trsm_block_batched_kernel(const f64_tab_t L, size_t offL, int ldl, int l0, int nb, int trans,
+                                                                 const f64_tab_t Bm, size_t offB, int ldb, int rows, int c0) {
+  trsm_block_body(L.p[blockIdx.y] + offL, ldl, l0, nb, trans, Bm.p[blockIdx.y] + offB, ldb, rows, c0);
 }
 
 extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int trans, double* Bm, int ldb, int rows, int c0,
@@ -340,6 +377,80 @@ extern "C" int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, i
     if (rc) return rc;
     if (j0 > 0) {
       rc = vlm_gemm_f64(0, 0, rows, j0, nb, -1.0, rhs + j0, ld, 0, chol + (size_t)j0 * n, n, 1.0, rhs, ld, stream);
+      if (rc) return rc;
+    }
+  }
+  return VLM_OK;
+}
+
+
+// ---- batched drivers: `count` (<= VLM_F64_MAX_BATCH) matrices of ONE shape; same kernels, same order, same results per matrix as
+// vlm_cholesky_f64 / vlm_solve_spd_right_f64 ----------------------------------------------------------------------------------------
+static int f64_tab(double* const* list, int count, f64_tab_t& t) {
+  if (!list || count <= 0 || count > VLM_F64_MAX_BATCH) return VLM_ERR_ARG;
+  for (int i = 0; i < count; ++i) {
+    if (!list[i]) return VLM_ERR_ARG;
+    t.p[i] = list[i];
+  }
+  return VLM_OK;
+}
+static int gemm_f64_batched(int ta, int tb, int M, int N, int K, double alpha, const f64_tab_t& A, size_t offA, int lda,
+                            const f64_tab_t& B, size_t offB, int ldb, double beta, const f64_tab_t& C, size_t offC, int ldc, int count,
+                            hipStream_t s) {
+  if (M <= 0 || N <= 0) return VLM_OK;
+  dim3 grid((N + F64_TILE - 1) / F64_TILE, (M + F64_TILE - 1) / F64_TILE, count);
+  hipLaunchKernelGGL(gemm_f64_batched_kernel, grid, dim3(256), 0, s, ta, tb, M, N, K, alpha, A, offA, lda, B, offB, ldb, beta, C, offC, ldc);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_cholesky_f64_batched(double* const* A_list, int count, int n, int* status, void* stream) {
+  if (n == 0 || count == 0) return VLM_OK;
+  if (n < 0 || !status) return VLM_ERR_ARG;
+  f64_tab_t A;
+  int rc = f64_tab(A_list, count, A);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int nb = n - j0 < 64 ? n - j0 : 64, r = n - j0 - nb;
+    hipLaunchKernelGGL(potrf_block_batched_kernel, dim3(count), dim3(64), 0, s, A, n, j0, nb, status);
+    VLM_CHECK_LAUNCH();
+    if (r > 0) {
+      const size_t below = (size_t)(j0 + nb) * n;
+      hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((r + 3) / 4, count), dim3(256), 0, s, A, (size_t)0, n, j0, nb, 1, A, below, n, r, j0);
+      VLM_CHECK_LAUNCH();
+      rc = gemm_f64_batched(0, 1, r, r, nb, -1.0, A, below + j0, n, A, below + j0, n, 1.0, A, below + j0 + nb, n, count, s);
+      if (rc) return rc;
+    }
+  }
+  return VLM_OK;
+}
+
+extern "C" int vlm_solve_spd_right_f64_batched(double* const* chol_list, int n, double* const* rhs_list, int ld, int rows, int count,
+                                               void* stream) {
+  if (n == 0 || rows == 0 || count == 0) return VLM_OK;
+  if (n < 0 || rows < 0 || ld < n) return VLM_ERR_ARG;
+  f64_tab_t Lt, R;
+  int rc = f64_tab(chol_list, count, Lt);
+  if (rc) return rc;
+  rc = f64_tab(rhs_list, count, R);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int nb = n - j0 < 64 ? n - j0 : 64, j1 = j0 + nb;
+    hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((rows + 3) / 4, count), dim3(256), 0, s, Lt, (size_t)0, n, j0, nb, 1, R, (size_t)0, ld, rows, j0);
+    VLM_CHECK_LAUNCH();
+    if (j1 < n) {
+      rc = gemm_f64_batched(0, 1, rows, n - j1, nb, -1.0, R, (size_t)j0, ld, Lt, (size_t)j1 * n + j0, n, 1.0, R, (size_t)j1, ld, count, s);
+      if (rc) return rc;
+    }
+  }
+  for (int j0 = ((n - 1) / 64) * 64; j0 >= 0; j0 -= 64) {
+    const int nb = n - j0 < 64 ? n - j0 : 64;
+    hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((rows + 3) / 4, count), dim3(256), 0, s, Lt, (size_t)0, n, j0, nb, 0, R, (size_t)0, ld, rows, j0);
+    VLM_CHECK_LAUNCH();
+    if (j0 > 0) {
+      rc = gemm_f64_batched(0, 0, rows, j0, nb, -1.0, R, (size_t)j0, ld, Lt, (size_t)j0 * n, n, 1.0, R, (size_t)0, ld, count, s);
       if (rc) return rc;
     }
   }

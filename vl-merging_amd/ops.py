@@ -491,6 +491,47 @@ def solve_spd_right_(rhs, chol):
     return rhs
 
 
+F64_MAX_BATCH = 64
+
+
+def _ptr_list(ts):
+    arr = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def cholesky_batched_(mats, status):
+    """cholesky_ of every matrix of `mats` (contiguous float64 [n, n], ONE n) in lock step: each block step is one launch over all
+    of them (vlm_cholesky_f64_batched).  status: int32 device tensor [len(mats)], zero on entry."""
+    L.require_cuda(status, *mats)
+    n = mats[0].shape[0]
+    for m in mats:
+        if m.dtype != F64 or tuple(m.shape) != (n, n) or not m.is_contiguous():
+            raise L.VlmError("cholesky_batched_: contiguous float64 [n,n] matrices of one size")
+    for i in range(0, len(mats), F64_MAX_BATCH):
+        chunk = mats[i:i + F64_MAX_BATCH]
+        L.check(L.get_lib().vlm_cholesky_f64_batched(_ptr_list(chunk), len(chunk), n, L.ptr(status[i:i + len(chunk)]), L.stream_ptr()),
+                "vlm_cholesky_f64_batched")
+    return mats
+
+
+def solve_spd_right_batched_(rhs, chols):
+    """solve_spd_right_ for every (rhs[i], chols[i]) pair, all of ONE shape, in lock step (vlm_solve_spd_right_f64_batched)."""
+    L.require_cuda(*rhs, *chols)
+    rows, n = rhs[0].shape
+    ld = _ld(rhs[0])
+    for r, c in zip(rhs, chols):
+        if r.dtype != F64 or c.dtype != F64 or tuple(r.shape) != (rows, n) or _ld(r) != ld or r.stride(1) != 1 \
+                or tuple(c.shape) != (n, n) or not c.is_contiguous():
+            raise L.VlmError("solve_spd_right_batched_: float64 rhs [rows, n] of one shape, contiguous float64 factors [n, n]")
+    for i in range(0, len(rhs), F64_MAX_BATCH):
+        rc, cc = rhs[i:i + F64_MAX_BATCH], chols[i:i + F64_MAX_BATCH]
+        L.check(L.get_lib().vlm_solve_spd_right_f64_batched(_ptr_list(cc), n, _ptr_list(rc), ld, rows, len(rc), L.stream_ptr()),
+                "vlm_solve_spd_right_f64_batched")
+    return rhs
+
+
 def patch_im2col(image, patches, patch, lead_rows):
     L.require_cuda(image, patches)
     B, C, H, W = image.shape

@@ -23,46 +23,49 @@ def scale_gram(G, alpha):
 class _Solves:
     """The 48 independent W* = num @ inverse(den) solves of a merge (:432-434), float64, on the device.  The sum of
     a*G + (1-a)*diag(G) over SPD Gram matrices is SPD, so each is a blocked Cholesky factorisation + two triangular solves --
-    a long chain of small dependent launches (48 block columns for fc2's 3072^2 Gram sum) that leaves most of the chip idle:
-    the solves are dealt round-robin over a few HIP streams, and their positive-definiteness verdicts are read once, after
-    everything has been issued.  A Gram sum that is rank-deficient or numerically indefinite (few capture batches: fewer rows
-    than columns for fc2, scaling_for_non_diag = 1) has no Cholesky factor, while the reference's LU-based torch.inverse still
-    returns a result: that case falls back, loudly, to a general float64 inverse on the device (torch.linalg.inv = hipSOLVER)
-    followed by the MFMA-f64 product."""
+    a long chain of small dependent launches (48 block columns for fc2's 3072^2 Gram sum) that leaves most of the chip idle
+    when run one matrix at a time.  The solves are COLLECTED and run per shape in lock step (round 5: ops.cholesky_batched_ /
+    solve_spd_right_batched_: every block step is ONE launch over all matrices of a shape -- 36 of 768^2 under three right-hand-
+    side shapes, 12 of 3072^2 -- ~420 launches instead of ~5 000), their positive-definiteness verdicts read once at the end.
+    A Gram sum that is rank-deficient or numerically indefinite (few capture batches: fewer rows than columns for fc2,
+    scaling_for_non_diag = 1) has no Cholesky factor, while the reference's LU-based torch.inverse still returns a result: that
+    case falls back, loudly, to a general float64 inverse on the device (torch.linalg.inv = hipSOLVER) followed by the MFMA-f64
+    product."""
 
-    N_STREAMS = 4
     MAX_JOBS = 256
 
     def __init__(self, device):
         self.device = device
-        self.main = torch.cuda.current_stream(device)
-        self.streams = [torch.cuda.Stream(device) for _ in range(self.N_STREAMS)]
         # sized up front and NEVER reallocated while factorisations are in flight (their verdicts land through the raw pointer):
         # a merge has 12 layers x 4 weights = 48 solves
         self.status = torch.zeros(self.MAX_JOBS, device=device, dtype=torch.int32)
-        self.jobs = []  # (what, num (solved in place), den copy, status index)
+        self.jobs = []  # (what, num (solved in place), den (factorised in place), den copy, num copy)
 
     def submit(self, num, den, what):
-        i = len(self.jobs)
-        if i >= self.MAX_JOBS:
+        if len(self.jobs) >= self.MAX_JOBS:
             raise RuntimeError("regmean: more than %d solves in one merge" % self.MAX_JOBS)
-        st = self.streams[i % self.N_STREAMS]
-        st.wait_stream(self.main)  # num / den were produced on the caller's stream
-        with torch.cuda.stream(st):
-            keep_den, keep_num = den.clone(), num.clone()  # both are overwritten in place; the copies serve the fallback
-            ops.solve_spd_right_(num, ops.cholesky_(den, status=self.status[i:i + 1]))
-        for t in (num, den, keep_den, keep_num):
-            t.record_stream(st)
-        self.jobs.append((what, num, keep_den, keep_num))
+        # both are overwritten in place; the copies serve the fallback
+        self.jobs.append((what, num, den, den.clone(), num.clone()))
         return num
 
     def finish(self, out):
-        for st in self.streams:
-            self.main.wait_stream(st)
         if not self.jobs:
             return
+        groups = {}
+        for i, (what, num, den, _, _) in enumerate(self.jobs):
+            groups.setdefault((den.shape[0], num.shape[0], num.stride(0)), []).append(i)
+        order = [i for key in sorted(groups) for i in groups[key]]  # status slots in issue order
+        slot = {j: k for k, j in enumerate(order)}
+        k0 = 0
+        for key in sorted(groups):
+            idx = groups[key]
+            dens = [self.jobs[i][2] for i in idx]
+            ops.cholesky_batched_(dens, self.status[k0:k0 + len(idx)])
+            ops.solve_spd_right_batched_([self.jobs[i][1] for i in idx], dens)
+            k0 += len(idx)
         verdict = self.status[:len(self.jobs)].tolist()  # ONE synchronisation for all solves
-        for (what, num, keep_den, keep_num), bad in zip(self.jobs, verdict):
+        for j, (what, num, den, keep_den, keep_num) in enumerate(self.jobs):
+            bad = verdict[slot[j]]
             if bad:
                 import warnings
                 warnings.warn("regmean: the Gram sum of %s is not positive definite (pivot %d); using a general inverse like "
