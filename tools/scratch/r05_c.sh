@@ -1,13 +1,15 @@
 #!/bin/bash
-# round 5: folded LayerScale -- kernel tests, model goldens, the two-rank reducer tests, then an A/B of the switch on one box
+# round 5: same-box baseline (the round-4 tree), then A/Bs of the two new switches, then the tests of the folded LayerScale
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05; mkdir -p $O
-timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_ddp_gpu.py tests/test_attention_gpu.py -m gpu -x -q --durations=8 > $O/c_tests.log 2>&1; tail -22 $O/c_tests.log
-for v in 0 1 0 1; do
-  VLM_FOLD_LAYERSCALE=$v python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-merge --no-calibrate --no-secondary > /tmp/b.json 2>/tmp/b.err
-  python -c "import json;d=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1]);print('fold=$v', round(d['value'],2), round(d['ms_per_step'],3), round(d['roofline']['achieved'],1), d['config']['final_loss'])" | tee -a $O/c_ab.txt
+O=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p $O
+: > $O/c_ab.txt
+line() { python -c "import json,sys;d=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1]);print(sys.argv[1], round(d['value'],2), round(d['ms_per_step'],3), round(d['roofline']['achieved'],1), d['config']['final_loss'])" "$1" | tee -a $O/c_ab.txt; }
+ARGS="--steps 12 --warmup 3 --no-cpu-baseline --no-merge --no-calibrate --no-secondary"
+for rep in 1 2; do
+  (cd tools/scratch/r04_tree && timeout 300 python bench.py $ARGS > /tmp/b.json 2>/tmp/b.err); line "r04_tree"
+  VLM_FOLD_LAYERSCALE=0 VLM_ATT_BWD_FUSED=0 timeout 300 python bench.py $ARGS > /tmp/b.json 2>/tmp/b.err; line "r05 fold=0 attfused=0"
+  VLM_FOLD_LAYERSCALE=0 VLM_ATT_BWD_FUSED=1 timeout 300 python bench.py $ARGS > /tmp/b.json 2>/tmp/b.err; line "r05 fold=0 attfused=1"
+  VLM_FOLD_LAYERSCALE=1 VLM_ATT_BWD_FUSED=1 timeout 300 python bench.py $ARGS > /tmp/b.json 2>/tmp/b.err; line "r05 fold=1 attfused=1"
 done
-for v in 0 1; do
-  VLM_ATT_BWD_FUSED=$v python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-merge --no-calibrate --no-secondary > /tmp/b.json 2>/tmp/b.err
-  python -c "import json;d=json.loads(open('/tmp/b.json').read().strip().splitlines()[-1]);print('attfused=$v', round(d['value'],2), round(d['ms_per_step'],3), round(d['roofline']['achieved'],1), d['config']['final_loss'])" | tee -a $O/c_ab.txt
-done
+timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_f64_gpu.py tests/test_model_gpu.py tests/test_ddp_gpu.py -m gpu -x -q --durations=8 > $O/c_tests.log 2>&1; tail -25 $O/c_tests.log
+timeout 600 python bench.py --steps 8 --warmup 2 > $O/bench_c.json 2> $O/bench_c.err; echo "bench rc=$?"; grep "^\[bench" $O/bench_c.err | tail -30

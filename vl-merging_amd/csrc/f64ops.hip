@@ -27,16 +27,30 @@ __device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1,
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  // The next step's panel elements are requested into registers BEFORE the current step's MFMAs (round 5: the load -> LDS ->
+  // barrier -> MFMA chain of one step used to run back to back: the global-load latency was exposed once per 16 reduction rows)
+  constexpr int PER = (F64_KC * F64_TILE) / 256;
+  double ra[PER], rb[PER];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u, kk = e >> 6, c = e & 63;
+      const bool ok = k + kk < k1;
+      ra[u] = ok ? a_at(k + kk, c) : 0.0;
+      rb[u] = ok ? b_at(k + kk, c) : 0.0;
+    }
+  };
+  if (k0 < k1) fetch(k0);
   for (int k = k0; k < k1; k += F64_KC) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < (F64_KC * F64_TILE) / 256; ++u) {
+    for (int u = 0; u < PER; ++u) {
       const int e = tid + 256 * u, kk = e >> 6, c = e & 63;
-      const bool ok = k + kk < k1;
-      sa[kk][c] = ok ? a_at(k + kk, c) : 0.0;
-      sb[kk][c] = ok ? b_at(k + kk, c) : 0.0;
+      sa[kk][c] = ra[u];
+      sb[kk][c] = rb[u];
     }
     __syncthreads();
+    if (k + F64_KC < k1) fetch(k + F64_KC);
 #pragma unroll
     for (int k4 = 0; k4 < F64_KC; k4 += 4) {
       const int kk = k4 + (lane >> 4), c = lane & 15;
