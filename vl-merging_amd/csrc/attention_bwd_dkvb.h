@@ -45,6 +45,13 @@ static inline __host__ __device__ int dkvb_nblk(int n0, int n1, int pos1, int mo
 
 typedef __attribute__((address_space(3))) s16x4 dkvb_lds_s16x4;
 
+// two fp32 -> one dword of two bf16 (round to nearest even), low half = first argument
+__device__ __forceinline__ uint32_t dkvb_cvt_pk(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 template <int W>
 __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd_params_t bp, int n_groups, int panel_blocks) {
   const attn_params_t& p = bp.f;
@@ -138,27 +145,28 @@ __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd
     // next block's operands, requested one block ahead
     u32x4 nq[4], no_[4], nbw[2];
     float nlse = 0.f, ndel = 0.f;
+    // Every lane ALWAYS loads: a position outside the streamed range (ragged last block, the text / image gap) is clamped to a
+    // row that exists, its scores are switched off by the statistics k-step (-30000) and by the table's own padding, so whatever
+    // finite Q / dO values arrive there are multiplied by P = 0.  (A per-lane `ok ? offset : out-of-range` made hipcc put every
+    // load under an exec-mask branch of its own: ~120 scalar instructions per block and no counted vmcnt.)
+    const uint32_t row_txt = (uint32_t)(ps.base0 + b * ps.n0), row_img = (uint32_t)(ps.base1 + b * ps.n1 - ps.pos1);
+    auto row_of = [&](int qp) -> uint32_t {
+      qp = qp < s_hi - 1 ? qp : s_hi - 1;
+      return (uint32_t)qp + (qp < ps.n0 ? row_txt : row_img);
+    };
     auto request = [&](int j) {
       const int q0 = s_lo + j * ATT_KB;
+      const uint32_t c16 = (uint32_t)(lane & 7) * 16u + (uint32_t)h * 128u;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int qp = q0 + 8 * u + (lane >> 3);
-        const bool txt = qp < ps.n0, img = qp >= ps.pos1 && qp < ps.NP;
-        const bool ok = (txt || img) && qp < s_hi;
-        const uint32_t row = (uint32_t)(txt ? ps.base0 + b * ps.n0 + qp : ps.base1 + b * ps.n1 + (qp - ps.pos1));
-        const uint32_t c16 = (uint32_t)(lane & 7) * 16u;
-        nq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rq, ok ? (row * (uint32_t)p.ld_qkv + (uint32_t)h * 64u) * 2u + c16 : 0xFFFFFFF0u, 0, 0));
-        no_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rdo, ok ? (row * (uint32_t)bp.ld_do + (uint32_t)h * 64u) * 2u + c16 : 0xFFFFFFF0u, 0, 0));
+        const uint32_t row = row_of(q0 + 8 * u + (lane >> 3));
+        nq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, row * (uint32_t)(p.ld_qkv * 2) + c16, 0, 0));
+        no_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, row * (uint32_t)(bp.ld_do * 2) + c16, 0, 0));
       }
       {
-        const int qp = q0 + r;  // both lane halves ask for the same 32 rows (the upper half's copy is not used)
-        const bool txt = qp < ps.n0, img = qp >= ps.pos1 && qp < ps.NP;
-        const bool ok = (txt || img) && qp < s_hi;
-        const uint32_t row = (uint32_t)(txt ? ps.base0 + b * ps.n0 + qp : ps.base1 + b * ps.n1 + (qp - ps.pos1));
-        nlse = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rlse, ok ? row * 4u : 0xFFFFFFF0u, 0, 0));
-        ndel = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdel, ok ? row * 4u : 0xFFFFFFF0u, 0, 0));
+        const uint32_t row = row_of(q0 + r);  // both lane halves ask for the same 32 rows (the upper half's copy is not used)
+        nlse = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rlse, row * 4u, 0, 0));
+        ndel = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdel, row * 4u, 0, 0));
       }
       {
         const uint32_t soff = (uint32_t)(j >> 1) * 4096u + (uint32_t)(j & 1) * 2048u;
@@ -181,93 +189,97 @@ __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd
         bstat[0] = bstat[1] = bstat[2] = (bf16_t)1.0f;
         bstat[3] = (bf16_t)(kept ? 0.f : ATT_NEG_BIG);  // dropped key: every score of its column goes to -30000, P = 0
       }
-      request((wave * S) % nblk);
+      request(wave * S);
     }
 
-    for (int t = 0; t < nblk; ++t) {
-      if (active) {
-        int j = t + wave * S;
-        if (j >= nblk) j -= nblk;
-        // ---- the block requested one step ago: Q / dO -> this wave's LDS slot (one image for row reads and transposed reads) ------
+    if (!active) {  // (wave-uniform) an idle wave of this round only keeps the barriers company
+      for (int t = 0, ph = 0; t < nblk; ++t) {
+        if (++ph == S || t + 1 == nblk) { ph = 0; __syncthreads(); }
+      }
+      continue;
+    }
+    for (int t = 0, ph = 0, j = wave * S; t < nblk; ++t) {
+      // ---- the block requested one step ago: Q / dO -> this wave's LDS slot (one image for row reads and transposed reads) ------
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t wo = (u & 1 ? wr_off1 : wr_off0) + (u >> 1) * 2048u;
-          *reinterpret_cast<u32x4*>(slot + wo) = nq[u];
-          *reinterpret_cast<u32x4*>(slot + 4096 + wo) = no_[u];
-        }
-        // ---- query side of the statistics k-step: (-lse, -delta) of row q0 + r as three bf16 terms each ------------------------
-        bf16x8 astat_e, astat_d;
-        {
-          const int qp = s_lo + j * ATT_KB + r;
-          const bool qok = qp < s_hi && (qp < ps.n0 || qp >= ps.pos1);
-          const float ve = qok ? -nlse : ATT_NEG_BIG, vd = qok ? -ndel : 0.f;
-          const bf16_t e0 = (bf16_t)ve, d0 = (bf16_t)vd;
-          const float re = ve - (float)e0, rdl = vd - (float)d0;
-          const bf16_t e1 = (bf16_t)re, d1 = (bf16_t)rdl;
-          const bf16_t e2 = (bf16_t)(re - (float)e1), d2 = (bf16_t)(rdl - (float)d1);
-          const bf16_t z = (bf16_t)0.f;
-          const bool lo = hh == 0;
-          astat_e = (bf16x8){lo ? e0 : z, lo ? e1 : z, lo ? e2 : z, lo ? (bf16_t)1.0f : z, z, z, z, z};
-          astat_d = (bf16x8){lo ? d0 : z, lo ? d1 : z, lo ? d2 : z, z, z, z, z, z};
-        }
-        // ---- E = -lse + mask + Bias log2e + Q (c1 K)^T ;  dP = -delta + dO V^T --------------------------------------------------
-        f32x16 e, dp;
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t wo = (u & 1 ? wr_off1 : wr_off0) + (u >> 1) * 2048u;
+        *reinterpret_cast<u32x4*>(slot + wo) = nq[u];
+        *reinterpret_cast<u32x4*>(slot + 4096 + wo) = no_[u];
+      }
+      // ---- query side of the statistics k-step: (-lse, -delta) of row q0 + r as three bf16 terms each ------------------------
+      bf16x8 astat_e, astat_d;
+      {
+        const int qp = s_lo + j * ATT_KB + r;
+        const bool qok = qp < s_hi && (qp < ps.n0 || qp >= ps.pos1);
+        const float ve = qok ? -nlse : ATT_NEG_BIG, vd = qok ? -ndel : 0.f;
+        const bf16_t e0 = (bf16_t)ve, d0 = (bf16_t)vd;
+        const float re = ve - (float)e0, rdl = vd - (float)d0;
+        const bf16_t e1 = (bf16_t)re, d1 = (bf16_t)rdl;
+        const bf16_t e2 = (bf16_t)(re - (float)e1), d2 = (bf16_t)(rdl - (float)d1);
+        const bf16_t z = (bf16_t)0.f;
+        const bool lo = hh == 0;
+        astat_e = (bf16x8){lo ? e0 : z, lo ? e1 : z, lo ? e2 : z, lo ? (bf16_t)1.0f : z, z, z, z, z};
+        astat_d = (bf16x8){lo ? d0 : z, lo ? d1 : z, lo ? d2 : z, z, z, z, z, z};
+      }
+      // ---- E = -lse + mask + Bias log2e + Q (c1 K)^T ;  dP = -delta + dO V^T --------------------------------------------------
+      f32x16 e, dp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = dp[i] = 0.f;
-        e = att_bias_mfma(sel0, sel1, nbw, e);
-        {  // the requested operands are consumed: the next block's requests go out into the same registers
-          int jn = j + 1;
-          if (jn >= nblk) jn -= nblk;
-          request(t + 1 < nblk ? jn : j);  // (the last step re-requests its own block: same operations every step, result unused)
-        }
-        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(astat_e, bstat, e, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(astat_d, bstat, dp, 0, 0, 0);
+      for (int i = 0; i < 16; ++i) e[i] = dp[i] = 0.f;
+      e = att_bias_mfma(sel0, sel1, nbw, e);
+      {  // the requested operands are consumed: the next block's requests go out into the same registers
+        int jn = j + 1;
+        if (jn >= nblk) jn -= nblk;
+        request(t + 1 < nblk ? jn : j);  // (the last step re-requests its own block: same operations every step, result unused)
+      }
+      e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(astat_e, bstat, e, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(astat_d, bstat, dp, 0, 0, 0);
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-          const bf16x8 qa = *reinterpret_cast<const bf16x8*>(slot + (row_off0 ^ (uint32_t)(ss << 5)));
-          const bf16x8 oa = *reinterpret_cast<const bf16x8*>(slot + 4096 + (row_off0 ^ (uint32_t)(ss << 5)));
-          e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ss], e, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
-        }
+      for (int ss = 0; ss < 4; ++ss) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(slot + (row_off0 ^ (uint32_t)(ss << 5)));
+        const bf16x8 oa = *reinterpret_cast<const bf16x8*>(slot + 4096 + (row_off0 ^ (uint32_t)(ss << 5)));
+        e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ss], e, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ss], dp, 0, 0, 0);
+      }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          e[i] = att_exp2(e[i]);  // P
-          dp[i] *= e[i];          // dS (natural units)
-        }
-        // ---- G += dS: this wave is the only one in this 4-KB block of the panel until the next barrier ----------------------------
-        {
-          float* g = panel + (size_t)j * 1024 + lane * 4;
+      for (int i = 0; i < 16; ++i) {
+        e[i] = att_exp2(e[i]);  // P
+        dp[i] *= e[i];          // dS (natural units)
+      }
+      // ---- G += dS: this wave is the only one in this 4-KB block of the panel until the next barrier ----------------------------
+      {
+        float* g = panel + (size_t)j * 1024 + lane * 4;
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(g + g4 * 256);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(g + g4 * 256);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += dp[4 * g4 + i];
-            *reinterpret_cast<f32x4*>(g + g4 * 256) = v;
-          }
-        }
-        // ---- dV += P^T dO ,  dK += dS^T Q -------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8 pf, df;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            pf[jj] = (bf16_t)e[8 * s2 + jj];
-            df[jj] = (bf16_t)dp[8 * s2 + jj];
-          }
-#pragma unroll
-          for (int db = 0; db < 2; ++db) {
-            const s16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + 4096 + s2 * 2048 + tr_off[db][0]));
-            const s16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + 4096 + s2 * 2048 + tr_off[db][1]));
-            const s16x8 ov = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
-            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, __builtin_bit_cast(bf16x8, ov), dv[db], 0, 0, 0);
-            const s16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + s2 * 2048 + tr_off[db][0]));
-            const s16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + s2 * 2048 + tr_off[db][1]));
-            const s16x8 qv = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
-            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, __builtin_bit_cast(bf16x8, qv), dk[db], 0, 0, 0);
-          }
+          for (int i = 0; i < 4; ++i) v[i] += dp[4 * g4 + i];
+          *reinterpret_cast<f32x4*>(g + g4 * 256) = v;
         }
       }
-      if ((t + 1) % S == 0 || t + 1 == nblk) __syncthreads();  // the waves move on to panel blocks another wave has just left
+      // ---- dV += P^T dO ,  dK += dS^T Q -------------------------------------------------------------------------------------------
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 pw, dw;  // P and dS of rows 8 s2 .. 8 s2 + 7 as bf16 pairs (ONE v_cvt_pk_bf16_f32 per pair, nothing to re-pack)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          pw[jj] = dkvb_cvt_pk(e[8 * s2 + 2 * jj], e[8 * s2 + 2 * jj + 1]);
+          dw[jj] = dkvb_cvt_pk(dp[8 * s2 + 2 * jj], dp[8 * s2 + 2 * jj + 1]);
+        }
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), df = __builtin_bit_cast(bf16x8, dw);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const s16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + 4096 + s2 * 2048 + tr_off[db][0]));
+          const s16x4 ohi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + 4096 + s2 * 2048 + tr_off[db][1]));
+          const s16x8 ov = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, __builtin_bit_cast(bf16x8, ov), dv[db], 0, 0, 0);
+          const s16x4 qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + s2 * 2048 + tr_off[db][0]));
+          const s16x4 qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + s2 * 2048 + tr_off[db][1]));
+          const s16x8 qv = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, __builtin_bit_cast(bf16x8, qv), dk[db], 0, 0, 0);
+        }
+      }
+      if (++j >= nblk) j = 0;
+      if (++ph == S || t + 1 == nblk) { ph = 0; __syncthreads(); }  // the waves move on to panel blocks another wave has just left
     }
 
     // ---- this sample's dK, dV: accumulator rows = keys (registers), column = d (lane & 31) -------------------------------------
