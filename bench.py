@@ -107,13 +107,13 @@ GEMM_HELPERS = ("splitk_reduce_kernel",)  # second launch of a wgrad call: its b
 
 def pmc_traffic(kernels, helpers=()):
     """HBM-side bytes per launch of a kernel (or, launch-weighted, of a family of kernels that serve the same call) from the
-    committed rocprofv3 --pmc passes over this same bench command (profiles/r04_pmc_traffic.json, made by
+    committed rocprofv3 --pmc passes over this same bench command (the newest profiles/r*_pmc_traffic.json, made by
     tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950).
     Counters cannot be read from inside the timed process; None if the file is absent."""
     if isinstance(kernels, str):
         kernels = (kernels,)
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC passes
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC passes
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 ks = json.load(f)["kernels"]

@@ -93,7 +93,7 @@ def main():
     torch.cuda.synchronize()
     f = model._flat
     out["params"] = f.flat_p[:f.numel].cpu().numpy()
-    out["shadow_ok"] = np.array(bool(torch.equal(f.flat_b[:f.numel], f.flat_p[:f.numel].to(torch.bfloat16))))
+    out["shadow_ok"] = np.array(bool(torch.equal(f.flat_b[:f.numel], f.shadow_reference())))
     out["state_elements"] = np.array(opt.state_elements())
     out["numel"] = np.array(f.numel)
     np.savez(os.path.join(outdir, "%s_rank%d.npz" % (config, rank)), **out)

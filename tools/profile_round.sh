@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace stats + three separate PMC passes over the SAME bench command, condensed into
 # gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: tools/profile_round.sh r02
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -45,7 +45,25 @@ for k, v in acc.items():
     if ("attn" in k or "vlm_gemm" in k or "merge" in k) and v.get("GRBM_GUI_ACTIVE"):
         # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
         res[k] = {"launches": n[(k, "GRBM_GUI_ACTIVE")], "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)}
-json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 2 --warmup 1: busy cycles summed over the 1024 SIMDs / (1024 x per-XCD active cycles), time-weighted over all launches of a kernel", "kernels": res}, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
+# attention on ALGORITHMIC flops next to the busy counter (the counter also counts the bias-selection, statistics and row-sum MFMAs):
+# per step forward 4 n_q n_k 64 per (sample, head, layer) summed over the passes of configs[1] = 1.427 TFLOP, backward 2 x that;
+# kernel times from the serial kernel trace of the same command (6 steps)
+alg = {}
+try:
+    t = {}
+    for r in csv.DictReader(open("$OUT/trace/run_kernel_stats.csv")):
+        nm = re.sub(r"[<(].*", "", r["Name"]).replace("void ", "")
+        t[nm] = t.get(nm, 0.0) + float(r["TotalDurationNs"]) / 6e6  # ms per step
+    fwd = t.get("attn_fwd_kernel", 0.0)
+    bwd = sum(v for k, v in t.items() if k.startswith("attn_bwd_") or k == "attn_dbias_fold_kernel")
+    alg = {"fwd_tflop_per_step": 1.427, "fwd_ms_per_step": fwd, "fwd_tflops": 1.427 / fwd * 1e3 if fwd else None,
+           "fwd_frac_of_2500": 1.427 / fwd * 1e3 / 2500 if fwd else None,
+           "bwd_tflop_per_step": 2.854, "bwd_ms_per_step": bwd, "bwd_tflops": 2.854 / bwd * 1e3 if bwd else None,
+           "bwd_frac_of_2500": 2.854 / bwd * 1e3 / 2500 if bwd else None,
+           "bwd_kernels_ms_per_step": {k: v for k, v in t.items() if k.startswith("attn_")}}
+except Exception as e:
+    alg = {"error": repr(e)}
+json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 2 --warmup 1: busy cycles summed over the 1024 SIMDs / (1024 x per-XCD active cycles), time-weighted over all launches of a kernel", "kernels": res, "attention_on_algorithmic_flops": alg}, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 grep -E '^\{"metric' $OUT/trace.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_under_trace.txt

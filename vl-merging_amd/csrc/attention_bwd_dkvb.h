@@ -15,8 +15,8 @@
 // query blocks SKEWED: wave w is at block (t + w S) mod nblk in step t, S = nblk / W, so within any S consecutive steps no two
 // waves touch the same 4-KB block of the panel and the read-modify-write of G needs no atomics, only a workgroup barrier every S
 // steps.  Nothing else is shared: no staging barrier, no statistics in LDS.
-// Everything linear rides on the matrix pipe: -lse and -delta enter as a 5th k-step (the row's value split into three bf16 terms
-// against ones on the key side -- exact to 24 bits in the fp32 accumulator), the key-padding mask as one more k-slot of that
+// Everything linear rides on the matrix pipe: -lse and -delta enter as a 5th k-step (the row's value split into two bf16 terms
+// against ones on the key side -- 16 significant bits in the fp32 accumulator), the key-padding mask as one more k-slot of that
 // step, the bias through two selection MFMAs on the tiled fp16 table (attention_common.h).
 #pragma once
 
@@ -45,11 +45,15 @@ static inline __host__ __device__ int dkvb_nblk(int n0, int n1, int pos1, int mo
 
 typedef __attribute__((address_space(3))) s16x4 dkvb_lds_s16x4;
 
-// two fp32 -> one dword of two bf16 (round to nearest even), low half = first argument
-__device__ __forceinline__ uint32_t dkvb_cvt_pk(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+typedef __attribute__((ext_vector_type(8))) float dkvb_f32x8;
+// eight fp32 -> eight bf16 (round to nearest even) as FOUR v_cvt_pk_bf16_f32: the element-wise (bf16_t) casts compiled to one
+// conversion per value plus v_perm re-packing.  (Not inline asm: hipcc does not pad the VALU-write -> MFMA-operand hazard of an
+// asm statement -- cdna_hip_programming.md 5.7 item 2 -- and the first asm version of this returned wrong dK on some waves.)
+__device__ __forceinline__ bf16x8 dkvb_pack8(const f32x16& v, int first) {
+  dkvb_f32x8 t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = v[first + i];
+  return __builtin_convertvector(t, bf16x8);
 }
 
 template <int W>
@@ -107,6 +111,9 @@ __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd
   const __amdgpu_buffer_rsrc_t rdel = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(bp.delta + (size_t)h * p.total_rows), 0, (uint32_t)p.total_rows * 4u, 0x00020000);
 
+  // per-lane parts of the Q / dO load addresses (16-B chunk of the head's 128-B row segment; row (lane >> 3) of an 8-row group)
+  const uint32_t c16 = (uint32_t)(lane & 7) * 16u + (uint32_t)h * 128u;
+  const uint32_t voff_q = (uint32_t)(lane >> 3) * (uint32_t)(p.ld_qkv * 2) + c16, voff_o = (uint32_t)(lane >> 3) * (uint32_t)(bp.ld_do * 2) + c16;
   // LDS addresses of this lane inside a block image (the Q image; dO's is 4096 further)
   unsigned char* slot = slots + wave * 8192;
   // (row bits 4 and up do not enter the swizzle: 16 rows further = + 2048 bytes; 8 rows further flips chunk bit 1; chunk bit 2 /
@@ -156,14 +163,24 @@ __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd
     };
     auto request = [&](int j) {
       const int q0 = s_lo + j * ATT_KB;
-      const uint32_t c16 = (uint32_t)(lane & 7) * 16u + (uint32_t)h * 128u;
+      // 17 of the 20 blocks of a 384^2 pass are 32 consecutive image rows: their addresses are a scalar base + per-lane
+      // constants (no vector arithmetic at all); both paths issue the same loads in the same order
+      if (q0 >= ps.pos1 && q0 + ATT_KB <= s_hi) {  // (wave-uniform)
+        const uint32_t row0 = row_img + (uint32_t)q0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t row = row_of(q0 + 8 * u + (lane >> 3));
-        nq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, row * (uint32_t)(p.ld_qkv * 2) + c16, 0, 0));
-        no_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, row * (uint32_t)(bp.ld_do * 2) + c16, 0, 0));
-      }
-      {
+        for (int u = 0; u < 4; ++u) {
+          nq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, voff_q, (row0 + 8u * u) * (uint32_t)(p.ld_qkv * 2), 0));
+          no_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, voff_o, (row0 + 8u * u) * (uint32_t)(bp.ld_do * 2), 0));
+        }
+        nlse = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rlse, (uint32_t)r * 4u, row0 * 4u, 0));
+        ndel = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdel, (uint32_t)r * 4u, row0 * 4u, 0));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t row = row_of(q0 + 8 * u + (lane >> 3));
+          nq[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, row * (uint32_t)(p.ld_qkv * 2) + c16, 0, 0));
+          no_[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, row * (uint32_t)(bp.ld_do * 2) + c16, 0, 0));
+        }
         const uint32_t row = row_of(q0 + r);  // both lane halves ask for the same 32 rows (the upper half's copy is not used)
         nlse = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rlse, row * 4u, 0, 0));
         ndel = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdel, row * 4u, 0, 0));
@@ -212,14 +229,14 @@ __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd
         const int qp = s_lo + j * ATT_KB + r;
         const bool qok = qp < s_hi && (qp < ps.n0 || qp >= ps.pos1);
         const float ve = qok ? -nlse : ATT_NEG_BIG, vd = qok ? -ndel : 0.f;
+        // two bf16 terms each: 16 significant bits -- an error of 2^-17 |lse| < 2e-4 in the exponent, 1e-4 relative in P,
+        // against the 2^-9 of P's own rounding to bf16
         const bf16_t e0 = (bf16_t)ve, d0 = (bf16_t)vd;
-        const float re = ve - (float)e0, rdl = vd - (float)d0;
-        const bf16_t e1 = (bf16_t)re, d1 = (bf16_t)rdl;
-        const bf16_t e2 = (bf16_t)(re - (float)e1), d2 = (bf16_t)(rdl - (float)d1);
+        const bf16_t e1 = (bf16_t)(ve - (float)e0), d1 = (bf16_t)(vd - (float)d0);
         const bf16_t z = (bf16_t)0.f;
         const bool lo = hh == 0;
-        astat_e = (bf16x8){lo ? e0 : z, lo ? e1 : z, lo ? e2 : z, lo ? (bf16_t)1.0f : z, z, z, z, z};
-        astat_d = (bf16x8){lo ? d0 : z, lo ? d1 : z, lo ? d2 : z, z, z, z, z, z};
+        astat_e = (bf16x8){lo ? e0 : z, lo ? e1 : z, z, lo ? (bf16_t)1.0f : z, z, z, z, z};
+        astat_d = (bf16x8){lo ? d0 : z, lo ? d1 : z, z, z, z, z, z, z};
       }
       // ---- E = -lse + mask + Bias log2e + Q (c1 K)^T ;  dP = -delta + dO V^T --------------------------------------------------
       f32x16 e, dp;
@@ -259,13 +276,7 @@ __global__ __launch_bounds__(W * 64, 1) void attn_bwd_dkvb_kernel(const attn_bwd
       // ---- dV += P^T dO ,  dK += dS^T Q -------------------------------------------------------------------------------------------
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        u32x4 pw, dw;  // P and dS of rows 8 s2 .. 8 s2 + 7 as bf16 pairs (ONE v_cvt_pk_bf16_f32 per pair, nothing to re-pack)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          pw[jj] = dkvb_cvt_pk(e[8 * s2 + 2 * jj], e[8 * s2 + 2 * jj + 1]);
-          dw[jj] = dkvb_cvt_pk(dp[8 * s2 + 2 * jj], dp[8 * s2 + 2 * jj + 1]);
-        }
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), df = __builtin_bit_cast(bf16x8, dw);
+        const bf16x8 pf = dkvb_pack8(e, 8 * s2), df = dkvb_pack8(dp, 8 * s2);  // P and dS of rows 8 s2 .. 8 s2 + 7
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const s16x4 olo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dkvb_lds_s16x4*)(slot + 4096 + s2 * 2048 + tr_off[db][0]));

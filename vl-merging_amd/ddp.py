@@ -9,6 +9,7 @@ no gradient in a step (position_embeddings, mask_token, ...) stay
 reducer needs no unused-parameter discovery (the optimizer keeps the structural set of parameters a backward pass has
 written, engine.FlatParams.touched, and skips the rest as HF AdamW skips p.grad is None).  The 1/world average is folded into the fused AdamW kernel (grad_scale).
 """
+import os
 import re
 
 import torch
@@ -77,6 +78,15 @@ class FlatGradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # Data-parallel defaults from the single-GPU contention stand-in (profiles/r05_contention.json, tools/contention_sweep.py:
+        # every bucket's collective replaced by k workgroups holding a CU each + a copy of the bucket): the weight-gradient side
+        # stream stays ON (68.9-69.2 ms per step against 70.2-70.7 without it at k = 8..32), and the GEMM grids plan for 248
+        # of the 256 CUs (neutral at k <= 16, 70.6 -> 69.2 ms at k = 32).  VLM_GEMM_CUS in the environment overrides.
+        if self.world > 1 and not os.environ.get("VLM_GEMM_CUS"):
+            from . import _lib as L
+            lib = L.get_lib()
+            if lib.vlm_device_cus() >= 256:
+                lib.vlm_set_cu_budget(248)
         names_by_block = {}
         early, late = [], []
         for n in self.flat.names:

@@ -172,6 +172,17 @@ class FlatParams:
         self._ls_buf = buf
         self.ls_pending = set()
 
+    def shadow_reference(self):
+        """What the bf16 shadow buffer must hold right now (tests): bf16(master) everywhere, bf16(diag(gamma) W) in the weights
+        whose LayerScale is folded."""
+        ref = self.flat_p[:self.numel].to(BF16)
+        for jobs in getattr(self, "_ls_jobs", {}).values():
+            for j in jobs:
+                w = j["weight"]
+                o = (w.data_ptr() - self.flat_p.data_ptr()) // 4
+                ref[o:o + w.numel()] = (j["gamma"][:, None] * w).to(BF16).reshape(-1)
+        return ref
+
     def refresh_folded(self):
         jobs = getattr(self, "_ls_jobs", None)
         if jobs:
