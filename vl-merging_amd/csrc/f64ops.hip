@@ -21,7 +21,10 @@ __device__ __forceinline__ double f64_load<bf16_t>(const bf16_t* p) { return (do
 
 // One 64x64 output tile's accumulation over reduction rows [k0, k1): A-side and B-side panels are staged as
 // [F64_KC][64 + 1] doubles.  a(k, i) / b(k, j) are fetched through the functors (any layout / element type).
-template <typename FA, typename FB>
+// A_KC / B_KC: the operand is stored with the REDUCTION index contiguous (a row-major A, a transposed B): consecutive lanes then
+// fetch consecutive k of one row / column (16 x 8 B = one 128-B line per 16 lanes) instead of 64 different lines per wave
+// instruction -- round 5: RegMean's W G products and every GEMM of the blocked Cholesky / solves read at least one operand that way.
+template <bool A_KC = false, bool B_KC = false, typename FA, typename FB>
 __device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1, FA a_at, FB b_at, double (*sa)[F64_TILE + 1],
                                              double (*sb)[F64_TILE + 1]) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -34,10 +37,11 @@ __device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1,
   auto fetch = [&](int k) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int e = tid + 256 * u, kk = e >> 6, c = e & 63;
-      const bool ok = k + kk < k1;
-      ra[u] = ok ? a_at(k + kk, c) : 0.0;
-      rb[u] = ok ? b_at(k + kk, c) : 0.0;
+      const int e = tid + 256 * u;
+      const int ka = A_KC ? (e & (F64_KC - 1)) : (e >> 6), ca = A_KC ? (e / F64_KC) : (e & 63);
+      const int kb = B_KC ? (e & (F64_KC - 1)) : (e >> 6), cb = B_KC ? (e / F64_KC) : (e & 63);
+      ra[u] = k + ka < k1 ? a_at(k + ka, ca) : 0.0;
+      rb[u] = k + kb < k1 ? b_at(k + kb, cb) : 0.0;
     }
   };
   if (k0 < k1) fetch(k0);
@@ -45,9 +49,9 @@ __device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1,
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int e = tid + 256 * u, kk = e >> 6, c = e & 63;
-      sa[kk][c] = ra[u];
-      sb[kk][c] = rb[u];
+      const int e = tid + 256 * u;
+      sa[A_KC ? (e & (F64_KC - 1)) : (e >> 6)][A_KC ? (e / F64_KC) : (e & 63)] = ra[u];
+      sb[B_KC ? (e & (F64_KC - 1)) : (e >> 6)][B_KC ? (e / F64_KC) : (e & 63)] = rb[u];
     }
     __syncthreads();
     if (k + F64_KC < k1) fetch(k + F64_KC);
@@ -141,9 +145,13 @@ __device__ __forceinline__ void gemm_f64_body(int ta, int tb, int M, int N, int 
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
-  f64_tile_mac(acc, 0, K,
-               [&](int k, int c) { return i0 + c < M ? (double)(ta ? A[(size_t)k * lda + i0 + c] : A[(size_t)(i0 + c) * lda + k]) : 0.0; },
-               [&](int k, int c) { return j0 + c < N ? (tb ? B[(size_t)(j0 + c) * ldb + k] : B[(size_t)k * ldb + j0 + c]) : 0.0; }, sa, sb);
+  auto a_at = [&](int k, int c) { return i0 + c < M ? (double)(ta ? A[(size_t)k * lda + i0 + c] : A[(size_t)(i0 + c) * lda + k]) : 0.0; };
+  auto b_at = [&](int k, int c) { return j0 + c < N ? (tb ? B[(size_t)(j0 + c) * ldb + k] : B[(size_t)k * ldb + j0 + c]) : 0.0; };
+  // (ta, tb are launch-uniform) the reduction index is contiguous in a row-major A and in a transposed B
+  if (!ta && tb) f64_tile_mac<true, true>(acc, 0, K, a_at, b_at, sa, sb);
+  else if (!ta) f64_tile_mac<true, false>(acc, 0, K, a_at, b_at, sa, sb);
+  else if (tb) f64_tile_mac<false, true>(acc, 0, K, a_at, b_at, sa, sb);
+  else f64_tile_mac<false, false>(acc, 0, K, a_at, b_at, sa, sb);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
 #pragma unroll
