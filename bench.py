@@ -430,7 +430,7 @@ class TrainLeg:
         torch.cuda.empty_cache()
 
 
-def secondary_train_legs(mods, dev, rank, world, headline, force_dist=False, steps=4, warm=2):
+def secondary_train_legs(mods, dev, rank, world, headline, force_dist=False, steps=4, warm=2, image_size=384, batch=None):
     """The other data-parallel BASELINE configs, run by EVERY rank after the timed region (configs[2] all_moe B = 22 and
     configs[4] irtr on ufo B = 20 at 384^2, whichever is not the headline): whole-job samples/s over `steps` timed steps after
     `warm` warm-ups, fenced and MAX-reduced like the headline -- one `bench.py --gpus N` gives all three DP numbers."""
@@ -438,10 +438,10 @@ def secondary_train_legs(mods, dev, rank, world, headline, force_dist=False, ste
     for key, task, arch in (("ufo_b22", "pretrain", "ufo"), ("all_moe_b22", "pretrain", "all_moe"), ("irtr_ufo_b20", "irtr", "ufo")):
         if (task, arch) == headline:
             continue
-        B = TASKS[task][1]
+        B = batch or TASKS[task][1]
         err = torch.zeros(1, device=dev)
         try:
-            leg = TrainLeg(mods, task, arch, B, 384, rank, world, dev, force_dist)
+            leg = TrainLeg(mods, task, arch, B, image_size, rank, world, dev, force_dist)
         except Exception as e:  # a secondary leg must never take the headline number down with it
             out[key] = {"error": repr(e)}
             err += 1
@@ -830,11 +830,15 @@ def main():
     del leg, reducer
 
     secondary = {}
-    if not args.no_secondary and args.image_size == 384:
+    small = os.environ.get("VLM_BENCH_FORCE_SECONDARY", "0") != "0"  # tests: the legs at the headline's (small) geometry
+    if not args.no_secondary and (args.image_size == 384 or small):
         # every rank takes part: the other two data-parallel BASELINE workloads at this world size
         if rank == 0:
             _phase("secondary data-parallel legs")
-        secondary.update(secondary_train_legs(mods, dev, rank, world, (args.task, args.arch), force_dist))
+        secondary.update(secondary_train_legs(mods, dev, rank, world, (args.task, args.arch), force_dist,
+                                              image_size=args.image_size, batch=args.batch if small else None))
+    if rank == 0 and secondary and out is not None:
+        out["secondary"] = dict(secondary)
     if rank == 0:
         merge_check = None
         if not args.no_merge:

@@ -79,6 +79,14 @@ def test_bench_irtr_task_at_two_ranks_with_secondary_legs_and_step_parity():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and "task_finetune_irtr_coco" in d["config"]["workload"] and "configs[4]" in d["config"]["workload"]
     assert d["value"] > 0 and d["config"]["global_batch"] == 4
+    # the other two data-parallel workloads, run by both ranks after the headline (here at the small geometry)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--task", "irtr"] + [a for a in SMALL if a != "--no-secondary"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env_clean, VLM_BENCH_FORCE_SECONDARY="1", **env))
+    assert r.returncode == 0, r.stderr[-3000:]
+    sec = json.loads(r.stdout.strip().splitlines()[-1])["secondary"]
+    for k in ("ufo_b22", "all_moe_b22"):
+        assert k in sec and "error" not in sec[k] and sec[k]["n_gpus"] == 2 and sec[k]["samples_per_s"] > 0, (k, sec.get(k))
+    assert "irtr_ufo_b20" not in sec  # the headline itself
 
 
 @pytest.mark.gpu
