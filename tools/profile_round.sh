@@ -6,6 +6,7 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export VLM_BENCH_SETUP_STEPS=0  # the traces cover exactly warm-up + timed steps (6 steps), as in rounds 1-4
 CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary"
 # Two kernel traces of the same command.  (1) VLM_WGRAD_STREAM=0: every launch alone on the chip -- the per-kernel durations
 # that bench.py's roofline figure (whose bracketed steps also run without the side stream) has to agree with; the PMC passes
