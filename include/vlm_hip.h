@@ -342,6 +342,8 @@ int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, int ld, int 
  * them (RegMean's 36 solves of 768^2 and 12 of 3072^2, vilt_module.py:432-434: ~420 launches instead of ~5 000).  A_list / chol_list /
  * rhs_list: HOST arrays of device pointers; status: device int[count], zero on entry, verdict per matrix as in vlm_cholesky_f64.
  * Per matrix bit-identical to the unbatched calls. */
+int vlm_gemm_f64_batched(int ta, int tb, int M, int N, int K, double alpha, const void* const* A_list, int lda, int a_is_f32,
+                         const double* const* B_list, int ldb, double beta, double* const* C_list, int ldc, int count, void* stream);
 int vlm_cholesky_f64_batched(double* const* A_list, int count, int n, int* status, void* stream);
 int vlm_solve_spd_right_f64_batched(double* const* chol_list, int n, double* const* rhs_list, int ld, int rows, int count, void* stream);
 

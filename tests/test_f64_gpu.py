@@ -116,3 +116,34 @@ def test_batched_cholesky_and_solve_are_the_single_calls_bit_for_bit(ops):
         assert torch.equal(bx[i], single_x[i]), i
         want = rhs[i] @ torch.linalg.inv(mats[i])
         assert float((bx[i] - want).abs().max()) <= 1e-8 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("a32", [False, True])
+def test_batched_gemm_is_the_single_call_bit_for_bit(ops, a32):
+    """vlm_gemm_f64_batched (RegMean's W_m G'_m products of one shape in one launch, vilt_module.py:421-423): per product the bits of
+    vlm_gemm_f64, with and without the accumulate (second model's term); 70 products cross the 64-per-launch table."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    M, K, N, count = 100, 136, 72, 70
+    A = [torch.randn(M, K, device="cuda", dtype=torch.float32 if a32 else torch.float64, generator=gen) for _ in range(count)]
+    B = [torch.randn(K, N, device="cuda", dtype=torch.float64, generator=gen) for _ in range(count)]
+    C0 = [torch.randn(M, N, device="cuda", dtype=torch.float64, generator=gen) for _ in range(count)]
+    for beta in (0.0, 1.0):
+        single = [ops.gemm_f64(a, b, c.clone(), beta=beta) for a, b, c in zip(A, B, C0)]
+        got = ops.gemm_f64_batched(A, B, [c.clone() for c in C0], beta=beta)
+        for i in range(count):
+            assert torch.equal(got[i], single[i]), (beta, i)
+        want = A[7].double() @ B[7] + beta * C0[7]
+        assert float((got[7] - want).abs().max()) <= 1e-12 * float(want.abs().max())
+
+
+def test_gram_slices_fill_whole_rounds(ops):
+    """vlm_gram_f64 at the two capture widths with a row count that gives every slice count a chance: the accumulated G equals the
+    fp64 product of the bf16 rows whatever the slice count chosen for the launch."""
+    gen = torch.Generator(device="cuda"); gen.manual_seed(6)
+    for D, rows in ((768, 3001), (3072, 1500)):
+        x = torch.randn(rows, D, device="cuda", generator=gen).to(torch.bfloat16)
+        g = torch.zeros(D, D, device="cuda", dtype=torch.float64)
+        ops.gram_accumulate(x, g)
+        want = x.double().t() @ x.double()
+        assert float((g - want).abs().max()) <= 1e-11 * float(want.abs().max())
+        assert torch.equal(g, g.t())

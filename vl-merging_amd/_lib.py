@@ -142,6 +142,8 @@ SIGNATURES = {
     "vlm_trsm_block_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vlm_cholesky_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vlm_solve_spd_right_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "vlm_gemm_f64_batched": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.POINTER(c_void_p), c_int, c_int,
+                                     ctypes.POINTER(c_void_p), c_int, ctypes.c_double, ctypes.POINTER(c_void_p), c_int, c_int, c_void_p]),
     "vlm_cholesky_f64_batched": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]),
     "vlm_solve_spd_right_f64_batched": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "vlm_cross_entropy_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),

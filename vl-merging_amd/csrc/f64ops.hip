@@ -24,9 +24,16 @@ __device__ __forceinline__ double f64_load<bf16_t>(const bf16_t* p) { return (do
 // A_KC / B_KC: the operand is stored with the REDUCTION index contiguous (a row-major A, a transposed B): consecutive lanes then
 // fetch consecutive k of one row / column (16 x 8 B = one 128-B line per 16 lanes) instead of 64 different lines per wave
 // instruction -- round 5: RegMean's W G products and every GEMM of the blocked Cholesky / solves read at least one operand that way.
+// LDS images of a staged panel (round 5; conflict-free by the ds_read_b64 / ds_write_b64 lane-group rules, where the round-2
+// [16][64 + 1] image put the two reduction rows a 32-lane group reads on the same banks: every MFMA operand read took 2 x):
+//   operand stored with the OUTPUT index contiguous:    [kk][64 + 16]  (row stride 160 words = 32 mod 64: rows kk, kk + 1 in different halves)
+//   operand stored with the REDUCTION index contiguous: [c][16 + 2]    (row stride 36 words: 16 consecutive c land on 16 distinct bank quads)
+#define F64_LDS_DOUBLES 1280  // max(16 x 80, 64 x 18)
+template <bool KC>
+__device__ __forceinline__ int f64_lds_at(int kk, int c) { return KC ? c * (F64_KC + 2) + kk : kk * (F64_TILE + 16) + c; }
+
 template <bool A_KC = false, bool B_KC = false, typename FA, typename FB>
-__device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1, FA a_at, FB b_at, double (*sa)[F64_TILE + 1],
-                                             double (*sb)[F64_TILE + 1]) {
+__device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1, FA a_at, FB b_at, double* sa, double* sb) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
@@ -50,16 +57,16 @@ __device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1,
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tid + 256 * u;
-      sa[A_KC ? (e & (F64_KC - 1)) : (e >> 6)][A_KC ? (e / F64_KC) : (e & 63)] = ra[u];
-      sb[B_KC ? (e & (F64_KC - 1)) : (e >> 6)][B_KC ? (e / F64_KC) : (e & 63)] = rb[u];
+      sa[f64_lds_at<A_KC>(A_KC ? (e & (F64_KC - 1)) : (e >> 6), A_KC ? (e / F64_KC) : (e & 63))] = ra[u];
+      sb[f64_lds_at<B_KC>(B_KC ? (e & (F64_KC - 1)) : (e >> 6), B_KC ? (e / F64_KC) : (e & 63))] = rb[u];
     }
     __syncthreads();
     if (k + F64_KC < k1) fetch(k + F64_KC);
 #pragma unroll
     for (int k4 = 0; k4 < F64_KC; k4 += 4) {
       const int kk = k4 + (lane >> 4), c = lane & 15;
-      const double a0 = sa[kk][wi + c], a1 = sa[kk][wi + 16 + c];
-      const double b0 = sb[kk][wj + c], b1 = sb[kk][wj + 16 + c];
+      const double a0 = sa[f64_lds_at<A_KC>(kk, wi + c)], a1 = sa[f64_lds_at<A_KC>(kk, wi + 16 + c)];
+      const double b0 = sb[f64_lds_at<B_KC>(kk, wj + c)], b1 = sb[f64_lds_at<B_KC>(kk, wj + 16 + c)];
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
@@ -73,7 +80,7 @@ __device__ __forceinline__ void f64_tile_mac(f64x4 (&acc)[2][2], int k0, int k1,
 // the way out; the M rows are cut into gridDim.z slices that meet in G through fp64 atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void gram_f64_kernel(const T* __restrict__ x, int ldx, int M, int D, double* __restrict__ g) {
-  __shared__ double sa[F64_KC][F64_TILE + 1], sb[F64_KC][F64_TILE + 1];
+  __shared__ double sa[F64_LDS_DOUBLES], sb[F64_LDS_DOUBLES];
   // blockIdx.x enumerates tile pairs (ti <= tj)
   const int nt = (D + F64_TILE - 1) / F64_TILE;
   int ti = 0, rem = blockIdx.x;
@@ -118,10 +125,21 @@ extern "C" int vlm_gram_f64(const void* x, int ldx, int M, int D, int x_is_f32, 
   const int nt = (D + F64_TILE - 1) / F64_TILE, pairs = nt * (nt + 1) / 2;
   int cus = vlm_device_cus();
   if (cus <= 0) cus = 256;
-  int slices = (4 * cus + pairs - 1) / pairs;  // ~4 workgroups per CU
-  const int max_slices = (M + 4 * F64_KC - 1) / (4 * F64_KC);
-  if (slices > max_slices) slices = max_slices;
-  if (slices < 1) slices = 1;
+  // Row slices: the kernel keeps 4 workgroups per CU resident (116 registers per lane), every workgroup of a launch runs the same
+  // number of steps, so the launch takes ceil(workgroups / slots) rounds of equal length.  Round 4's "ceil(slots / pairs)" put
+  // D = 768 at 1092 workgroups on 1024 slots and D = 3072 at 1176: two rounds, the second nearly empty (0.53 / 0.57 of the time
+  // useful -- the whole of the round-4 "0.54 of the fp64 peak").  Take the slice count whose last round is fullest, with a small
+  // charge per slice for its 64 x 64 x 2 atomics on the way out.
+  const int slots = 4 * cus;
+  int max_slices = (M + 4 * F64_KC - 1) / (4 * F64_KC);
+  if (max_slices > 32) max_slices = 32;
+  int slices = 1;
+  double best = -1.0;
+  for (int s = 1; s <= max_slices; ++s) {
+    const long wgs = (long)pairs * s, rounds = (wgs + slots - 1) / slots;
+    const double score = (double)wgs / (double)(rounds * slots) - 0.004 * s;
+    if (score > best) { best = score; slices = s; }
+  }
   dim3 grid(pairs, 1, slices);
   if (x_is_f32)
     hipLaunchKernelGGL((gram_f64_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(x), ldx, M, D, gram);
@@ -138,7 +156,7 @@ template <typename TA_>
 __device__ __forceinline__ void gemm_f64_body(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
                                               int lda, const double* __restrict__ B, int ldb, double beta,
                                               double* __restrict__ C, int ldc) {
-  __shared__ double sa[F64_KC][F64_TILE + 1], sb[F64_KC][F64_TILE + 1];
+  __shared__ double sa[F64_LDS_DOUBLES], sb[F64_LDS_DOUBLES];
   const int i0 = blockIdx.y * F64_TILE, j0 = blockIdx.x * F64_TILE;
   f64x4 acc[2][2];
 #pragma unroll
@@ -169,9 +187,10 @@ __device__ __forceinline__ void gemm_f64_body(int ta, int tb, int M, int N, int 
 }
 
 template <typename TA_>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
+__global__ __launch_bounds__(256, 4) void gemm_f64_kernel(int ta, int tb, int M, int N, int K, double alpha, const TA_* __restrict__ A,
                                                        int lda, const double* __restrict__ B, int ldb, double beta,
-                                                       double* __restrict__ C, int ldc) {
+                                                       double* __restrict__ C, int ldc, int lower) {
+  if (lower && blockIdx.x > blockIdx.y) return;  // (a symmetric update: only the tiles on and below the diagonal)
   gemm_f64_body<TA_>(ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
@@ -182,26 +201,36 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int ta, int tb, int M, in
 struct f64_tab_t {
   double* p[VLM_F64_MAX_BATCH];
 };
-__global__ __launch_bounds__(256) void gemm_f64_batched_kernel(int ta, int tb, int M, int N, int K, double alpha, const f64_tab_t A,
+template <typename TA_ = double>
+__global__ __launch_bounds__(256, 4) void gemm_f64_batched_kernel(int ta, int tb, int M, int N, int K, double alpha, const f64_tab_t A,
                                                                size_t offA, int lda, const f64_tab_t B, size_t offB, int ldb,
-                                                               double beta, const f64_tab_t C, size_t offC, int ldc) {
-  gemm_f64_body<double>(ta, tb, M, N, K, alpha, A.p[blockIdx.z] + offA, lda, B.p[blockIdx.z] + offB, ldb, beta,
-                        C.p[blockIdx.z] + offC, ldc);
+                                                               double beta, const f64_tab_t C, size_t offC, int ldc, int lower) {
+  if (lower && blockIdx.x > blockIdx.y) return;
+  gemm_f64_body<TA_>(ta, tb, M, N, K, alpha, reinterpret_cast<const TA_*>(A.p[blockIdx.z]) + offA, lda, B.p[blockIdx.z] + offB, ldb,
+                     beta, C.p[blockIdx.z] + offC, ldc);
 }
 
-extern "C" int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32,
-                            const double* B, int ldb, double beta, double* C, int ldc, void* stream) {
+// lower: C is a symmetric update (M == N) of which only the tiles on and below the diagonal are computed -- the Cholesky trailing
+// update A22 -= L21 L21^T, whose upper triangle nothing reads (round 5: half the flops and half the C traffic of a K = 64 GEMM
+// that is bound by reading and writing C)
+static int gemm_f64_launch(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32, const double* B,
+                           int ldb, double beta, double* C, int ldc, int lower, void* stream) {
   if (M == 0 || N == 0) return VLM_OK;
   if (!A || !B || !C || M < 0 || N < 0 || K < 0 || ldc < N) return VLM_ERR_ARG;
   dim3 grid((N + F64_TILE - 1) / F64_TILE, (M + F64_TILE - 1) / F64_TILE);
   if (a_is_f32)
     hipLaunchKernelGGL((gemm_f64_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, ta, tb, M, N, K, alpha,
-                       reinterpret_cast<const float*>(A), lda, B, ldb, beta, C, ldc);
+                       reinterpret_cast<const float*>(A), lda, B, ldb, beta, C, ldc, lower);
   else
     hipLaunchKernelGGL((gemm_f64_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, ta, tb, M, N, K, alpha,
-                       reinterpret_cast<const double*>(A), lda, B, ldb, beta, C, ldc);
+                       reinterpret_cast<const double*>(A), lda, B, ldb, beta, C, ldc, lower);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
+}
+
+extern "C" int vlm_gemm_f64(int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda, int a_is_f32,
+                            const double* B, int ldb, double beta, double* C, int ldc, void* stream) {
+  return gemm_f64_launch(ta, tb, M, N, K, alpha, A, lda, a_is_f32, B, ldb, beta, C, ldc, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- G' = a G + (1-a) diag(G), summed
@@ -370,7 +399,7 @@ extern "C" int vlm_cholesky_f64(double* A, int n, int* status, void* stream) {
       rc = vlm_trsm_block_f64(A, n, j0, nb, 1, below, n, r, j0, stream);  // panel: L21 = A21 L11^-T
       if (rc) return rc;
       // trailing update A22 -= L21 L21^T
-      rc = vlm_gemm_f64(0, 1, r, r, nb, -1.0, below + j0, n, 0, below + j0, n, 1.0, below + j0 + nb, n, stream);
+      rc = gemm_f64_launch(0, 1, r, r, nb, -1.0, below + j0, n, 0, below + j0, n, 1.0, below + j0 + nb, n, 1, stream);
       if (rc) return rc;
     }
   }
@@ -418,10 +447,30 @@ static int f64_tab(double* const* list, int count, f64_tab_t& t) {
 }
 static int gemm_f64_batched(int ta, int tb, int M, int N, int K, double alpha, const f64_tab_t& A, size_t offA, int lda,
                             const f64_tab_t& B, size_t offB, int ldb, double beta, const f64_tab_t& C, size_t offC, int ldc, int count,
-                            hipStream_t s) {
+                            hipStream_t s, int lower = 0) {
   if (M <= 0 || N <= 0) return VLM_OK;
   dim3 grid((N + F64_TILE - 1) / F64_TILE, (M + F64_TILE - 1) / F64_TILE, count);
-  hipLaunchKernelGGL(gemm_f64_batched_kernel, grid, dim3(256), 0, s, ta, tb, M, N, K, alpha, A, offA, lda, B, offB, ldb, beta, C, offC, ldc);
+  hipLaunchKernelGGL((gemm_f64_batched_kernel<double>), grid, dim3(256), 0, s, ta, tb, M, N, K, alpha, A, offA, lda, B, offB, ldb, beta, C, offC, ldc, lower);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// `count` products of ONE shape in one launch (round 5: RegMean's 96 W_m G'_m products ran one 144..576-workgroup launch each on
+// 1024 slots; per shape they now fill the chip).  Per matrix bit-identical to vlm_gemm_f64.
+extern "C" int vlm_gemm_f64_batched(int ta, int tb, int M, int N, int K, double alpha, const void* const* A_list, int lda, int a_is_f32,
+                                    const double* const* B_list, int ldb, double beta, double* const* C_list, int ldc, int count,
+                                    void* stream) {
+  if (M == 0 || N == 0 || count == 0) return VLM_OK;
+  if (M < 0 || N < 0 || K < 0 || ldc < N) return VLM_ERR_ARG;
+  f64_tab_t A, B, C;
+  int rc = f64_tab(reinterpret_cast<double* const*>(const_cast<void* const*>(A_list)), count, A);
+  if (!rc) rc = f64_tab(const_cast<double* const*>(B_list), count, B);
+  if (!rc) rc = f64_tab(C_list, count, C);
+  if (rc) return rc;
+  if (!a_is_f32) return gemm_f64_batched(ta, tb, M, N, K, alpha, A, 0, lda, B, 0, ldb, beta, C, 0, ldc, count, (hipStream_t)stream);
+  dim3 grid((N + F64_TILE - 1) / F64_TILE, (M + F64_TILE - 1) / F64_TILE, count);
+  hipLaunchKernelGGL((gemm_f64_batched_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, ta, tb, M, N, K, alpha, A, (size_t)0, lda,
+                     B, (size_t)0, ldb, beta, C, (size_t)0, ldc, 0);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
@@ -441,7 +490,7 @@ extern "C" int vlm_cholesky_f64_batched(double* const* A_list, int count, int n,
       const size_t below = (size_t)(j0 + nb) * n;
       hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((r + 3) / 4, count), dim3(256), 0, s, A, (size_t)0, n, j0, nb, 1, A, below, n, r, j0);
       VLM_CHECK_LAUNCH();
-      rc = gemm_f64_batched(0, 1, r, r, nb, -1.0, A, below + j0, n, A, below + j0, n, 1.0, A, below + j0 + nb, n, count, s);
+      rc = gemm_f64_batched(0, 1, r, r, nb, -1.0, A, below + j0, n, A, below + j0, n, 1.0, A, below + j0 + nb, n, count, s, 1);
       if (rc) return rc;
     }
   }

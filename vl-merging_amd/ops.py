@@ -501,6 +501,34 @@ def _ptr_list(ts):
     return arr
 
 
+def gemm_f64_batched(a_list, b_list, c_list, alpha=1.0, beta=0.0):
+    """c[i] = alpha * a[i] @ b[i] + beta * c[i] for products of ONE shape, one launch per 64 of them (vlm_gemm_f64_batched);
+    a: contiguous float64 or float32 [M,K] (one dtype), b / c: contiguous float64."""
+    if not (len(a_list) == len(b_list) == len(c_list)):
+        raise L.VlmError("gemm_f64_batched: three lists of one length")
+    if not a_list:
+        return c_list
+    L.require_cuda(*a_list, *b_list, *c_list)
+    a0, b0, c0 = a_list[0], b_list[0], c_list[0]
+    M, K = a0.shape
+    N = b0.shape[1]
+    for a, b, c in zip(a_list, b_list, c_list):
+        if a.dtype != a0.dtype or a.dtype not in (F64, F32) or b.dtype != F64 or c.dtype != F64 or tuple(a.shape) != (M, K) \
+                or tuple(b.shape) != (K, N) or tuple(c.shape) != (M, N) or not (a.is_contiguous() and b.is_contiguous() and c.is_contiguous()):
+            raise L.VlmError("gemm_f64_batched: contiguous a [M,K] (one of float64/float32), float64 b [K,N], c [M,N] of one shape")
+    if K == 0:
+        if beta == 0.0:
+            for c in c_list:
+                c.zero_()
+        return c_list
+    for i in range(0, len(a_list), F64_MAX_BATCH):
+        j = i + F64_MAX_BATCH
+        L.check(L.get_lib().vlm_gemm_f64_batched(0, 0, M, N, K, float(alpha), _ptr_list(a_list[i:j]), K, int(a0.dtype == F32),
+                                                 _ptr_list(b_list[i:j]), N, float(beta), _ptr_list(c_list[i:j]), N,
+                                                 len(a_list[i:j]), L.stream_ptr()), "vlm_gemm_f64_batched")
+    return c_list
+
+
 def cholesky_batched_(mats, status):
     """cholesky_ of every matrix of `mats` (contiguous float64 [n, n], ONE n) in lock step: each block step is one launch over all
     of them (vlm_cholesky_f64_batched).  status: int32 device tensor [len(mats)], zero on entry."""

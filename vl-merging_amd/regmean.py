@@ -44,18 +44,21 @@ class _Solves:
     def submit(self, num, den, what):
         if len(self.jobs) >= self.MAX_JOBS:
             raise RuntimeError("regmean: more than %d solves in one merge" % self.MAX_JOBS)
-        # both are overwritten in place; the copies serve the fallback
-        self.jobs.append((what, num, den, den.clone(), num.clone()))
+        self.jobs.append([what, num, den, None, None])
         return num
 
-    def finish(self, out):
+    def launch(self):
+        """Issue every factorisation and solve (no synchronisation).  The numerators may still be in flight on the stream when this
+        is called: the copies kept for the fallback are taken here, in stream order after them (both are overwritten in place)."""
         if not self.jobs:
             return
+        for job in self.jobs:
+            job[3], job[4] = job[2].clone(), job[1].clone()
         groups = {}
         for i, (what, num, den, _, _) in enumerate(self.jobs):
             groups.setdefault((den.shape[0], num.shape[0], num.stride(0)), []).append(i)
         order = [i for key in sorted(groups) for i in groups[key]]  # status slots in issue order
-        slot = {j: k for k, j in enumerate(order)}
+        self.slot = {j: k for k, j in enumerate(order)}
         k0 = 0
         for key in sorted(groups):
             idx = groups[key]
@@ -63,7 +66,13 @@ class _Solves:
             ops.cholesky_batched_(dens, self.status[k0:k0 + len(idx)])
             ops.solve_spd_right_batched_([self.jobs[i][1] for i in idx], dens)
             k0 += len(idx)
-        verdict = self.status[:len(self.jobs)].tolist()  # ONE synchronisation for all solves
+
+    def collect(self, out):
+        """Read the verdicts (ONE synchronisation for all solves) and replace what has no Cholesky factor."""
+        if not self.jobs:
+            return
+        slot = self.slot
+        verdict = self.status[:len(self.jobs)].tolist()
         for j, (what, num, den, keep_den, keep_num) in enumerate(self.jobs):
             bad = verdict[slot[j]]
             if bad:
@@ -73,6 +82,10 @@ class _Solves:
                 inv = torch.linalg.inv(keep_den).contiguous()
                 out[what] = ops.gemm_f64(keep_num, inv, torch.empty_like(num))
         self.jobs = []
+
+    def finish(self, out):
+        self.launch()
+        self.collect(out)
 
 
 def _solve(num, den, what):
@@ -84,8 +97,43 @@ def _solve(num, den, what):
     return out.get(what, res)
 
 
+class _Products:
+    """The numerators' terms num (+)= W_m.double() @ G'_m (:421-423), collected per (term, shape) and run `count` at a time in one
+    launch (round 5: one product is 144..576 workgroups on 1024 slots).  A group is flushed as soon as it holds four rounds of
+    workgroups, so the device starts while the host is still walking the layers; a weight's term 0 (beta = 0) always precedes its
+    term 1 on the stream."""
+
+    ROUNDS = 4 * 1024
+
+    def __init__(self):
+        self.groups = {}
+
+    def add(self, term, W, Gs, num):
+        key = (tuple(W.shape), W.dtype)
+        g = self.groups.setdefault(key, {})
+        g.setdefault(term, []).append((W, Gs, num))
+        tiles = -(-W.shape[0] // 64) * -(-Gs.shape[1] // 64)
+        if tiles * len(g[term]) >= self.ROUNDS:
+            self._flush(key, upto=term)
+
+    def _flush(self, key, upto=None):
+        g = self.groups[key]
+        for term in sorted(g):
+            if upto is not None and term > upto:
+                break
+            if g[term]:
+                ws, gs, ns = zip(*g[term])
+                ops.gemm_f64_batched(list(ws), list(gs), list(ns), beta=0.0 if term == 0 else 1.0)
+                g[term] = []
+
+    def flush(self):
+        for key in list(self.groups):
+            self._flush(key)
+        self.groups = {}
+
+
 def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None):
-    out = M._passthrough(state_dict)
+    passthrough = M._passthrough(state_dict)
     if gram_matrices is None:
         from . import checkpoint
         gram_matrices = checkpoint.load_file(config["gram_matrices"])
@@ -93,15 +141,19 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
     plan = M.MergePlan(device)
     dev = plan.device
     solves = _Solves(dev)
+    products = _Products()
+    merged, order, plain = {}, [], []
+    # first the linear weights of every layer (they feed the device: ~150 launches of products, then the solves' ~420), then the
+    # plain averages' bookkeeping while those run; `out` is assembled in the reference's key order at the end
     for i in range(M.NUM_MERGE_LAYERS):
         mods = M.modalities_for_layer(config, i, honour_only_used=False)
         for src, dst in M._tensor_names(i):
+            order.append(dst)
             is_weight = dst.endswith(".weight") and "norm" not in dst
             if not is_weight:
-                srcs, through = M._collect(state_dict, src, dst, mods)
-                out[dst] = through if srcs is None else plan.add(L.MERGE_MEAN, [t for _, t in srcs], None)
+                plain.append((src, dst, mods))
                 continue
-            num, den, through = None, None, None
+            num, den, through, terms = None, None, None, 0
             for m in mods:
                 name = src(m)
                 gname = name.replace(".qkv.weight", "") if "qkv" in name else name.replace(".weight", "")
@@ -115,22 +167,31 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
                     W = W.contiguous() if W.dtype in (torch.float32, torch.float64) else W.double().contiguous()
                     if num is None:
                         den = Gs
-                        num = ops.gemm_f64(W, Gs, torch.empty(W.shape[0], G.shape[0], device=dev, dtype=torch.float64))
+                        num = torch.empty(W.shape[0], G.shape[0], device=dev, dtype=torch.float64)
                     else:
-                        ops.gemm_f64(W, Gs, num, beta=1.0)               # num += W_m.double() @ G'_m   (:421-423)
                         den = den + Gs
+                    products.add(terms, W, Gs, num)                      # num (+)= W_m.double() @ G'_m   (:421-423)
+                    terms += 1
                 else:
                     through = state_dict[dst]
                     break
             if through is not None:
-                out[dst] = through
+                merged[dst] = through
             elif num is None:
-                out[dst] = 0  # the reference's untouched accumulator (no modality had a gram; does not occur in practice)
+                merged[dst] = 0  # the reference's untouched accumulator (no modality had a gram; does not occur in practice)
             else:
-                out[dst] = solves.submit(num, den, dst)
-    solves.finish(out)
+                merged[dst] = solves.submit(num, den, dst)
+    products.flush()
+    solves.launch()
+    for src, dst, mods in plain:
+        srcs, through = M._collect(state_dict, src, dst, mods)
+        merged[dst] = through if srcs is None else plan.add(L.MERGE_MEAN, [t for _, t in srcs], None)
     if plan.jobs:
         plan.run()
+    solves.collect(merged)
+    out = passthrough
+    for dst in order:
+        out[dst] = merged[dst]
     if plan_out is not None:
         plan_out.append(plan)
     return out
