@@ -175,10 +175,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
   store(0, 0);
   __syncthreads();
 
+  ATT_STAMP_DECL()
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const int kp0 = sp.s_lo + t * ATT_BK;
+    ATT_STAMP(slot++);  // trip start
     load(t + 1);
+    ATT_STAMP(slot++);  // next tile requested
     const unsigned char* lk = ldsK + cur * ATT_TILE_BYTES;
     const unsigned char* lkt = ldsKt + cur * ATT_TILE_BYTES;
     const unsigned char* lv = ldsV + cur * ATT_TILE_BYTES;
@@ -200,6 +203,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
         e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ss], qf[ss], e, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ss], dof[ss], dp, 0, 0, 0);
       }
+      // the next tile's bias rows of this block: same registers, consumed by the selection MFMAs above -- requested HERE, a block
+      // (kb = 1) to a tile and a half (kb = 0) before their use (round 5: the four loads used to be issued at the end of the trip,
+      // one LDS store + barrier before the first selection MFMA of the next trip: an L2 round trip exposed per 64 keys).  Past the
+      // last tile the rows are out of the descriptor's range (zeros, unused).
+      if (HAS_BIAS) att_bias_load_half(bw, kb, rbias, bvoff, t + 1);
+      ATT_STAMP(slot++);  // score / dP chains issued
       if (masked) {  // workgroup-uniform
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) e[i] = att_exp2(e[i]) * dp[i];  // dS^T (natural units, unscaled)
+      ATT_STAMP(slot++);  // dS known
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 df;
@@ -221,9 +231,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(const attn_
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, df, o[db], 0, 0, 0);
         }
       }
+      ATT_STAMP(slot++);  // dQ products issued
     }
-    if (HAS_BIAS) att_bias_load(bw, rbias, bvoff, t + 1);  // same registers, consumed next trip (past the last tile: unused)
     store(t + 1, cur ^ 1);
+    ATT_STAMP(slot++);  // next tile in LDS
     __syncthreads();
   }
 #pragma unroll
@@ -907,7 +918,12 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   if (pl.W) {
     // dQ (+ delta), then dK / dV and the bias-table gradient in ONE launch: 7 MFMA products per score instead of 9
     bp.nstat = nullptr;  // (the 16-wave kernel's C operands are not needed)
+#ifdef VLM_DIAG  // harness only: VLM_DIAG_DQ_PAD_LDS=bytes of unused dynamic LDS (40960: one workgroup per CU instead of two)
+    static const size_t dq_pad = [] { const char* e = getenv("VLM_DIAG_DQ_PAD_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, dq_pad, s, bp);
+#else
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
+#endif
     VLM_CHECK_LAUNCH();
     const size_t need = hr + (size_t)pl.items * p.R;
     bp.dbias_part = ws_floats >= need ? delta_ws + hr : nullptr;
