@@ -8,6 +8,7 @@
 // MFMA f64 16x16x4 operand layout: A[16][4]: lane l holds A[l & 15][l >> 4]; B[4][16]: lane l holds B[l >> 4][l & 15];
 // C/D[16][16]: register r of lane l holds row 4*r + (l >> 4) of column l & 15.
 #include "vlm_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) double f64x4;
 
@@ -329,6 +330,7 @@ extern "C" int vlm_potrf_block_f64(double* A, int lda, int j0, int nb, int* stat
 // workgroups fill the chip, the row is read and written as one coalesced 512-B piece.  (History: a runtime-indexed `double v[64]`
 // per thread lived in scratch memory, 201 us per launch; fully unrolled in registers it was instruction-fetch bound, 62 us.)
 // A ragged block (nb < 64) is padded with the identity.
+#define F64_TRSM_ROWS 4  // rows per wave; a workgroup (4 waves) covers 16 (8: 34 instead of 31 us per launch)
 __device__ __forceinline__ void trsm_block_body(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
                                                 double* __restrict__ Bm, int ldb, int rows, int c0) {
   __shared__ double s[64][65];
@@ -341,27 +343,40 @@ __device__ __forceinline__ void trsm_block_body(const double* __restrict__ L, in
   __syncthreads();
   if (tid < 64) invd[tid] = 1.0 / s[tid][tid];
   __syncthreads();
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= rows) return;  // wave-uniform
-  double* x = Bm + (size_t)row * ldb + c0;
-  double b = lane < nb ? x[lane] : 0.0;
+  // F64_TRSM_ROWS rows per wave (round 5; one row per wave before): the block load above is shared by 16 rows instead of 4 and the four
+  // rows' substitution chains are independent -- their readlane / fma latencies hide each other.  Per row the same operations in the
+  // same order as ever.
+  const int row0 = (blockIdx.x * 4 + wave) * F64_TRSM_ROWS;
+  if (row0 >= rows) return;  // wave-uniform
+  double* x = Bm + (size_t)row0 * ldb + c0;
+  double b[F64_TRSM_ROWS];
+#pragma unroll
+  for (int i = 0; i < F64_TRSM_ROWS; ++i) b[i] = (lane < nb && row0 + i < rows) ? x[(size_t)i * ldb + lane] : 0.0;
   const double rd = invd[lane];
   if (trans) {  // X L^T = B:  x_k = (b_k - sum_{j<k} x_j L[k][j]) / L[k][k];  after x_k: b_j -= x_k L[j][k] for j > k
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
-      const double xk = f64_readlane(b, k) * f64_readlane(rd, k);
-      const double ljk = s[lane][k];
-      b = lane == k ? xk : (lane > k ? __builtin_fma(-xk, ljk, b) : b);
+      const double rdk = f64_readlane(rd, k), ljk = s[lane][k];
+#pragma unroll
+      for (int i = 0; i < F64_TRSM_ROWS; ++i) {
+        const double xk = f64_readlane(b[i], k) * rdk;
+        b[i] = lane == k ? xk : (lane > k ? __builtin_fma(-xk, ljk, b[i]) : b[i]);
+      }
     }
   } else {      // X L = B:    x_k = (b_k - sum_{j>k} x_j L[j][k]) / L[k][k];  after x_k: b_j -= x_k L[k][j] for j < k
 #pragma unroll
     for (int k = 63; k >= 0; --k) {
-      const double xk = f64_readlane(b, k) * f64_readlane(rd, k);
-      const double lkj = s[k][lane];
-      b = lane == k ? xk : (lane < k ? __builtin_fma(-xk, lkj, b) : b);
+      const double rdk = f64_readlane(rd, k), lkj = s[k][lane];
+#pragma unroll
+      for (int i = 0; i < F64_TRSM_ROWS; ++i) {
+        const double xk = f64_readlane(b[i], k) * rdk;
+        b[i] = lane == k ? xk : (lane < k ? __builtin_fma(-xk, lkj, b[i]) : b[i]);
+      }
     }
   }
-  if (lane < nb) x[lane] = b;
+#pragma unroll
+  for (int i = 0; i < F64_TRSM_ROWS; ++i)
+    if (lane < nb && row0 + i < rows) x[(size_t)i * ldb + lane] = b[i];
 }
 
 __global__ __launch_bounds__(256) void trsm_block_kernel(const double* __restrict__ L, int ldl, int l0, int nb, int trans,
@@ -377,7 +392,7 @@ extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int 
                                   void* stream) {
   if (nb == 0 || rows == 0) return VLM_OK;
   if (!L || !Bm || nb < 0 || nb > 64 || rows < 0 || l0 < 0 || c0 < 0) return VLM_ERR_ARG;
-  hipLaunchKernelGGL(trsm_block_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, L, ldl, l0, nb, trans, Bm, ldb,
+  hipLaunchKernelGGL(trsm_block_kernel, dim3((rows + 4 * F64_TRSM_ROWS - 1) / (4 * F64_TRSM_ROWS)), dim3(256), 0, (hipStream_t)stream, L, ldl, l0, nb, trans, Bm, ldb,
                      rows, c0);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
@@ -386,57 +401,8 @@ extern "C" int vlm_trsm_block_f64(const double* L, int ldl, int l0, int nb, int 
 // ---------------------------------------------------------------------------------------------------- blocked drivers
 // The whole factorisation / solve as ONE call: the block-column loops run here instead of in the Python host code (a 3072^2
 // factor is 48 block columns x 3 launches, the solve 2 x 48 x 2 more: issuing them through ctypes cost more host time than the
-// kernels take).  Same kernels, same order, same results as the per-block entry points above.
-extern "C" int vlm_cholesky_f64(double* A, int n, int* status, void* stream) {
-  if (n == 0) return VLM_OK;
-  if (!A || n < 0 || !status) return VLM_ERR_ARG;
-  for (int j0 = 0; j0 < n; j0 += 64) {
-    const int nb = n - j0 < 64 ? n - j0 : 64, r = n - j0 - nb;
-    int rc = vlm_potrf_block_f64(A, n, j0, nb, status, stream);
-    if (rc) return rc;
-    if (r > 0) {
-      double* below = A + (size_t)(j0 + nb) * n;
-      rc = vlm_trsm_block_f64(A, n, j0, nb, 1, below, n, r, j0, stream);  // panel: L21 = A21 L11^-T
-      if (rc) return rc;
-      // trailing update A22 -= L21 L21^T
-      rc = gemm_f64_launch(0, 1, r, r, nb, -1.0, below + j0, n, 0, below + j0, n, 1.0, below + j0 + nb, n, 1, stream);
-      if (rc) return rc;
-    }
-  }
-  return VLM_OK;
-}
-
-// rhs [rows][ld] <- rhs (L L^T)^-1 in place: Y L^T = rhs forward over the block columns, then X L = Y backward.
-// RIGHT-looking: as soon as a block column of the solution is known, the columns still to be solved are updated by one GEMM
-// over ALL of them (rows x (n - j1) outputs, K = 64) -- a left-looking sweep would compute each 64-column block with one
-// GEMM of rows / 64 workgroups and a reduction up to n long: 12 workgroups on 256 CUs for a [768, 3072] right-hand side.
-extern "C" int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, int ld, int rows, void* stream) {
-  if (n == 0 || rows == 0) return VLM_OK;
-  if (!chol || !rhs || n < 0 || rows < 0 || ld < n) return VLM_ERR_ARG;
-  for (int j0 = 0; j0 < n; j0 += 64) {  // Y[:, jb] = B[:, jb] L[jb, jb]^-T ;  B[:, j1:] -= Y[:, jb] L[j1:, jb]^T
-    const int nb = n - j0 < 64 ? n - j0 : 64, j1 = j0 + nb;
-    int rc = vlm_trsm_block_f64(chol, n, j0, nb, 1, rhs, ld, rows, j0, stream);
-    if (rc) return rc;
-    if (j1 < n) {
-      rc = vlm_gemm_f64(0, 1, rows, n - j1, nb, -1.0, rhs + j0, ld, 0, chol + (size_t)j1 * n + j0, n, 1.0, rhs + j1, ld, stream);
-      if (rc) return rc;
-    }
-  }
-  for (int j0 = ((n - 1) / 64) * 64; j0 >= 0; j0 -= 64) {  // X[:, jb] = Y[:, jb] L[jb, jb]^-1 ;  Y[:, :j0] -= X[:, jb] L[jb, :j0]
-    const int nb = n - j0 < 64 ? n - j0 : 64;
-    int rc = vlm_trsm_block_f64(chol, n, j0, nb, 0, rhs, ld, rows, j0, stream);
-    if (rc) return rc;
-    if (j0 > 0) {
-      rc = vlm_gemm_f64(0, 0, rows, j0, nb, -1.0, rhs + j0, ld, 0, chol + (size_t)j0 * n, n, 1.0, rhs, ld, stream);
-      if (rc) return rc;
-    }
-  }
-  return VLM_OK;
-}
-
-
-// ---- batched drivers: `count` (<= VLM_F64_MAX_BATCH) matrices of ONE shape; same kernels, same order, same results per matrix as
-// vlm_cholesky_f64 / vlm_solve_spd_right_f64 ----------------------------------------------------------------------------------------
+// kernels take).  Built from the block kernels above and the tile GEMM; `count` (<= VLM_F64_MAX_BATCH) matrices of ONE shape walk
+// in lock step, every step ONE launch over all of them; the single-matrix entry points are the same code at count = 1.
 static int f64_tab(double* const* list, int count, f64_tab_t& t) {
   if (!list || count <= 0 || count > VLM_F64_MAX_BATCH) return VLM_ERR_ARG;
   for (int i = 0; i < count; ++i) {
@@ -475,6 +441,17 @@ extern "C" int vlm_gemm_f64_batched(int ta, int tb, int M, int N, int K, double 
   return VLM_OK;
 }
 
+// Blocking (round 5): the factorisation and the solves walk 64-wide block columns (the block kernels' width), but the updates
+// that touch everything to the right are taken once per F64_BIG = 256 columns with K = 256 -- a K = 64 update GEMM is bound by reading
+// and writing its C (the trailing matrix / the right-hand side's remaining columns: 35 GB per RegMean merge at the base width, 21 ms of
+// its 49); inside a 256-column block the next 64 columns first receive the block's earlier columns' contribution (a GEMM with 64
+// output columns), left-looking.  Same flops, a quarter of the C traffic, the same number of launches.
+static int f64_big(void) {  // VLM_F64_BIG: experiments
+  static const int v = [] { const char* e = getenv("VLM_F64_BIG"); const int x = e ? atoi(e) : 256; return x >= 64 && x % 64 == 0 ? x : 256; }();
+  return v;
+}
+#define F64_BIG f64_big()
+
 extern "C" int vlm_cholesky_f64_batched(double* const* A_list, int count, int n, int* status, void* stream) {
   if (n == 0 || count == 0) return VLM_OK;
   if (n < 0 || !status) return VLM_ERR_ARG;
@@ -482,21 +459,34 @@ extern "C" int vlm_cholesky_f64_batched(double* const* A_list, int count, int n,
   int rc = f64_tab(A_list, count, A);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  for (int j0 = 0; j0 < n; j0 += 64) {
-    const int nb = n - j0 < 64 ? n - j0 : 64, r = n - j0 - nb;
-    hipLaunchKernelGGL(potrf_block_batched_kernel, dim3(count), dim3(64), 0, s, A, n, j0, nb, status);
-    VLM_CHECK_LAUNCH();
-    if (r > 0) {
-      const size_t below = (size_t)(j0 + nb) * n;
-      hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((r + 3) / 4, count), dim3(256), 0, s, A, (size_t)0, n, j0, nb, 1, A, below, n, r, j0);
+  for (int J0 = 0; J0 < n; J0 += F64_BIG) {
+    const int J1 = J0 + F64_BIG < n ? J0 + F64_BIG : n;
+    for (int c = J0; c < J1; c += 64) {
+      const int nb = n - c < 64 ? n - c : 64, c1 = c + nb, r = n - c1;
+      if (c > J0) {  // A[c:, c:c1] -= L[c:, J0:c] L[c:c1, J0:c]^T
+        rc = gemm_f64_batched(0, 1, n - c, nb, c - J0, -1.0, A, (size_t)c * n + J0, n, A, (size_t)c * n + J0, n, 1.0, A, (size_t)c * n + c, n, count, s);
+        if (rc) return rc;
+      }
+      hipLaunchKernelGGL(potrf_block_batched_kernel, dim3(count), dim3(64), 0, s, A, n, c, nb, status);
       VLM_CHECK_LAUNCH();
-      rc = gemm_f64_batched(0, 1, r, r, nb, -1.0, A, below + j0, n, A, below + j0, n, 1.0, A, below + j0 + nb, n, count, s, 1);
+      if (r > 0) {  // panel: L[c1:, c:c1] = A[c1:, c:c1] L[c:c1, c:c1]^-T
+        hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((r + 4 * F64_TRSM_ROWS - 1) / (4 * F64_TRSM_ROWS), count), dim3(256), 0, s, A, (size_t)0, n, c, nb, 1, A, (size_t)c1 * n, n, r, c);
+        VLM_CHECK_LAUNCH();
+      }
+    }
+    const int r = n - J1;
+    if (r > 0) {  // trailing update A[J1:, J1:] -= L[J1:, J0:J1] L[J1:, J0:J1]^T, tiles on and below the diagonal
+      rc = gemm_f64_batched(0, 1, r, r, J1 - J0, -1.0, A, (size_t)J1 * n + J0, n, A, (size_t)J1 * n + J0, n, 1.0, A, (size_t)J1 * n + J1, n, count, s, 1);
       if (rc) return rc;
     }
   }
   return VLM_OK;
 }
 
+// rhs [rows][ld] <- rhs (L L^T)^-1 in place: Y L^T = rhs forward over the block columns, then X L = Y backward.  RIGHT-looking
+// across the 256-column blocks: as soon as a block of the solution is known the columns still to be solved are updated by ONE GEMM
+// over all of them (rows x (n - J1) outputs) -- a left-looking sweep would compute each block with rows / 64 workgroups and a
+// reduction up to n long: 12 workgroups on 256 CUs for a [768, 3072] right-hand side.
 extern "C" int vlm_solve_spd_right_f64_batched(double* const* chol_list, int n, double* const* rhs_list, int ld, int rows, int count,
                                                void* stream) {
   if (n == 0 || rows == 0 || count == 0) return VLM_OK;
@@ -507,23 +497,52 @@ extern "C" int vlm_solve_spd_right_f64_batched(double* const* chol_list, int n, 
   rc = f64_tab(rhs_list, count, R);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  for (int j0 = 0; j0 < n; j0 += 64) {
-    const int nb = n - j0 < 64 ? n - j0 : 64, j1 = j0 + nb;
-    hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((rows + 3) / 4, count), dim3(256), 0, s, Lt, (size_t)0, n, j0, nb, 1, R, (size_t)0, ld, rows, j0);
-    VLM_CHECK_LAUNCH();
-    if (j1 < n) {
-      rc = gemm_f64_batched(0, 1, rows, n - j1, nb, -1.0, R, (size_t)j0, ld, Lt, (size_t)j1 * n + j0, n, 1.0, R, (size_t)j1, ld, count, s);
+  for (int J0 = 0; J0 < n; J0 += F64_BIG) {  // Y L^T = B
+    const int J1 = J0 + F64_BIG < n ? J0 + F64_BIG : n;
+    for (int c = J0; c < J1; c += 64) {
+      const int nb = n - c < 64 ? n - c : 64;
+      if (c > J0) {  // B[:, c:c1] -= Y[:, J0:c] L[c:c1, J0:c]^T
+        rc = gemm_f64_batched(0, 1, rows, nb, c - J0, -1.0, R, (size_t)J0, ld, Lt, (size_t)c * n + J0, n, 1.0, R, (size_t)c, ld, count, s);
+        if (rc) return rc;
+      }
+      hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((rows + 4 * F64_TRSM_ROWS - 1) / (4 * F64_TRSM_ROWS), count), dim3(256), 0, s, Lt, (size_t)0, n, c, nb, 1, R, (size_t)0, ld, rows, c);
+      VLM_CHECK_LAUNCH();
+    }
+    if (J1 < n) {  // B[:, J1:] -= Y[:, J0:J1] L[J1:, J0:J1]^T
+      rc = gemm_f64_batched(0, 1, rows, n - J1, J1 - J0, -1.0, R, (size_t)J0, ld, Lt, (size_t)J1 * n + J0, n, 1.0, R, (size_t)J1, ld, count, s);
       if (rc) return rc;
     }
   }
-  for (int j0 = ((n - 1) / 64) * 64; j0 >= 0; j0 -= 64) {
-    const int nb = n - j0 < 64 ? n - j0 : 64;
-    hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((rows + 3) / 4, count), dim3(256), 0, s, Lt, (size_t)0, n, j0, nb, 0, R, (size_t)0, ld, rows, j0);
-    VLM_CHECK_LAUNCH();
-    if (j0 > 0) {
-      rc = gemm_f64_batched(0, 0, rows, j0, nb, -1.0, R, (size_t)j0, ld, Lt, (size_t)j0 * n, n, 1.0, R, (size_t)0, ld, count, s);
+  for (int J0 = ((n - 1) / F64_BIG) * F64_BIG; J0 >= 0; J0 -= F64_BIG) {  // X L = Y
+    const int J1 = J0 + F64_BIG < n ? J0 + F64_BIG : n;
+    for (int c = J0 + ((J1 - J0 - 1) / 64) * 64; c >= J0; c -= 64) {
+      const int nb = n - c < 64 ? n - c : 64, c1 = c + nb;
+      if (c1 < J1) {  // Y[:, c:c1] -= X[:, c1:J1] L[c1:J1, c:c1]
+        rc = gemm_f64_batched(0, 0, rows, nb, J1 - c1, -1.0, R, (size_t)c1, ld, Lt, (size_t)c1 * n + c, n, 1.0, R, (size_t)c, ld, count, s);
+        if (rc) return rc;
+      }
+      hipLaunchKernelGGL(trsm_block_batched_kernel, dim3((rows + 4 * F64_TRSM_ROWS - 1) / (4 * F64_TRSM_ROWS), count), dim3(256), 0, s, Lt, (size_t)0, n, c, nb, 0, R, (size_t)0, ld, rows, c);
+      VLM_CHECK_LAUNCH();
+    }
+    if (J0 > 0) {  // Y[:, :J0] -= X[:, J0:J1] L[J0:J1, :J0]
+      rc = gemm_f64_batched(0, 0, rows, J0, J1 - J0, -1.0, R, (size_t)J0, ld, Lt, (size_t)J0 * n, n, 1.0, R, (size_t)0, ld, count, s);
       if (rc) return rc;
     }
   }
   return VLM_OK;
+}
+
+// The single-matrix calls are the batched ones at count = 1 (one algorithm, one set of kernels: bit-identical by construction).
+extern "C" int vlm_cholesky_f64(double* A, int n, int* status, void* stream) {
+  if (n == 0) return VLM_OK;
+  if (!A || n < 0 || !status) return VLM_ERR_ARG;
+  double* list[1] = {A};
+  return vlm_cholesky_f64_batched(list, 1, n, status, stream);
+}
+extern "C" int vlm_solve_spd_right_f64(const double* chol, int n, double* rhs, int ld, int rows, void* stream) {
+  if (n == 0 || rows == 0) return VLM_OK;
+  if (!chol || !rhs || n < 0 || rows < 0 || ld < n) return VLM_ERR_ARG;
+  double* cl[1] = {const_cast<double*>(chol)};
+  double* rl[1] = {rhs};
+  return vlm_solve_spd_right_f64_batched(cl, n, rl, ld, rows, 1, stream);
 }

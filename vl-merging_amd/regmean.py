@@ -20,6 +20,16 @@ def scale_gram(G, alpha):
     return alpha * G + (1 - alpha) * torch.diag_embed(torch.diag(G))
 
 
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    pool = _SIDE.setdefault(torch.device(device).index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool
+
+
 class _Solves:
     """The 48 independent W* = num @ inverse(den) solves of a merge (:432-434), float64, on the device.  The sum of
     a*G + (1-a)*diag(G) over SPD Gram matrices is SPD, so each is a blocked Cholesky factorisation + two triangular solves --
@@ -59,13 +69,27 @@ class _Solves:
             groups.setdefault((den.shape[0], num.shape[0], num.stride(0)), []).append(i)
         order = [i for key in sorted(groups) for i in groups[key]]  # status slots in issue order
         self.slot = {j: k for k, j in enumerate(order)}
-        k0 = 0
+        # One stream per shape group (round 5): a group's factorisation + solve is a chain of ~300 small dependent launches (a block
+        # factor is ONE wave per matrix, a panel solve a few hundred workgroups), and the groups are independent -- side by side the
+        # 768-wide groups hide under the 3072-wide one.  The largest group stays on the caller's stream.
+        main = torch.cuda.current_stream(self.device)
+        keys = sorted(groups, key=lambda k: -k[0] * k[0] * len(groups[k]))
+        starts, k0 = {}, 0
         for key in sorted(groups):
+            starts[key] = k0
+            k0 += len(groups[key])
+        side = _side_streams(self.device, len(keys) - 1)
+        for n_, key in enumerate(keys):
             idx = groups[key]
-            dens = [self.jobs[i][2] for i in idx]
-            ops.cholesky_batched_(dens, self.status[k0:k0 + len(idx)])
-            ops.solve_spd_right_batched_([self.jobs[i][1] for i in idx], dens)
-            k0 += len(idx)
+            st = main if n_ == 0 else side[n_ - 1]
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                dens = [self.jobs[i][2] for i in idx]
+                ops.cholesky_batched_(dens, self.status[starts[key]:starts[key] + len(idx)])
+                ops.solve_spd_right_batched_([self.jobs[i][1] for i in idx], dens)
+        for st in side[:len(keys) - 1]:
+            main.wait_stream(st)
 
     def collect(self, out):
         """Read the verdicts (ONE synchronisation for all solves) and replace what has no Cholesky factor."""
