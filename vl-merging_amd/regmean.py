@@ -57,13 +57,13 @@ class _Solves:
         self.jobs.append([what, num, den, None, None])
         return num
 
-    def launch(self):
+    def launch(self, small_ready=None):
         """Issue every factorisation and solve (no synchronisation).  The numerators may still be in flight on the stream when this
-        is called: the copies kept for the fallback are taken here, in stream order after them (both are overwritten in place)."""
+        is called: the copies kept for the fallback are taken here, in stream order after them (both are overwritten in place).
+        small_ready: an event after which every product with a reduction of <= 1 024 is complete (_Products.small_event) -- the
+        768-wide groups' side streams wait for IT, not for the whole caller's stream, and start under the 3 072-wide products."""
         if not self.jobs:
             return
-        for job in self.jobs:
-            job[3], job[4] = job[2].clone(), job[1].clone()
         groups = {}
         for i, (what, num, den, _, _) in enumerate(self.jobs):
             groups.setdefault((den.shape[0], num.shape[0], num.stride(0)), []).append(i)
@@ -83,8 +83,13 @@ class _Solves:
             idx = groups[key]
             st = main if n_ == 0 else side[n_ - 1]
             if st is not main:
-                st.wait_stream(main)
+                if small_ready is not None and key[0] <= 1024:
+                    st.wait_event(small_ready)
+                else:
+                    st.wait_stream(main)
             with torch.cuda.stream(st):
+                for i in idx:  # (on the group's own stream: before its in-place factorisation, after its products)
+                    self.jobs[i][3], self.jobs[i][4] = self.jobs[i][2].clone(), self.jobs[i][1].clone()
                 dens = [self.jobs[i][2] for i in idx]
                 ops.cholesky_batched_(dens, self.status[starts[key]:starts[key] + len(idx)])
                 ops.solve_spd_right_batched_([self.jobs[i][1] for i in idx], dens)
@@ -123,14 +128,15 @@ def _solve(num, den, what):
 
 class _Products:
     """The numerators' terms num (+)= W_m.double() @ G'_m (:421-423), collected per (term, shape) and run `count` at a time in one
-    launch (round 5: one product is 144..576 workgroups on 1024 slots).  A group is flushed as soon as it holds four rounds of
+    launch (round 5: one product is 144..576 workgroups on 1024 slots).  A group is flushed as soon as it holds eight rounds of
     workgroups, so the device starts while the host is still walking the layers; a weight's term 0 (beta = 0) always precedes its
     term 1 on the stream."""
 
-    ROUNDS = 4 * 1024
+    ROUNDS = 8 * 1024  # (1 024 / 2 048 / 4 096 / 8 192 tiles: 0.042 / 0.039 / 0.038-0.044 / 0.037-0.038 s per merge)
 
     def __init__(self):
         self.groups = {}
+        self.small_event = None  # recorded after the latest launch of products whose reduction is <= 1 024 long
 
     def add(self, term, W, Gs, num):
         key = (tuple(W.shape), W.dtype)
@@ -149,9 +155,12 @@ class _Products:
                 ws, gs, ns = zip(*g[term])
                 ops.gemm_f64_batched(list(ws), list(gs), list(ns), beta=0.0 if term == 0 else 1.0)
                 g[term] = []
+                if key[0][1] <= 1024:
+                    self.small_event = torch.cuda.Event()
+                    self.small_event.record()
 
     def flush(self):
-        for key in list(self.groups):
+        for key in sorted(self.groups, key=lambda k: k[0][1]):  # short reductions first: their solves may start under the long ones
             self._flush(key)
         self.groups = {}
 
@@ -206,7 +215,7 @@ def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None
             else:
                 merged[dst] = solves.submit(num, den, dst)
     products.flush()
-    solves.launch()
+    solves.launch(small_ready=products.small_event)
     for src, dst, mods in plain:
         srcs, through = M._collect(state_dict, src, dst, mods)
         merged[dst] = through if srcs is None else plan.add(L.MERGE_MEAN, [t for _, t in srcs], None)
