@@ -59,7 +59,9 @@ def test_scale_gram(ops):
     assert torch.equal(out, want + want)
 
 
-@pytest.mark.parametrize("n,rows", [(64, 10), (200, 333), (768, 3072), (3072, 768)])
+# (264, 520, 600: the 256-column blocks of the drivers end in a ragged block / a ragged 64-column step; 17 / 50 rows: fewer than one
+# workgroup of the triangular block solve)
+@pytest.mark.parametrize("n,rows", [(64, 10), (200, 333), (264, 17), (520, 50), (600, 129), (768, 3072), (3072, 768)])
 def test_cholesky_solve_matches_inverse(ops, n, rows):
     g = torch.Generator(device="cuda"); g.manual_seed(n)
     x = torch.randn(n + 64, n, device="cuda", generator=g, dtype=torch.float64)
