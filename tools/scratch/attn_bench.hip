@@ -4,6 +4,7 @@
 // Run (GPU box):          tools/scratch/attn_bench [B] [mode 0 joint / 1 separate] [bias 0/1]
 #include "../../vl-merging_amd/csrc/attention_fwd.hip"
 #include "../../vl-merging_amd/csrc/attention_bwd.hip"
+#include "../../vl-merging_amd/csrc/attention_fwd2.hip"
 #include <cstdio>
 #include <cmath>
 #include <cstring>

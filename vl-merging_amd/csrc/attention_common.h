@@ -125,6 +125,9 @@ static inline int att_fill_params(const vlm_attn_desc_t* d, attn_params_t& p) {
   return VLM_OK;
 }
 
+// attention_fwd2.hip: 1 = launched, 0 = not a call for the hand-placed kernel, < 0 = error
+int att_fwd2_launch(const attn_params_t& p, hipStream_t s);
+
 // Bias byte-offsets (4 x relative-position index) of this lane's 32 (row, col) pairs of one 64-wide tile: 8 loads of
 // 8 B (4 consecutive columns each) from row `row` of `mat`, columns col0 + 32*kb + 8*g4 + 4*hh.  They are issued one
 // tile AHEAD (right after the previous tile's scores are formed, into the same 16 registers) so that their L2

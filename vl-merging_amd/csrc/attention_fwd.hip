@@ -253,6 +253,11 @@ extern "C" int vlm_attention_fwd(const vlm_attn_desc_t* d, void* out, int ld_out
   const size_t smem = 0;
   dim3 grid(att_grid_size(nt, p.seq.B, p.H)), block(ATT_THREADS);
   hipStream_t s = (hipStream_t)stream;
+  if (p.bias_t) {  // the hand-placed stream (attention_fwd2.hip) takes the calls it covers
+    const int r2 = att_fwd2_launch(p, s);
+    if (r2 < 0) return r2;
+    if (r2 == 1) return VLM_OK;
+  }
   if (p.bias_t) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, block, smem, s, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, block, smem, s, p);
   VLM_CHECK_LAUNCH();
