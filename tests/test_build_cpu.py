@@ -66,3 +66,21 @@ def test_attention_kernels_keep_their_occupancy(resources):
             continue  # the four-wave form of the fused dK/dV + bias-gradient kernel (480^2 panels): one wave per SIMD by design
         if "attn_fwd_kernel" in name or "attn_bwd_dq" in name or "attn_bwd_dkv" in name or "attn_bwd_dbias" in name:
             assert o >= 2, (name, o)
+
+
+def test_hand_placed_forward_fits_two_waves_per_simd(resources):
+    """attn_fwd2_kernel's stream names its registers (v32..v191, a0..a63): 192 + 64 = the 256 a wave may have at two waves
+    per SIMD.  One register more and the second workgroup of a CU -- the one that covers a workgroup's prologue -- is gone."""
+    r = [v for k, v in resources.items() if "attn_fwd2_kernel" in k]
+    assert len(r) == 1
+    r = r[0]
+    assert r["Occupancy"] == 2 and r["VGPRs"] <= 192 and r["AGPRs"] == 64, r
+    assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and 2 * r["LDS Size"] <= 160 * 1024, r
+
+
+def test_generated_stream_is_current():
+    """csrc/attention_fwd2_body.inc is what csrc/gen/attn_fwd2_gen.py writes."""
+    import subprocess
+    import sys
+    gen = os.path.join(CSRC, "gen", "attn_fwd2_gen.py")
+    assert subprocess.call([sys.executable, gen, "--check"]) == 0, "run python vl-merging_amd/csrc/gen/attn_fwd2_gen.py"

@@ -85,8 +85,10 @@ int main(int argc, char** argv) {
     unsigned long long st[8 * 64];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(att_stamps), sizeof(st)));
     for (int w = 0; w < 8; w += 4) {
-      printf("wave %d deltas:", w);
-      for (int i = 1; i < 60 && st[w * 64 + i]; ++i) printf(" %llu", st[w * 64 + i] - st[w * 64 + i - 1]);
+      printf("wave %d stamps (slot:delta to the previous stamped slot):", w);
+      unsigned long long prev = 0;
+      for (int i = 0; i < 60; ++i)
+        if (st[w * 64 + i]) { if (prev) printf(" %d:%llu", i, st[w * 64 + i] - prev); prev = st[w * 64 + i]; }
       printf("\n");
       if (st[w * 64 + 61] > st[w * 64 + 60])
         printf("wave %d clock: %.3f GHz (slots 20..50: %llu shader cycles in %llu x 10 ns)\n", w,

@@ -24,7 +24,7 @@
 #include "vlm_diag.h"
 #include <stdlib.h>
 
-#define F2_STAGE 32768
+#define F2_STAGE 16384
 #define F2_NSTAGE 4
 #define F2_KM (F2_NSTAGE * F2_STAGE)
 #define F2_LDS (F2_KM + 2048)
@@ -32,17 +32,18 @@
 typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
 typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
 
-// v96..v175 (S, P, K / V fragments) and v206..v223 (temporaries, current addresses) belong to the stream
-#define F2_CLOBBER_V                                                                                                            \
-  "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",   \
-  "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126",       \
-  "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141",       \
-  "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156",       \
-  "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171",       \
-  "v172", "v173", "v174", "v175", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216",       \
-  "v217", "v218", "v219", "v220", "v221", "v222", "v223"
+// v88..v159 (S, P, K / V fragments), v168..v179 (statistics operands) and v186..v191 (temporaries) belong to the stream;
+// v0..v31 stay with the compiler
+#define F2_CLOBBER_V \
+  "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+  "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", \
+  "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", \
+  "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", \
+  "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", \
+  "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v186", "v187", \
+  "v188", "v189", "v190", "v191"
 
-__global__ __launch_bounds__(ATT_THREADS, 1) void attn_fwd2_kernel(const attn_params_t p) {
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_params_t p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[F2_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -57,19 +58,56 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_fwd2_kernel(const attn_pa
   const int D = p.H * 64;
   const int bs[2] = {2 * bp, 2 * bp + 1 < ps.B ? 2 * bp + 1 : 2 * bp};  // an odd batch's last pair computes sample 0 twice
   const bool has1 = 2 * bp + 1 < ps.B;
-
-  const int qp = sp.p0 + wave * 32 + r;
   const int ntiles = (sp.s_hi - sp.s_lo + ATT_BK - 1) / ATT_BK;
-  bool qvalid[2];
-  size_t qrow[2];
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(att_lds_void*)lds;
+  const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv), 0, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000);
+  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
+  const uint32_t bvoff = att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + wave, lane);
+  const uint32_t rb_bytes = (uint32_t)p.dense_tiles * 4096u;
+  const _Float16* bias_col = p.dense + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048;
+  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(bias_col), 0, rb_bytes, 0x00020000);
+
+  // ---- prologue (1): everything that goes to memory first -- bias rows of tile 0, blocks 0 and 1 of both samples, sample 0's
+  // pieces of block 2 (one LDS-DMA piece = this wave's 8 rows of a 32-key block), the mask words
+  u32x4 b0w[2];  // key block 0's operands (the stream re-requests the set for every following block)
+  b0w[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff, 0, 0));
+  b0w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff + 1024, 0, 0));
+  const uint32_t drow = (uint32_t)wave * 8u + (uint32_t)(lane >> 3), c16 = lane & 7;
+  const uint32_t voffK = (drow * p.ld_qkv + ((c16 ^ (drow & 7)) << 3)) * 2u;
+  const uint32_t voffV = (drow * p.ld_qkv + (((((c16 >> 1) ^ (((drow >> 1) & 1) << 1)) << 1) | (c16 & 1)) << 3)) * 2u;
+  auto stage_block = [&](int blk, int s) {
+    const int kp0 = sp.s_lo + blk * 32, pq = kp0 + (int)drow;
+    const bool txt = pq < ps.n0, img = pq >= ps.pos1 && pq < ps.NP;
+    const bool ok = (txt || img) && pq < sp.s_hi;
+    const int first = txt ? ps.base0 + bs[s] * ps.n0 + kp0 : ps.base1 + bs[s] * ps.n1 + (kp0 - ps.pos1);
+    const uint32_t rowoff = (uint32_t)first * (uint32_t)p.ld_qkv * 2u;
+    unsigned char* dst = lds + (blk & 3) * F2_STAGE + s * 4096 + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rkv, (att_lds_void*)dst, 16, ok ? rowoff + (uint32_t)(D + h * 64) * 2u + voffK : 0xFFFFFFF0u, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rkv, (att_lds_void*)(dst + 8192), 16, ok ? rowoff + (uint32_t)(2 * D + h * 64) * 2u + voffV : 0xFFFFFFF0u, 0, 0, 0);
+  };
+  stage_block(0, 0);
+  stage_block(0, 1);
+  stage_block(1, 0);
+  stage_block(1, 1);
+  stage_block(2, 0);
+  {
+    const int t = tid >> 7, s = (tid >> 6) & 1, k = tid & 63;
+    const float mk = att_key_mask(ps, bs[s], sp.s_lo + t * ATT_BK + k, sp.s_hi, p.keep0, p.keep1);
+    *reinterpret_cast<uint32_t*>(lds + F2_KM + tid * 4) = mk < 0.f ? 0xC6EAu : 0u;  // bf16(-30 000) in k-slot 2
+    *reinterpret_cast<uint32_t*>(lds + F2_KM + 1024 + tid * 4) = 0u;
+  }
+
+  // ---- prologue (2): Q fragments and the per-lane constants of the stream, while the tiles are in flight -------------------
+  const int qp = sp.p0 + wave * 32 + r;
   u32x16 qv[2];
   const float c1 = p.scale * ATT_LOG2E;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int raw = qp < sp.s_hi ? att_row_of(ps, bs[s], qp) : -1;
-    qvalid[s] = raw >= 0;
-    qrow[s] = qvalid[s] ? (size_t)raw : (size_t)att_row_of(ps, bs[s], sp.s_lo);
-    const bf16_t* qptr = p.qkv + qrow[s] * p.ld_qkv + h * 64 + 8 * hh;
+    const size_t qrow = raw >= 0 ? (size_t)raw : (size_t)att_row_of(ps, bs[s], sp.s_lo);
+    const bf16_t* qptr = p.qkv + qrow * p.ld_qkv + h * 64 + 8 * hh;
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
       const bf16x8 rawq = *reinterpret_cast<const bf16x8*>(qptr + 16 * ss);
@@ -81,14 +119,8 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_fwd2_kernel(const attn_pa
       for (int e = 0; e < 4; ++e) qv[s][4 * ss + e] = w[e];
     }
   }
-
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(att_lds_void*)lds;
-  const att_dma_t dk = att_dma_init<false>(p.ld_qkv, wave, lane), dv = att_dma_init<true>(p.ld_qkv, wave, lane);
-  const att_dense_layout_t dl = att_dense_layout(ps.n0, ps.n1, ps.pos1, p.mode);
-  const uint32_t bvoff = att_bias_voff(dl, sp.part, sp.tile_in_part * 4 + wave, lane);
-
-  // ---- per-lane constants of the stream ---------------------------------------------------------------------------------
-  u32x16 ad, cs;
+  u32x16 ad;
+  u32x8 cs;
 #pragma unroll
   for (int ss = 0; ss < 4; ++ss) ad[ss] = lds0 + r * 128 + (((2 * ss + hh) ^ (r & 7)) << 4);
   {
@@ -102,61 +134,28 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_fwd2_kernel(const attn_pa
   const uint32_t zword = lds0 + F2_KM + 1024 + r * 4;
   ad[6] = hh == 0 ? lds0 + F2_KM + r * 4 : zword;
   ad[7] = zword;
-  ad[15] = hh == 0 ? lds0 + F2_KM + 512 + r * 4 : zword;
-  ad[8] = dk.off[0]; ad[9] = dk.off[1]; ad[10] = dv.off[0]; ad[11] = dv.off[1];
-  ad[12] = dk.row[0]; ad[13] = dk.row[1];
-  ad[14] = bvoff;
+  ad[8] = voffK; ad[9] = voffV; ad[10] = drow; ad[11] = bvoff;
+  ad[12] = hh == 0 ? lds0 + F2_KM + 512 + r * 4 : zword;
+  ad[13] = 0xFFFFFFF0u;
+  ad[14] = 0u; ad[15] = 0u;
   {
     f16x8 sel0, sel1;
     att_select_frags(lane, sel0, sel1);
     const u32x4 a0 = __builtin_bit_cast(u32x4, sel0), a1 = __builtin_bit_cast(u32x4, sel1);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { cs[e] = a0[e]; cs[4 + e] = a1[e]; cs[8 + e] = 0x3F803F80u; cs[12 + e] = 0u; }
-    cs[12] = 0xFFFFFFF0u;
+    for (int e = 0; e < 4; ++e) { cs[e] = a0[e]; cs[4 + e] = a1[e]; }
   }
   const uint64_t qa = (uint64_t)(uintptr_t)p.qkv;
   const u32x4 rkv4 = {(uint32_t)qa, (uint32_t)(qa >> 32) & 0xffffu, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000u};
-  const uint64_t ba = (uint64_t)(uintptr_t)(p.dense + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048);
-  const u32x4 rb4 = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, (uint32_t)p.dense_tiles * 4096u, 0x00020000u};
-  const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.qkv), 0, rkv4[2], 0x00020000);
-  const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<_Float16*>(p.dense + (size_t)(p.head_row0 + h) * p.dense_tiles * 2048), 0, rb4[2], 0x00020000);
-
-  // ---- prologue: bias rows of tile 0, tiles 0 and 1 of both samples, sample 0's K pieces of tile 2, mask words -----------
-  att_bias_t b0;
-  att_bias_load(b0, rbias, bvoff, 0);
-  u32x16 bwv;
+  const uint64_t ba = (uint64_t)(uintptr_t)bias_col;
+  const u32x4 rb4 = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, rb_bytes, 0x00020000u};
+  u32x8 bwv;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { bwv[e] = b0.w[0][0][e]; bwv[4 + e] = b0.w[0][1][e]; bwv[8 + e] = b0.w[1][0][e]; bwv[12 + e] = b0.w[1][1][e]; }
-  {
-    const int t = tid >> 7, s = (tid >> 6) & 1, k = tid & 63;
-    const float mk = att_key_mask(ps, bs[s], sp.s_lo + t * ATT_BK + k, sp.s_hi, p.keep0, p.keep1);
-    *reinterpret_cast<uint32_t*>(lds + F2_KM + tid * 4) = mk < 0.f ? 0xC6EAu : 0u;  // bf16(-30 000) in k-slot 2
-    *reinterpret_cast<uint32_t*>(lds + F2_KM + 1024 + tid * 4) = 0u;
-  }
-  auto stage_tile = [&](int t, int s, bool k_only) {
-    const int kp0 = sp.s_lo + t * ATT_BK;
-    unsigned char* dstK = lds + t * F2_STAGE + s * 8192;
-    unsigned char* dstV = dstK + 16384;
-    if (att_tile_plain(ps, kp0, sp.s_hi)) {
-      att_dma_plain(rkv, dstK, dk, ps, bs[s], kp0, p.ld_qkv, D + h * 64, wave);
-      if (!k_only) att_dma_plain(rkv, dstV, dv, ps, bs[s], kp0, p.ld_qkv, 2 * D + h * 64, wave);
-    } else {
-      att_dma_any(rkv, dstK, dk, ps, bs[s], kp0, sp.s_hi, p.ld_qkv, D + h * 64, wave);
-      if (!k_only) att_dma_any(rkv, dstV, dv, ps, bs[s], kp0, sp.s_hi, p.ld_qkv, 2 * D + h * 64, wave);
-    }
-  };
-  stage_tile(0, 0, false);
-  stage_tile(0, 1, false);
-  if (ntiles > 1) { stage_tile(1, 0, false); stage_tile(1, 1, false); }
-  if (ntiles > 2) stage_tile(2, 0, true);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- the stream's scalar state: the DMA tile is tile 2 ------------------------------------------------------------------
+  for (int e = 0; e < 4; ++e) { bwv[e] = b0w[0][e]; bwv[4 + e] = b0w[1][e]; }
+  // the stream's scalar state: the DMA block is block 2 (its sample-1 pieces are the stream's first two)
   u32x8 sc;
   {
-    const int kp2 = sp.s_lo + 2 * ATT_BK;
+    const int kp2 = sp.s_lo + 64;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const uint32_t first = (uint32_t)(ps.base1 + bs[s] * ps.n1 + (kp2 - ps.pos1));
@@ -165,34 +164,47 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_fwd2_kernel(const attn_pa
     }
     sc[4] = (uint32_t)ntiles;
     sc[5] = (uint32_t)(sp.s_hi - kp2);
-    sc[6] = lds0 + 2 * F2_STAGE + (uint32_t)wave * 2048u;
-    sc[7] = (uint32_t)p.ld_qkv * 128u;
+    sc[6] = lds0 + (uint32_t)wave * 1024u;
+    sc[7] = (uint32_t)p.ld_qkv * 64u;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
-  ATT_STAMP(1);
-  f32x16 o00, o01, o10, o11, l0, l1;
-  u32x16 bw_out;
-  float m_out[2];
-  u32x8 sc_out;
+  ATT_STAMP(20);
+  f32x16 o00, o01, o10, o11;
+  u32x16 ad_out;
+  u32x8 sc_out, bw_out;
+  float m_out[2], l_out[4];
+  // the thread index goes THROUGH the statement: whatever the epilogue needs per lane (its rows, its validity) is recomputed
+  // from the copy that comes out, so that no per-lane value has to stay in a register across the stream (the stream owns
+  // v32..v191 and a0..a63 of the 256 registers a wave may have at two waves per SIMD)
+  int tid2 = tid;
   asm volatile(
 #include "attention_fwd2_body.inc"
-      : "={a[0:15]}"(o00), "={a[16:31]}"(o01), "={a[32:47]}"(o10), "={a[48:63]}"(o11), "={a[64:79]}"(l0), "={a[80:95]}"(l1),
-        "={v204}"(m_out[0]), "={v205}"(m_out[1]), "={v[176:191]}"(bw_out), "={s[48:55]}"(sc_out)
-      : "{v[32:47]}"(ad), "{v[48:63]}"(cs), "{v[64:79]}"(qv[0]), "{v[80:95]}"(qv[1]), "8"(bwv), "9"(sc),
-        "{s[40:43]}"(rkv4), "{s[44:47]}"(rb4), "{s64}"(lds0)
-      : F2_CLOBBER_V, "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s65", "vcc", "scc", "memory");
+      : "={a[0:15]}"(o00), "={a[16:31]}"(o01), "={a[32:47]}"(o10), "={a[48:63]}"(o11), "={v180}"(m_out[0]), "={v181}"(m_out[1]),
+        "={v182}"(l_out[0]), "={v183}"(l_out[1]), "={v184}"(l_out[2]), "={v185}"(l_out[3]), "={v[160:167]}"(bw_out),
+        "={s[48:55]}"(sc_out), "={v[32:47]}"(ad_out), "+v"(tid2)
+      : "{v[48:55]}"(cs), "{v[56:71]}"(qv[0]), "{v[72:87]}"(qv[1]), "10"(bwv), "11"(sc), "12"(ad), "{s[40:43]}"(rkv4),
+        "{s[44:47]}"(rb4)
+      : F2_CLOBBER_V, "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory");
 
-  ATT_STAMP(2);
+  ATT_STAMP(50);
   // ---- epilogue -----------------------------------------------------------------------------------------------------------
+  const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6), hh2 = lane2 >> 5;
+  const int qp2 = sp.p0 + wave2 * 32 + (lane2 & 31);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const f32x16& oa = s ? o10 : o00;
     const f32x16& ob = s ? o11 : o01;
-    const float lt = s ? l1[0] : l0[0];
+    // a lane's 16 score registers are the keys of ITS half-wave (rows (i & 3) + 8 (i >> 2) + 4 hh of a block): the two halves'
+    // partial sums meet here
+    const float lh = l_out[2 * s] + l_out[2 * s + 1];
+    const float lt = lh + __shfl_xor(lh, 32, 64);
     const float m = m_out[s];
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
-    if (qvalid[s] && (s == 0 || has1)) {
-      bf16_t* op = p.out + qrow[s] * p.ld_out + h * 64 + 4 * hh;
+    const int raw = qp2 < sp.s_hi ? att_row_of(ps, bs[s], qp2) : -1;
+    if (raw >= 0 && (s == 0 || has1)) {
+      bf16_t* op = p.out + (size_t)raw * p.ld_out + h * 64 + 4 * hh2;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -202,24 +214,24 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_fwd2_kernel(const attn_pa
           for (int e = 0; e < 4; ++e) v[e] = (bf16_t)((db ? ob : oa)[4 * g4 + e] * inv);
           *reinterpret_cast<bf16x4*>(op + db * 32 + 8 * g4) = v;
         }
-      if (hh == 0 && p.lse) p.lse[(size_t)h * p.total_rows + qrow[s]] = m + log2f(lt);
+      if (hh2 == 0 && p.lse) p.lse[(size_t)h * p.total_rows + raw] = m + log2f(lt);
     }
   }
-  ATT_STAMP(3);
+  ATT_STAMP(51);
 }
 
-// The geometries the stream covers: a dense bias table, no image keep mask (its mask words exist for tiles 0 and 1 only: the
-// text segment and the gap must end inside them), everything the 32-bit buffer offsets reach.
+// The geometries the stream covers: a dense bias table, no image keep mask (its mask words exist for tiles 0 and 1 only, and its
+// own loads start at position 64 with image rows: the text segment and the gap must end inside tile 0), 32-bit buffer offsets.
 static bool att_fwd2_eligible(const attn_params_t& p) {
   if (!p.dense || p.keep1) return false;
-  if (p.seq.pos1 > 2 * ATT_BK) return false;
+  if (p.seq.pos1 > ATT_BK) return false;
   if ((size_t)p.total_rows * p.ld_qkv * 2 >= (1ull << 32)) return false;
   return true;
 }
 
 // returns 1 when it has launched the call, 0 when the call is not for this kernel, < 0 on error
 int att_fwd2_launch(const attn_params_t& p, hipStream_t s) {
-  static const int enabled = [] { const char* e = getenv("VLM_ATT_FWD2"); return e ? atoi(e) : 0; }();
+  static const int enabled = [] { const char* e = getenv("VLM_ATT_FWD2"); return e ? atoi(e) : 1; }();
   if (!enabled || !att_fwd2_eligible(p)) return 0;
   const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
   dim3 grid(att_grid_size(nt, (p.seq.B + 1) / 2, p.H)), block(ATT_THREADS);

@@ -3,15 +3,16 @@
     python vl-merging_amd/csrc/gen/attn_fwd2_gen.py            # rewrite the .inc
     python vl-merging_amd/csrc/gen/attn_fwd2_gen.py --check    # exit 1 if the committed .inc is stale
 
-The kernel's work decomposition, LDS layout and register map are documented in attention_fwd2.hip; this file only
-knows the map below.  One wave owns 32 query positions of TWO samples (the relative-position bias of a (query block,
-key block) pair is loaded once and added to both samples' scores) and the whole 512-entry register file of its SIMD.
+The kernel's work decomposition and LDS layout are documented in attention_fwd2.hip; this file owns the register map.
+One wave = 32 query positions of TWO samples (the relative-position bias of a (query block, key block) pair is loaded once
+and added to both samples' scores); 256 registers per wave, two workgroups (waves) per CU (SIMD).
 
-Per 64-key tile a wave runs four UNITS u = (key block kb, sample s), each
+Keys are streamed in 32-key BLOCKS through a ring of four 16-KiB stages [K s0 | K s1 | V s0 | V s1]; a TRIP is one 64-key
+tile = two blocks = four UNITS u = (kb, s):
   A(u): 7 MFMAs  S[s]  = bias(kb) (2 selection MFMAs, f16) + K(kb, s) (c1 Q_s)^T (4) + statistics step (-m_s, key mask)
-  B(u): 6 MFMAs  l_s  += 1^T P,  O_s^T += V(kb, s)^T P^T          (P = bf16(exp2(S[s])))
-software-pipelined as  A(u+1) || exp/cvt(u), K/V fragment reads   then   B(u) || max(u+1), rescale decision(u+1),
-so that the exponentials of one unit issue in the gaps of the other sample's score chain.
+  B(u): 4 MFMAs  O_s^T += V(kb, s)^T P^T                     (P = bf16(exp2(S[s])); the row sums are f32 adds)
+software-pipelined as  A(u+1) || exp / row sums / cvt(u), V reads(u)   then   B(u) || max(u+1), rescale decision(u+1).
+The loop body is two trips (ring positions 0,1 and 2,3), so every LDS address is a per-lane base + an immediate.
 """
 import os
 import sys
@@ -20,42 +21,42 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from asmgen import Op, mfma, rr, regs, interleave, place_waits, pad_hazards, emit  # noqa: E402
 
 NSTAGE = 4
-STAGE = 32768                 # per stage: K0 | K1 | V0 | V1, 8 KiB each
+STAGE = 16384                 # per stage: K s0 | K s1 | V s0 | V s1, 4 KiB each (32 keys x 128 B)
 KM_BASE = NSTAGE * STAGE      # key-mask words of tiles 0, 1: [tile][sample][64]; then 1 KiB of zeros
 
 # ---- register map (must match attention_fwd2.hip) -----------------------------------------------------------------------
-V_ADDR = 32      # v32..35 K fragment addresses (stage 0), v36..37 V^T addresses, v38 mask word (tile 0), v39 zero word,
-                 # v40..41 K DMA voffsets, v42..43 V DMA voffsets, v44..45 tile row of DMA piece u, v46 bias voffset,
-                 # v47 mask word (tile 1)
-V_CONST = 48     # v48..51 sel0, v52..55 sel1, v56..59 ones, v60 = 0xFFFFFFF0 (out-of-range offset), v61..63 spare
-V_Q = 64         # v[64 + 16 s + 4 ss : +3] = c1 Q_s fragment of k-step ss
-V_S = 96         # S[s] = v[96 + 16 s : +15]
-V_P = 128        # P[s] = v[128 + 8 s : +7]
-V_KF = 144       # K fragments, 4 x 4
-V_VF = 160       # V^T fragments, (s2, db) -> 160 + 4 (2 s2 + db)
-V_BW = 176       # bias operands w[kb][j] -> 176 + 8 kb + 4 j
-V_KONE = 192     # key side of the statistics step: dword 0 = (1, 1) in the lower half-wave, dword 1 = mask word
-V_QM = 196       # query side: v[196 + 4 s : +3]; dword 0 = (-m hi, -m lo), dword 1 = (1, 0)
-V_M = 204        # running reference point m_s
-V_T = 206        # temporaries v206..v209
-V_DOFF = 210     # current (range-masked) DMA voffsets: 210, 211 K u = 0, 1; 212, 213 V
-V_KC = 214       # current-stage K fragment addresses (4), 218..219 V^T addresses, 220 current mask word address
+V_ADDR = 32      # v32..35 K fragment addresses (stage 0, sample 0), v36..37 V^T addresses, v38 mask word (tile 0), v39 zero word,
+                 # v40 K DMA voffset, v41 V DMA voffset, v42 block row of this lane's DMA piece, v43 bias voffset,
+                 # v44 mask word (tile 1), v45 = 0xFFFFFFF0 (out-of-range offset), v46 current mask word address, v47 spare
+V_SEL = 48       # v48..51 sel0, v52..55 sel1
+V_Q = 56         # v[56 + 16 s + 4 ss : +3] = c1 Q_s fragment of k-step ss
+V_S = 88         # S[s] = v[88 + 16 s : +15]
+V_P = 120        # P = v[120:127]: one buffer (a unit's P is consumed before the next unit's conversions start)
+V_KF = 128       # K fragments, 4 x 4
+V_VF = 144       # V^T fragments, (s2, db) -> 144 + 4 (2 s2 + db)
+V_BW = 160       # bias operands of the CURRENT key block w[j] -> 160 + 4 j (re-requested for the next block once both samples'
+                 # selection MFMAs have read them)
+V_KONE = 168     # key side of the statistics step: dword 0 = (1, 1) in the lower half-wave, dword 1 = mask word
+V_QM = 172       # query side: v[172 + 4 s : +3]; dword 0 = (-m hi, -m lo), dword 1 = (1, 0)
+V_M = 180        # running reference point m_s
+V_L = 182        # row sums: v[182 + 2 s], v[183 + 2 s] (two partial sums per sample)
+V_T = 186        # temporaries v186..v189
+V_DOFF = 190     # current (range-masked) DMA voffsets: 190 K, 191 V
+V_KMC = 46       # current mask word address (one of v38 / v44 / v39)
 A_O = 0          # o[s][db] = a[32 s + 16 db : +15]
-A_L = 64         # l[s] = a[64 + 16 s : +15]
+# v0..v31 are the compiler's (values that live across the asm statement)
 
 S_RKV, S_RB = 40, 44
-S_SOFF = 48      # s48 K sample 0, s49 K sample 1, s50 V sample 0, s51 V sample 1 (byte offsets of the DMA tile's first row)
-S_NT = 52
-S_REM = 53       # valid rows from the DMA tile's first position on (may be <= 0)
-S_LDSW = 54      # LDS byte address of this wave's first piece in the DMA tile's stage
-S_STEP = 55      # 64 * ld * 2
-S_RD = 56        # LDS byte address of the stage being read
+S_SOFF = 48      # s48 K sample 0, s49 K sample 1, s50 V sample 0, s51 V sample 1 (byte offsets of the DMA block's first row)
+S_NT = 52        # number of trips (64-key tiles)
+S_REM = 53       # valid rows from the DMA block's first position on (may be <= 0)
+S_W1K = 54       # wave * 1024: this wave's piece inside a 4-KiB operand image
+S_STEP = 55      # 32 * ld * 2
 S_T = 57
-S_NL = 58        # s[58:59]: all ones while a next tile exists
-S_BOFF = 60      # bias scalar offset of the NEXT tile
+S_NL = 58        # s[58:59]: all ones while a next trip exists
+S_BOFF = 60      # bias scalar offset of the current trip's SECOND key block (trip * 4096 + 2048)
 S_TMP = 61
 S_LO = 62        # s[62:63] = lower half-wave
-S_LDS0 = 64      # LDS base (stage 0), s65 = end of the ring
 
 MF_BF = "v_mfma_f32_32x32x16_bf16"
 MF_F16 = "v_mfma_f32_32x32x16_f16"
@@ -63,20 +64,19 @@ MF_F16 = "v_mfma_f32_32x32x16_f16"
 
 def S(s): return rr("v", V_S + 16 * s, 16)
 def Sr(s, i): return "v%d" % (V_S + 16 * s + i)
-def P(s, half): return rr("v", V_P + 8 * s + 4 * half, 4)
-def Pr(s, d): return "v%d" % (V_P + 8 * s + d)
+def P(s, half): return rr("v", V_P + 4 * half, 4)
+def Pr(s, d): return "v%d" % (V_P + d)
 def KF(ss): return rr("v", V_KF + 4 * ss, 4)
 def VF(s2, db): return rr("v", V_VF + 4 * (2 * s2 + db), 4)
-def BW(kb, j): return rr("v", V_BW + 8 * kb + 4 * j, 4)
+def BW(kb, j): return rr("v", V_BW + 4 * j, 4)
 def QF(s, ss): return rr("v", V_Q + 16 * s + 4 * ss, 4)
 def QM(s): return rr("v", V_QM + 4 * s, 4)
 def O(s, db): return rr("a", A_O + 32 * s + 16 * db, 16)
-def L(s): return rr("a", A_L + 16 * s, 16)
+def Lr(s, i): return "v%d" % (V_L + 2 * s + i)
 
 
 KONE = rr("v", V_KONE, 4)
-SEL = [rr("v", V_CONST, 4), rr("v", V_CONST + 4, 4)]
-ONES = rr("v", V_CONST + 8, 4)
+SEL = [rr("v", V_SEL, 4), rr("v", V_SEL + 4, 4)]
 
 
 def valu(text, reads, writes, **kw):
@@ -87,15 +87,16 @@ def salu(text, writes=(), reads=()):
     return Op(text, "salu", reads, writes)
 
 
-# ---- pieces of a unit ---------------------------------------------------------------------------------------------------
-def chain(u, tile_tag):
+# ---- pieces of a unit; `st` = ring position (0..3) of the unit's key block ------------------------------------------------
+def chain(u):
     """A(u): the score chain of unit u = (kb, s) into S[s]."""
     kb, s = u >> 1, u & 1
     ms = [mfma(MF_F16, S(s), SEL[0], BW(kb, 0), "0"), mfma(MF_F16, S(s), SEL[1], BW(kb, 1), S(s))]
     ms[0].needs = ["bias%d" % kb]
     for ss in range(4):
         m = mfma(MF_BF, S(s), KF(ss), QF(s, ss), S(s))
-        m.needs = ["k%d_%d" % (u, ss)]
+        if ss == 0:
+            m.needs = ["k%d_3" % u]  # LDS results return in order: the last fragment's wait covers all four
         ms.append(m)
     m = mfma(MF_BF, S(s), KONE, QM(s), S(s))
     m.needs = ["kone%d" % u]
@@ -103,64 +104,61 @@ def chain(u, tile_tag):
     return ms
 
 
-def k_reads(u):
+def k_reads(u, st):
     kb, s = u >> 1, u & 1
     out = []
     for ss in range(4):
-        out.append(Op("ds_read_b128 %s, v%d offset:%d" % (KF(ss), V_KC + ss, s * 8192 + kb * 4096), "lds",
-                      ["v%d" % (V_KC + ss)], regs("v", V_KF + 4 * ss, 4), tag="k%d_%d" % (u, ss)))
-    out.append(Op("ds_read_b32 v%d, v%d offset:%d" % (V_KONE + 1, V_KC + 6, s * 256 + kb * 128), "lds",
-                  ["v%d" % (V_KC + 6)], ["v%d" % (V_KONE + 1)], cost=4, tag="kone%d" % u))
+        out.append(Op("ds_read_b128 %s, v%d offset:%d" % (KF(ss), V_ADDR + ss, st * STAGE + s * 4096), "lds",
+                      ["v%d" % (V_ADDR + ss)], regs("v", V_KF + 4 * ss, 4), tag="k%d_%d" % (u, ss)))
+    out.append(Op("ds_read_b32 v%d, v%d offset:%d" % (V_KONE + 1, V_KMC, s * 256 + kb * 128), "lds",
+                  ["v%d" % V_KMC], ["v%d" % (V_KONE + 1)], cost=4, tag="kone%d" % u))
     return out
 
 
-def v_reads(u, after=0):
+def v_reads(u, st, after=0):
     kb, s = u >> 1, u & 1
     out = []
     for s2 in range(2):
         for db in range(2):
             base = V_VF + 4 * (2 * s2 + db)
-            off = 16384 + s * 8192 + kb * 4096 + s2 * 2048
-            out.append(Op("ds_read_b64_tr_b16 %s, v%d offset:%d" % (rr("v", base, 2), V_KC + 4 + db, off), "lds",
-                          ["v%d" % (V_KC + 4 + db)], regs("v", base, 2), cost=6, tag="v%d_%d%da" % (u, s2, db), after=after))
-            out.append(Op("ds_read_b64_tr_b16 %s, v%d offset:%d" % (rr("v", base + 2, 2), V_KC + 4 + db, off + 1024), "lds",
-                          ["v%d" % (V_KC + 4 + db)], regs("v", base + 2, 2), cost=6, tag="v%d_%d%db" % (u, s2, db), after=after))
+            off = st * STAGE + 8192 + s * 4096 + s2 * 2048
+            out.append(Op("ds_read_b64_tr_b16 %s, v%d offset:%d" % (rr("v", base, 2), V_ADDR + 4 + db, off), "lds",
+                          ["v%d" % (V_ADDR + 4 + db)], regs("v", base, 2), cost=6, tag="v%d_%d%da" % (u, s2, db), after=after))
+            out.append(Op("ds_read_b64_tr_b16 %s, v%d offset:%d" % (rr("v", base + 2, 2), V_ADDR + 4 + db, off + 1024), "lds",
+                          ["v%d" % (V_ADDR + 4 + db)], regs("v", base + 2, 2), cost=6, tag="v%d_%d%db" % (u, s2, db), after=after))
     return out
 
 
 def exp_cvt(u):
-    """P[s] = bf16(exp2(S[s])): 16 v_exp_f32 in place, 8 v_cvt_pk_bf16_f32 (each at least two instructions behind its inputs)."""
+    """P[s] = bf16(exp2(S[s])), l_s += sum: 16 v_exp_f32 in place, 16 v_add_f32 into two partial sums, 8 v_cvt_pk_bf16_f32;
+    every consumer sits at least two instructions behind the transcendental that feeds it."""
     s = u & 1
     out = []
-    order = list(range(16))
-    pending = []
-    for n, i in enumerate(order):
-        out.append(Op("v_exp_f32_e32 %s, %s" % (Sr(s, i), Sr(s, i)), "trans", [Sr(s, i)], [Sr(s, i)]))
-        if i & 1:
-            pending.append(i >> 1)
-        if len(pending) >= 2 or (n == 15):
-            # convert the OLDER finished pair(s): its exponentials are >= 2 instructions back
-            while pending and (len(pending) >= 2 or n == 15):
-                d = pending.pop(0)
-                out.append(valu("v_cvt_pk_bf16_f32 %s, %s, %s" % (Pr(s, d), Sr(s, 2 * d), Sr(s, 2 * d + 1)),
-                                [Sr(s, 2 * d), Sr(s, 2 * d + 1)], [Pr(s, d)]))
+
+    def ex(i): return Op("v_exp_f32_e32 %s, %s" % (Sr(s, i), Sr(s, i)), "trans", [Sr(s, i)], [Sr(s, i)])
+    def ad(i): return valu("v_add_f32_e32 %s, %s, %s" % (Lr(s, i & 1), Lr(s, i & 1), Sr(s, i)), [Lr(s, i & 1), Sr(s, i)], [Lr(s, i & 1)])
+    def cv(d): return valu("v_cvt_pk_bf16_f32 %s, %s, %s" % (Pr(s, d), Sr(s, 2 * d), Sr(s, 2 * d + 1)), [Sr(s, 2 * d), Sr(s, 2 * d + 1)], [Pr(s, d)])
+    out += [ex(0), ex(1)]
+    for i in range(2, 16, 2):
+        out += [ex(i), ad(i - 2), ex(i + 1), ad(i - 1), cv((i - 2) >> 1)]
+    out += [ad(14), ad(15), cv(7)]
     return out
 
 
 def pv(u):
-    """B(u): row sums and O^T += V^T P^T."""
+    """B(u): O^T += V^T P^T."""
     kb, s = u >> 1, u & 1
     ms = []
     for s2 in range(2):
-        ms.append(mfma(MF_BF, L(s), ONES, P(s, s2), L(s)))
         for db in range(2):
             m = mfma(MF_BF, O(s, db), VF(s2, db), P(s, s2), O(s, db))
-            m.needs = ["v%d_%d%da" % (u, s2, db), "v%d_%d%db" % (u, s2, db)]
+            if db == 0:
+                m.needs = ["v%d_%d1b" % (u, s2)]  # in-order returns: the last read of this k-step covers its four
             ms.append(m)
     return ms
 
 
-def max_decide(u, site, guard_last=False, after=2):
+def max_decide(u, site, guard_last=False, after=1):
     """Row maximum of S[s] (both half-waves), then the rare branch that moves the reference point."""
     s = u & 1
     a, b, t = "v%d" % V_T, "v%d" % (V_T + 1), "v%d" % (V_T + 2)
@@ -177,6 +175,7 @@ def max_decide(u, site, guard_last=False, after=2):
     out.append(m3(a, a, Sr(s, 14), Sr(s, 15)))
     out.append(valu("v_max_f32_e32 %s, %s, %s" % (a, a, b), [a, b], [a], after=after))
     out.append(valu("v_mov_b32_e32 %s, %s" % (t, a), [a], [t], after=after))
+    out.append(valu("v_mov_b32_e32 %s, %s" % (b, a), [a], [b], after=after))  # (a wait state between the write and the swap)
     out.append(Op("v_permlane32_swap_b32_e32 %s, %s" % (t, a), "perm", [t, a], [t, a], after=after))
     out.append(valu("v_max_f32_e32 %s, %s, %s" % (a, a, t), [a, t], [a], after=after))
     out.append(valu("v_cmp_lt_f32_e32 vcc, 0x40c00000, %s" % a, [a], ["vcc"], after=after))
@@ -210,8 +209,9 @@ def rare_block(site, s):
     t.append("v_cndmask_b32_e64 v%d, v%d, %s, s[%d:%d]" % (V_QM + 4 * s, V_QM + 4 * s, mx, S_LO, S_LO + 1))
     for i in range(16):
         t.append("v_sub_f32_e32 %s, %s, %s" % (Sr(s, i), Sr(s, i), dl))
-    accs = list(range(A_L + 16 * s, A_L + 16 * s + 16)) + list(range(A_O + 32 * s, A_O + 32 * s + 32))
-    for a in accs:
+    for i in range(2):
+        t.append("v_mul_f32_e32 %s, %s, %s" % (Lr(s, i), Lr(s, i), al))
+    for a in range(A_O + 32 * s, A_O + 32 * s + 32):
         t.append("v_accvgpr_read_b32 %s, a%d" % (mx, a))
         t.append("s_nop 0")
         t.append("v_mul_f32_e32 %s, %s, %s" % (mx, mx, al))
@@ -220,72 +220,116 @@ def rare_block(site, s):
     return t
 
 
-def dma_piece(j):
-    """Piece j of this wave's eight per tile: (sample, K or V, u)."""
-    order = [(0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1)]
-    s, kv, u = order[j]
-    imm = kv * 16384 + s * 8192 + u * 1024
-    return [salu("s_add_u32 m0, s%d, 0x%x" % (S_LDSW, imm), ["m0"], ["s%d" % S_LDSW]),
-            Op("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_DOFF + 2 * kv + u, S_RKV, S_RKV + 3, S_SOFF + 2 * kv + s),
-               "dma", ["v%d" % (V_DOFF + 2 * kv + u), "m0"], [], tag="dma%d" % j)]
+PIECES = [(0, 0), (0, 1), (1, 0), (1, 1)]  # (sample, K or V): this wave's four pieces of a block
+
+
+def dma_piece(j, st, name):
+    s, kv = PIECES[j]
+    imm = st * STAGE + kv * 8192 + s * 4096
+    return [salu("s_add_u32 m0, s%d, 0x%x" % (S_W1K, imm), ["m0"], ["s%d" % S_W1K]),
+            Op("buffer_load_dwordx4 v%d, s[%d:%d], s%d offen lds" % (V_DOFF + kv, S_RKV, S_RKV + 3, S_SOFF + 2 * kv + s),
+               "dma", ["v%d" % (V_DOFF + kv), "m0"], [], tag="dma%s%d" % (name, j))]
 
 
 def dma_offsets():
-    """Range-masked voffsets of the DMA tile: rows >= the tile's valid row count point out of range (zero fill)."""
+    """Range-masked voffsets of the DMA block: rows >= the block's valid row count point out of range (zero fill)."""
     t = "s%d" % S_TMP
-    out = [salu("s_min_i32 %s, s%d, 64" % (t, S_REM), [t]), salu("s_max_i32 %s, %s, 0" % (t, t), [t])]
-    for u in range(2):
-        out.append(valu("v_cmp_gt_u32_e32 vcc, %s, v%d" % (t, V_ADDR + 12 + u), [t], ["vcc"]))
-        out.append(valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF + u, V_CONST + 12, V_ADDR + 8 + u), ["vcc"], ["v%d" % (V_DOFF + u)]))
-        out.append(valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF + 2 + u, V_CONST + 12, V_ADDR + 10 + u), ["vcc"], ["v%d" % (V_DOFF + 2 + u)]))
-    return out
+    return [salu("s_min_i32 %s, s%d, 32" % (t, S_REM), [t]), salu("s_max_i32 %s, %s, 0" % (t, t), [t]),
+            valu("v_cmp_gt_u32_e32 vcc, %s, v%d" % (t, V_ADDR + 10), [t], ["vcc"]),
+            valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF, V_ADDR + 13, V_ADDR + 8), ["vcc"], ["v%d" % V_DOFF]),
+            valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF + 1, V_ADDR + 13, V_ADDR + 9), ["vcc"], ["v%d" % (V_DOFF + 1)])]
 
 
 def dma_advance():
-    """The DMA tile moves on by one: scalar row offsets, remaining rows, ring slot."""
+    """The DMA block moves on by one (32 rows)."""
     out = []
     for i in range(4):
         out.append(salu("s_add_u32 s%d, s%d, s%d" % (S_SOFF + i, S_SOFF + i, S_STEP), ["s%d" % (S_SOFF + i)]))
-    out.append(salu("s_sub_i32 s%d, s%d, 64" % (S_REM, S_REM), ["s%d" % S_REM]))
-    out.append(salu("s_add_u32 s%d, s%d, 0x%x" % (S_LDSW, S_LDSW, STAGE), ["s%d" % S_LDSW]))
-    out.append(salu("s_cmp_ge_u32 s%d, s%d" % (S_LDSW, S_LDS0 + 1), ["scc"]))
-    out.append(salu("s_cselect_b32 s%d, 0x%x, 0" % (S_TMP, NSTAGE * STAGE), ["s%d" % S_TMP], ["scc"]))
-    out.append(salu("s_sub_u32 s%d, s%d, s%d" % (S_LDSW, S_LDSW, S_TMP), ["s%d" % S_LDSW]))
+    out.append(salu("s_sub_i32 s%d, s%d, 32" % (S_REM, S_REM), ["s%d" % S_REM]))
     return out + dma_offsets()
 
 
-def read_addresses(k_only=None):
-    """Current-stage fragment addresses from the stage-0 addresses + the read stage's byte offset (s56 is RELATIVE to stage 0)."""
-    out = []
-    if k_only in (None, True):
-        for ss in range(4):
-            out.append(valu("v_add_u32_e32 v%d, s%d, v%d" % (V_KC + ss, S_RD, V_ADDR + ss), ["s%d" % S_RD], ["v%d" % (V_KC + ss)]))
-    if k_only in (None, False):
-        for db in range(2):
-            out.append(valu("v_add_u32_e32 v%d, s%d, v%d" % (V_KC + 4 + db, S_RD, V_ADDR + 4 + db), ["s%d" % S_RD], ["v%d" % (V_KC + 4 + db)]))
-    return out
-
-
 def bias_reload(kb, after):
+    """Request key block kb's operands (kb = 1: this trip's second block, kb = 0: the next trip's first)."""
     out = []
     for j in range(2):
-        out.append(Op("buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen offset:%d" % (BW(kb, j), V_ADDR + 14, S_RB, S_RB + 3, S_BOFF, (2 * kb + j) * 1024),
-                      "vmem", ["v%d" % (V_ADDR + 14)], regs("v", V_BW + 8 * kb + 4 * j, 4), tag="bias%d" % kb, after=after))
+        out.append(Op("buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen offset:%d" % (BW(kb, j), V_ADDR + 11, S_RB, S_RB + 3, S_BOFF, (2 * (1 - kb) + j) * 1024),
+                      "vmem", ["v%d" % (V_ADDR + 11)], regs("v", V_BW + 4 * j, 4), tag="bias%d" % kb, after=after))
     return out
+
+
+def spread(fill, extra, at):
+    """Insert the ops of `extra` into `fill` starting at index `at`, two positions apart."""
+    for n, e in enumerate(extra):
+        fill.insert(min(at + 2 * n, len(fill)), e)
+    return fill
+
+
+def trip(x, half):
+    """One 64-key trip whose blocks sit at ring positions x, x + 1; the next trip's first block at (x + 2) % 4.
+    DMA: phases 1-2 finish the block for ring position x + 2, phases 3-6 load x + 3, phases 7-8 start x + 4 = x."""
+    st = [x, x, x + 1, x + 1]          # ring position of unit u's block
+    nx = (x + 2) % NSTAGE
+    body = []
+    body += [salu("s_add_u32 s%d, s%d, 1" % (S_TMP, S_T), ["s%d" % S_TMP]),
+             salu("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), ["scc"]),
+             salu("s_cselect_b64 s[%d:%d], -1, 0" % (S_NL, S_NL + 1), ["s%d" % S_NL, "s%d" % (S_NL + 1)], ["scc"])]
+    tag = "ab"[half]
+    for u in (1, 2, 3):
+        fill = v_reads(u - 1, st[u - 1], after=1) + exp_cvt(u - 1)
+        if u & 1:
+            fill += bias_reload(1 - (u >> 1), after=2)
+        if u == 1:
+            d = dma_piece(2, nx, tag + "A")
+        else:
+            d = dma_piece(2 * (u - 2), (x + 3) % NSTAGE, tag + "B")
+        d[0].after = d[1].after = 1
+        spread(fill, d, 9)
+        lead = k_reads(u, st[u])
+        if u == 2:
+            # block x + 1 has landed for every wave (its pieces were issued in the previous trip's phases 3-6)
+            lead = [Op("s_nop 0", "salu", needs=["dma%sB3" % "ba"[half]]), Op("s_barrier", "salu")] + lead
+        body += interleave(chain(u), fill, lead=lead)
+        if u == 1:
+            d = dma_piece(3, nx, tag + "A")
+            adv = dma_advance()
+        elif u == 2:
+            d = dma_piece(1, (x + 3) % NSTAGE, tag + "B")
+            adv = []
+        else:
+            d = dma_piece(3, (x + 3) % NSTAGE, tag + "B")
+            adv = dma_advance()
+        for o in adv:
+            o.after = 3
+        body += interleave(pv(u - 1), d + max_decide(u, "%s%d" % (tag, u), after=1) + adv)
+    # trip boundary: the next trip's first block has landed (pieces 0, 1 in the previous trip's phases 7-8, pieces 2, 3 above)
+    body.append(Op("s_nop 0", "salu", needs=["dma%sA3" % tag]))
+    body.append(Op("s_barrier", "salu"))
+    body += [salu("s_cmp_eq_u32 s%d, 0" % S_T, ["scc"]),
+             salu("s_cselect_b64 vcc, -1, 0", ["vcc"], ["scc"]),
+             valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_KMC, V_ADDR + 7, V_ADDR + 12), ["vcc"], ["v%d" % V_KMC])]
+    # phase 7: A(0) of the next trip || exp/cvt(3), V reads of unit 3
+    fill = v_reads(3, st[3], after=1) + exp_cvt(3)
+    d = dma_piece(0, x, tag + "C")
+    d[0].after = d[1].after = 1
+    spread(fill, d, 9)
+    body += interleave(chain(0), fill, lead=k_reads(0, nx))
+    d = dma_piece(1, x, tag + "C")
+    body += interleave(pv(3), d + [salu("s_add_u32 s%d, s%d, 0x1000" % (S_BOFF, S_BOFF), ["s%d" % S_BOFF], ["s%d" % S_BOFF]),
+                                   salu("s_add_u32 s%d, s%d, 1" % (S_T, S_T), ["s%d" % S_T])] + max_decide(0, tag + "0", guard_last=True, after=1))
+    return body
 
 
 def build():
     # ---------------------------------------------------------------- once, before the loop
     pre = []
-    for a in range(96):
+    for a in range(64):
         pre.append(valu("v_accvgpr_write_b32 a%d, 0" % a, [], ["a%d" % a]))
     pre += [salu("s_mov_b32 s%d, -1" % S_LO, ["s%d" % S_LO]), salu("s_mov_b32 s%d, 0" % (S_LO + 1), ["s%d" % (S_LO + 1)]),
-            salu("s_mov_b32 s%d, 0" % S_T, ["s%d" % S_T]), salu("s_mov_b32 s%d, 0" % S_RD, ["s%d" % S_RD]),
-            salu("s_mov_b32 s%d, 0x1000" % S_BOFF, ["s%d" % S_BOFF]),
-            salu("s_add_u32 s%d, s%d, 0x%x" % (S_LDS0 + 1, S_LDS0, NSTAGE * STAGE), ["s%d" % (S_LDS0 + 1)])]
+            salu("s_mov_b32 s%d, 0" % S_T, ["s%d" % S_T]), salu("s_mov_b32 s%d, 0x800" % S_BOFF, ["s%d" % S_BOFF])]
     # statistics-step operands: key side (1, 1) in k-slots 0, 1 of the lower half-wave (dword 1 = the mask word, read per unit);
-    # query side k-slots 0, 1 = -m = 0, k-slot 2 = 1 (times the key's mask word); m = 0
-    for v in range(V_KONE, V_M + 2):
+    # query side k-slots 0, 1 = -m = 0, k-slot 2 = 1 (times the key's mask word); m = 0; row sums = 0
+    for v in range(V_KONE, V_L + 4):
         pre.append(valu("v_mov_b32_e32 v%d, 0" % v, [], ["v%d" % v]))
     t0 = "v%d" % V_T
     pre.append(valu("v_mov_b32_e32 %s, 0x3f803f80" % t0, [], [t0]))
@@ -294,60 +338,23 @@ def build():
     for s in range(2):
         pre.append(valu("v_cndmask_b32_e64 v%d, 0, %s, s[%d:%d]" % (V_QM + 4 * s + 1, t0, S_LO, S_LO + 1), [t0], ["v%d" % (V_QM + 4 * s + 1)]))
     pre += dma_offsets()
-    pre += read_addresses()
-    pre.append(valu("v_mov_b32_e32 v%d, v%d" % (V_KC + 6, V_ADDR + 6), [], ["v%d" % (V_KC + 6)]))
-    # A(0) of tile 0 alone, then its maximum / decision
-    pre += k_reads(0)
-    pre += chain(0, 0)
+    pre.append(valu("v_mov_b32_e32 v%d, v%d" % (V_KMC, V_ADDR + 6), [], ["v%d" % V_KMC]))
+    # A(0) of trip 0 alone, then its maximum / decision
+    pre += k_reads(0, 0)
+    pre += chain(0)
     pre += max_decide(0, "pre", after=0)
 
-    # ---------------------------------------------------------------- one trip = one 64-key tile
+    # ---------------------------------------------------------------- the loop: two trips per pass
     body = [Op("L_loop_%=:", "raw")]
-    # "a next tile exists" mask for the decision taken at the end of this trip
-    body += [salu("s_add_u32 s%d, s%d, 1" % (S_TMP, S_T), ["s%d" % S_TMP]),
-             salu("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), ["scc"]),
-             salu("s_cselect_b64 s[%d:%d], -1, 0" % (S_NL, S_NL + 1), ["s%d" % S_NL, "s%d" % (S_NL + 1)], ["scc"])]
-    # phases 1..6: A(u) || exp/cvt(u-1) + reads, B(u-1) || max(u)
-    for u in (1, 2, 3):
-        fill = v_reads(u - 1, after=1) + exp_cvt(u - 1)
-        if u & 1:
-            fill += bias_reload(u >> 1, after=2)
-        d = dma_piece(2 * (u - 1) + 2)
-        d[0].after = d[1].after = 1
-        fill.insert(8, d[0]); fill.insert(9, d[1])
-        body += interleave(chain(u, None), fill, lead=k_reads(u))
-        d = dma_piece(2 * (u - 1) + 3)
-        body += interleave(pv(u - 1), d + max_decide(u, "u%d" % u, after=2))
-    # tile boundary: the next tile's pieces (all but the two youngest DMA groups) have landed; publish; move on
-    wait = Op("s_nop 0", "salu", needs=["^dma7"])
-    body.append(wait)
-    body.append(Op("s_barrier", "salu"))
-    body += [salu("s_add_u32 s%d, s%d, 0x%x" % (S_RD, S_RD, STAGE), ["s%d" % S_RD]),
-             salu("s_cmp_ge_u32 s%d, 0x%x" % (S_RD, NSTAGE * STAGE), ["scc"]),
-             salu("s_cselect_b32 s%d, 0, s%d" % (S_RD, S_RD), ["s%d" % S_RD], ["scc"]),
-             salu("s_cmp_eq_u32 s%d, 0" % S_T, ["scc"]),
-             salu("s_cselect_b64 vcc, -1, 0", ["vcc"], ["scc"])]
-    body += read_addresses(k_only=True)
-    # mask words: tile 1 -> v47, tiles >= 2 -> the zero region
-    body.append(valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_KC + 6, V_ADDR + 7, V_ADDR + 15), ["vcc"], ["v%d" % (V_KC + 6)]))
-    body += dma_advance()
-    # phase 7: A(0) of the next tile || exp/cvt(3) + reads of V(3) (still the old stage addresses)
-    fill = v_reads(3, after=1) + exp_cvt(3)
-    d = dma_piece(0)
-    d[0].after = d[1].after = 1
-    fill.insert(8, d[0]); fill.insert(9, d[1])
-    body += interleave(chain(0, None), fill, lead=k_reads(0))
-    body += read_addresses(k_only=False)
-    d = dma_piece(1)
-    body += interleave(pv(3), d + [salu("s_add_u32 s%d, s%d, 0x1000" % (S_BOFF, S_BOFF), ["s%d" % S_BOFF]),
-                                   salu("s_add_u32 s%d, s%d, 1" % (S_T, S_T), ["s%d" % S_T])] + max_decide(0, "u0", guard_last=True, after=2))
+    body += trip(0, 0)
+    body += [salu("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NT), ["scc"]), Op("s_cbranch_scc0 L_exit_%=", "salu")]
+    body += trip(2, 1)
     body += [salu("s_cmp_lt_u32 s%d, s%d" % (S_T, S_NT), ["scc"]), Op("s_cbranch_scc1 L_loop_%=", "salu")]
 
     pre_w, body_w = place_waits(pre, body)
     pre_h = pad_hazards(pre_w)
     body_h1 = pad_hazards(body_w, history=pre_h)
-    body_h = pad_hazards(body_w, history=body_h1)  # steady state; must not need more than the first trip
-    # the first trip follows `pre`, later ones the loop's own tail: use the union (pad where either needs it)
+    body_h = pad_hazards(body_w, history=body_h1)
     if [o.text for o in body_h] != [o.text for o in body_h1]:
         merged = []
         i = j = 0
@@ -363,8 +370,11 @@ def build():
             else:
                 raise AssertionError("streams diverge: %r / %r" % (a and a.text, b and b.text))
         body_h = merged
-    tail = ["s_branch L_done_%="]
-    for site, s in (("pre", 0), ("u1", 1), ("u2", 0), ("u3", 1), ("u0", 0)):
+    tail = ["L_exit_%=:", "s_branch L_done_%="]
+    sites = [("pre", 0)]
+    for tag in "ab":
+        sites += [(tag + "1", 1), (tag + "2", 0), (tag + "3", 1), (tag + "0", 0)]
+    for site, s in sites:
         tail += rare_block(site, s)
     tail += ["L_done_%=:", "s_nop 15", "s_nop 15"]
     text = emit(pre_h) + emit(body_h) + "".join(("" if l.endswith(":") else "  ") + l + "\n" for l in tail)
@@ -399,5 +409,5 @@ if __name__ == "__main__":
     open(out_path, "w").write(txt)
     k, c = stats(body)
     nm = k.get("mfma", 0)
-    print("loop body: %d instructions, %s; issue-cost estimate %d cycles per tile (%d MFMAs = %d matrix cycles)"
+    print("loop body (two 64-key trips): %d instructions, %s; issue-cost estimate %d cycles (%d MFMAs = %d matrix cycles)"
           % (len(body), k, c, nm, 32 * nm))
