@@ -105,26 +105,105 @@ GEMM_KERNELS = ("vlm_gemm_big_kernel", "vlm_gemm_bigT_kernel", "vlm_gemm_kernel"
 GEMM_HELPERS = ("splitk_reduce_kernel",)  # second launch of a wgrad call: its bytes count, its launches do not
 
 
-def pmc_traffic(kernels, helpers=()):
+ATTN_KERNELS = {"fwd": ("attn_fwd2_kernel",), "bwd": ("attn_bwd_dq_kernel", "attn_bwd_dkvb_kernel", "attn_dbias_fold_kernel")}
+# what a default pretrain step launches from the attention / GEMM families: a committed PMC file that lacks one of them was
+# made from another build of the kernels and must not vouch for this run
+EXPECTED_IN_PROFILE = GEMM_KERNELS + GEMM_HELPERS + ATTN_KERNELS["fwd"] + ATTN_KERNELS["bwd"]
+
+
+def _git_blob_sha1(data):
+    import hashlib
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_traffic(kernels, helpers=(), with_meta=False):
     """HBM-side bytes per launch of a kernel (or, launch-weighted, of a family of kernels that serve the same call) from the
-    committed rocprofv3 --pmc passes over this same bench command (the newest profiles/r*_pmc_traffic.json, made by
+    committed rocprofv3 --pmc passes over this same bench command (the NEWEST profiles/r*_pmc_traffic.json, made by
     tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE doubled on gfx950).
-    Counters cannot be read from inside the timed process; None if the file is absent."""
+    Counters cannot be read from inside the timed process, so the figure is only as good as the file: the meta record names the
+    file and its git blob hash, and a file whose kernel list lacks a kernel this build launches (EXPECTED_IN_PROFILE) is
+    REFUSED (value None, the reason in meta["stale"], a line on stderr) -- tests/test_bench_gpu.py fails on that."""
     if isinstance(kernels, str):
         kernels = (kernels,)
+    import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the newest committed PMC passes
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True)
+    value, meta = None, {"file": None}
+    if files:
+        path = files[0]
         try:
-            with open(os.path.join(here, "profiles", name)) as f:
-                ks = json.load(f)["kernels"]
-        except (OSError, KeyError, ValueError):
-            continue
-        found = [ks[k] for k in kernels if k in ks]
-        if not found:
-            continue
-        total = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in found + [ks[h] for h in helpers if h in ks])
-        return total / sum(k["launches"] for k in found)
-    return None
+            with open(path, "rb") as f:
+                raw = f.read()
+            doc = json.loads(raw.decode())
+            ks = doc["kernels"]
+            meta = {"file": "profiles/" + os.path.basename(path), "git_blob": _git_blob_sha1(raw), "kernels_in_file": len(ks)}
+            if "total_bytes_per_step" in doc:
+                meta["total_bytes_per_step"] = doc["total_bytes_per_step"]
+            missing = [k for k in EXPECTED_IN_PROFILE if k not in ks]
+            if missing:
+                meta["stale"] = "the file has no record of %s: it was not made from this build" % ", ".join(missing)
+                sys.stderr.write("[bench] roofline.traffic REFUSED: %s (%s)\n" % (meta["stale"], meta["file"]))
+            else:
+                found = [ks[k] for k in kernels if k in ks]
+                if found:
+                    total = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in found + [ks[h] for h in helpers if h in ks])
+                    value = total / sum(k["launches"] for k in found)
+        except (OSError, KeyError, ValueError) as e:
+            meta = {"file": "profiles/" + os.path.basename(path), "stale": "unreadable: %r" % (e,)}
+    return (value, meta) if with_meta else value
+
+
+class AttnTimer:
+    """HIP-event timing of every fused-attention call (forward: one launch; backward: dQ + fused dK/dV/bias-gradient + fold)
+    on the launching stream, in the same bracketed steps as GemmTimer.  flop = the ALGORITHMIC count: 4 n_q n_k 64 per
+    (sample, head) forward (Q K^T and P V), twice that backward -- the convention of profiles/r0*_pmc_mfma_busy.json."""
+
+    def __init__(self, ops, gemm_timer):
+        self.ops, self.gt = ops, gemm_timer
+        self.rec = {"fwd": [], "bwd": []}
+        self.L = importlib.import_module("vl_merging_amd._lib")
+
+    def _flop(self, seq, H, mode):
+        n0, n1 = seq.n0, seq.n1
+        pairs = (n0 * n0 + n1 * n1) if mode == self.L.ATTN_SEPARATE else (n0 + n1) ** 2
+        return 4.0 * 64 * H * seq.B * pairs
+
+    def install(self):
+        of, ob = self.ops.attention_fwd, self.ops.attention_bwd
+
+        def bracket(kind, fn, flop):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            self.rec[kind].append((e0, e1, flop))
+            return r
+
+        def fwd(qkv, out, lse, seq, H, **kw):
+            if not self.gt.on:
+                return of(qkv, out, lse, seq, H, **kw)
+            return bracket("fwd", lambda: of(qkv, out, lse, seq, H, **kw), self._flop(seq, H, kw.get("mode", self.L.ATTN_JOINT)))
+
+        def bwd(qkv, out, dout, lse, dqkv, seq, H, **kw):
+            if not self.gt.on:
+                return ob(qkv, out, dout, lse, dqkv, seq, H, **kw)
+            return bracket("bwd", lambda: ob(qkv, out, dout, lse, dqkv, seq, H, **kw),
+                           2.0 * self._flop(seq, H, kw.get("mode", self.L.ATTN_JOINT)))
+
+        self.ops.attention_fwd, self.ops.attention_bwd = fwd, bwd
+
+    def summary(self):
+        out = {}
+        for kind, recs in self.rec.items():
+            if not recs:
+                continue
+            torch.cuda.synchronize()
+            t = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e-3
+            fl = sum(f for _, _, f in recs)
+            out[kind] = {"kernel": " + ".join(ATTN_KERNELS[kind]), "bound": "mfma", "achieved": fl / t / 1e12,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
+                         "launches": len(recs), "avg_call_us": t / len(recs) * 1e6, "flop_convention": "algorithmic: 4 n_q n_k 64 per (sample, head) forward, 2 x backward"}
+        return out or None
 
 
 def calibrate(dev):
@@ -368,7 +447,7 @@ class TrainLeg:
         self.reducer.attach(self.opt, defer_tail=os.environ.get("VLM_DEFER_TAIL_ALLREDUCE", "1") != "0")
         b = synthetic_batch(B, image_size, cfg["max_text_len"], cfg["vocab_size"], 1234 + rank, dev)
         self.batch = b if cfg["tasks"] is not None else b["vl"]  # vilt_module.py:1485: {"vl": batch} only with `tasks`
-        self.B, self.world, self.dist = B, world, (world > 1 or force_dist)
+        self.B, self.world, self.dist, self.rank = B, world, (world > 1 or force_dist), rank
         # Part of BUILDING the leg, before any warm-up or timed step: SETUP_STEPS full steps so that the caching allocator's pools,
         # the lazily loaded code objects and the gradient reducer's use counts exist (the first process on a fresh box showed one
         # 150-ms step among 65-ms ones as late as its fifth step: gpurun_out/r05/call_j.txt).  Disclosed in the JSON line as
@@ -410,8 +489,12 @@ class TrainLeg:
         for it in range(steps):
             if per_step is not None:
                 per_step(it)
+            # per-bucket issue / complete times of the LAST timed step only (the communication stream then waits for each of its
+            # collectives in turn: harmless, but kept out of the other steps)
+            self.reducer.timeline_on = self.rank == 0 and it == steps - 1
             loss = self.step()
             marks[it + 1].record()
+        self.reducer.timeline_on = False
         self.fence()
         dt = time.perf_counter() - t0
         if gc_was:
@@ -425,6 +508,7 @@ class TrainLeg:
 
     def close(self):
         self.reducer.begin_step()  # drains a deferred tail nobody waited for
+        self.reducer.close()       # the process-global CU budget goes back to what it was
         torch.cuda.synchronize()
         del self.model, self.opt, self.sch, self.reducer, self.batch
         torch.cuda.empty_cache()
@@ -762,6 +846,8 @@ def main():
     reducer = leg.reducer
     timer = GemmTimer(ops)
     timer.install()
+    atimer = AttnTimer(ops, timer)
+    atimer.install()
     use_timer = rank == 0 and not args.no_gemm_timer
     # The steps whose GEMM launches are bracketed run with the weight-gradient side stream OFF: a launch that shares the chip
     # with another stream's kernel takes longer for reasons that are not its own, and the roofline figure is the kernel's own
@@ -805,6 +891,12 @@ def main():
                           "sharded_optimizer": reducer.sharded, "bytes_per_step": int(reducer.flat.numel) * (2 if reducer.comm_dtype is not None else 4),
                           "buckets": reducer.bucket_plan(),
                           "cu_budget": L_.get_lib().vlm_device_cus(),  # VLM_GEMM_CUS: CUs the GEMM grids plan for (RCCL takes the rest)
+                          "cu_budget_set_by_reducer": reducer.cu_budget_set,
+                          # self-diagnosis of the first multi-GPU run: which library moves the gradients, between how many
+                          # ranks, and when each bucket of the last timed step was issued / complete (ms from the step's start)
+                          "backend": (dist.get_backend() if dist.is_initialized() else None),
+                          "rccl_ranks": (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0),
+                          "bucket_timeline_last_step": reducer.bucket_timeline(),
                           "wgrad_side_stream": bool(side_default), "standin": reducer.standin},
         }
         if args.image_size == 384:
@@ -814,8 +906,9 @@ def main():
         out["model_tflops"] = value * flop_per_sample / 1e12 / world
         if gs:
             n_timed = len(range(0, args.steps, max(1, args.gemm_timer_every)))
+            traffic, traffic_meta = pmc_traffic(GEMM_KERNELS, GEMM_HELPERS, with_meta=True)
             out["roofline"] = {"bound": "mfma", "achieved": gs["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(GEMM_KERNELS, GEMM_HELPERS),
+                               "frac": gs["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_meta,
                                "traffic_unit": "HBM-side bytes per vlm_gemm_bf16 call, launch-weighted over the kernels "
                                                "that serve it (rocprofv3 PMC, the newest profiles/r*_pmc_traffic.json)",
                                "kernel": "vlm_gemm_bf16 (+ _grouped / vlm_gemm_wgrad_grouped for all_moe): " + " / ".join(GEMM_KERNELS),
@@ -824,6 +917,10 @@ def main():
                                        "with the weight-gradient side stream off (every launch alone on the chip)",
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"], "timed_steps": n_timed,
                                "gemm_share_of_step": gs["seconds"] / (dt / args.steps * n_timed)}
+            ats = atimer.summary()
+            if ats:
+                # the kernels north_star puts a number on, timed in this run (not only in profiles/): same bracketed steps
+                out["roofline_attention"] = ats
         if not args.no_calibrate:
             out["attainable"] = calibrate(dev)
     leg.close()

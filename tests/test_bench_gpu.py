@@ -27,6 +27,17 @@ def test_bench_json_contract():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
+    # the committed PMC file vouches for this build of the kernels (a stale one is refused: traffic None, "stale" says why)
+    src = rf["traffic_source"]
+    assert src["file"].startswith("profiles/r") and len(src["git_blob"]) == 40 and "stale" not in src, src
+    assert rf["traffic"] is not None and rf["traffic"] > 0
+    # the attention kernels north_star puts a number on, HIP-event-bracketed in this run
+    ra = d["roofline_attention"]
+    for kind in ("fwd", "bwd"):
+        a = ra[kind]
+        assert a["bound"] == "mfma" and a["peak"] == 2500.0 and a["unit"] == "TFLOP/s" and a["launches"] > 0, a
+        assert abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-9 and 0.02 < a["frac"] < 1.0, a
+    assert "attn_fwd2_kernel" in ra["fwd"]["kernel"] and "attn_bwd_dq_kernel" in ra["bwd"]["kernel"]
     m = d["merge"]
     assert m["roofline"]["bound"] == "hbm" and m["algorithmic_bytes"] == 1077239808 and 0.3 < m["roofline"]["frac"] < 1.0
     # parity gate beside the number: the buffer the merge leg has just timed, against the CPU oracle on layers 0 and 11

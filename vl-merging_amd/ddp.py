@@ -46,7 +46,7 @@ class _WireHandle(_Works):
 
 class FlatGradReducer:
     def __init__(self, model, process_group=None, force_collectives=False, sharded=False, comm_dtype=None,
-                 collective="allreduce", standin=None):
+                 collective="allreduce", standin=None, cu_budget="auto"):
         """force_collectives: issue the all-reduces even at world size 1 (a single-GPU smoke test of the RCCL path).
         comm_dtype: None / torch.float32 -> the fp32 gradients travel as they are (what Lightning's DDP does with the
         reference's fp32 master gradients); torch.bfloat16 -> every bucket is cast into a bf16 wire buffer, reduced there
@@ -78,15 +78,28 @@ class FlatGradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        # Data-parallel defaults from the single-GPU contention stand-in (profiles/r05_contention.json, tools/contention_sweep.py:
-        # every bucket's collective replaced by k workgroups holding a CU each + a copy of the bucket): the weight-gradient side
-        # stream stays ON (68.9-69.2 ms per step against 70.2-70.7 without it at k = 8..32), and the GEMM grids plan for 248
-        # of the 256 CUs (neutral at k <= 16, 70.6 -> 69.2 ms at k = 32).  VLM_GEMM_CUS in the environment overrides.
-        if self.world > 1 and not os.environ.get("VLM_GEMM_CUS"):
+        # Data-parallel default from the single-GPU contention stand-in (profiles/r05_contention.json, tools/contention_sweep.py:
+        # every bucket's collective replaced by k workgroups holding a CU each + a copy of the bucket): the GEMM grids plan for 248
+        # of the 256 CUs (neutral at k <= 16, 70.6 -> 69.2 ms at k = 32).  cu_budget: "auto" = that default, and ONLY where it
+        # can matter -- gradients on a GPU exchanged by RCCL's own kernels (backend nccl), world size > 1, no VLM_GEMM_CUS in the
+        # environment; an integer = that budget; None = leave the library alone.  The budget is PROCESS-global (it sizes every GEMM
+        # grid and split-K slice count of this process, so a world-size-1 run and a world-size-N run differ in summation
+        # order): `cu_budget_set` says what this reducer did, `close()` puts the previous value back, bench.py reports the value.
+        self.cu_budget_set, self._cu_budget_prev = None, None
+        want = None
+        if cu_budget == "auto":
+            nccl = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+            if self.world > 1 and nccl and self.flat.flat_g.is_cuda and not os.environ.get("VLM_GEMM_CUS"):
+                want = 248
+        elif cu_budget is not None:
+            want = int(cu_budget)
+        if want is not None:
             from . import _lib as L
             lib = L.get_lib()
-            if lib.vlm_device_cus() >= 256:
-                lib.vlm_set_cu_budget(248)
+            if lib.vlm_device_cus() >= 256 or cu_budget != "auto":
+                self._cu_budget_prev = lib.vlm_device_cus()
+                lib.vlm_set_cu_budget(want)
+                self.cu_budget_set = want
         names_by_block = {}
         early, late = [], []
         for n in self.flat.names:
@@ -117,6 +130,8 @@ class FlatGradReducer:
         self._attached = None
         self._tail_handles = []
         self._wait_events = []
+        self.timeline_on = False  # bench.py: per-bucket issue / complete times of the LAST step (bucket_timeline())
+        self._t0, self._timeline = None, []
 
     @property
     def grad_scale(self):
@@ -135,11 +150,26 @@ class FlatGradReducer:
         self._attached = optimizer
         return self
 
+    def close(self):
+        """Put the process-global CU budget back to what it was before this reducer changed it (no-op otherwise)."""
+        if self.cu_budget_set is not None:
+            from . import _lib as L
+            lib = L.get_lib()
+            raw = self._cu_budget_prev
+            lib.vlm_set_cu_budget(0)
+            if raw is not None and raw != lib.vlm_device_cus():
+                lib.vlm_set_cu_budget(raw)  # the previous value was itself a budget (VLM_GEMM_CUS / an outer reducer)
+            self.cu_budget_set = None
+
     def begin_step(self):
         # a deferred tail all-reduce nobody waited for (optimizer step skipped, or defer_tail set by hand without
         # tail_sync) must land before the gradient buffer is written again
         if self._tail_handles:
             self.wait_tail()
+        if self.timeline_on and self.comm_stream is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record()
+            self._timeline = []
         for i in self.seen:
             self.seen[i] = 0
         self.handles = []
@@ -169,6 +199,24 @@ class FlatGradReducer:
             order.append({"what": "embeddings (deferred under AdamW)" if self.defer_tail else "embeddings",
                           "MB": round((hi - lo) * wire / 1e6, 2)})
         return {"count": len(order), "total_MB": round(sum(b["MB"] for b in order), 2), "in_issue_order": order}
+
+    def bucket_timeline(self):
+        """Per bucket of the last step (timeline_on): milliseconds from begin_step to the collective's issue on the
+        communication stream and to its completion -- the first multi-GPU run reads its exposed time off this (synchronises)."""
+        if not self._timeline or self._t0 is None:
+            return None
+        torch.cuda.synchronize()
+        names = {}
+        for i, (lo, hi) in self.block_slices.items():
+            names[(lo, hi)] = "block %d" % i
+        for lo, hi in self.late_slices:
+            names[(lo, hi)] = "heads"
+        for lo, hi in self.tail_slices:
+            names[(lo, hi)] = "embeddings"
+        wire = 2 if self.comm_dtype is not None else 4
+        return [{"what": names.get((lo, hi), "[%d,%d)" % (lo, hi)), "MB": round((hi - lo) * wire / 1e6, 2),
+                 "issue_ms": round(self._t0.elapsed_time(e0), 3), "done_ms": round(self._t0.elapsed_time(e1), 3)}
+                for lo, hi, e0, e1 in self._timeline]
 
     def own_chunk(self, lo, hi, rank=None):
         n = hi - lo
@@ -260,7 +308,18 @@ class FlatGradReducer:
             if ws is not None:
                 self.comm_stream.wait_stream(ws)  # the slice's weight gradients are produced on the side stream
             with torch.cuda.stream(self.comm_stream):
-                self.handles.append(self._reduce(lo, hi))
+                if self.timeline_on and self._t0 is not None:
+                    # issue -> complete of this bucket on the communication stream (which then waits for the collective itself:
+                    # collectives of one process group are serial anyway; the compute stream is not involved)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    h = self._reduce(lo, hi)
+                    h.wait()
+                    e1.record()
+                    self._timeline.append((lo, hi, e0, e1))
+                    self.handles.append(h)
+                else:
+                    self.handles.append(self._reduce(lo, hi))
         else:
             self.handles.append(self._reduce(lo, hi))
 
