@@ -112,7 +112,9 @@ def test_gathering_losses_two_ranks(pkg, tmp_path, config):
     # is a difference of nearly equal terms), and the worst element -- one entry of cls_token -- moves by 1-2 % of the scale in the
     # SINGLE-process run when one kernel is exchanged for an equivalent one (fused / unfused attention backward, folded / unfolded
     # LayerScale: round 5, gpurun_out/r05/call_f.txt), while both set-ups agree with the reference to the goldens' tolerance
-    assert err <= 5e-2 * scale, (err, scale, where, float(got[at]), float(want[at]))
+    # The well-conditioned pretrain step keeps 2 %: a reducer / finish ordering bug (a missed finish_layerscale on one rank moves
+    # the gamma gradients by about 5 %) must not hide behind the irtr case's allowance.
+    assert err <= (2e-2 if config == "pretrain" else 5e-2) * scale, (err, scale, where, float(got[at]), float(want[at]))
     # the contrastive share is really there (and really scaled by 1/W): leaving it out or taking it in full must fail
     c = np.abs(grads["contrastive"]).max()
     assert c / W > 4e-2 * scale or config == "pretrain"

@@ -120,6 +120,30 @@ def test_regmean_matches_reference_tiny(case, pkg, golden_dir):
             assert res[k] is sd[k]
 
 
+def test_regmean_with_modalities_of_different_dtypes(pkg, golden_dir):
+    """A weight whose two modalities arrive in different dtypes (fp32 beside fp16, which the merge widens to float64): its two
+    numerator terms land in different product batches.  Term 0 (beta = 0) must still run before term 1 (beta = 1); the result
+    is the tiny golden's up to the fp16 rounding of the one modality, i.e. equal to the merge of the ROUNDED state in fp32."""
+    rm = importlib.import_module("vl_merging_amd.regmean")
+    case = [c for c in sorted(CASES) if CASES[c][0] == "regmean"][0]
+    cfg = merge_cfg(**CASES[case][1])
+    base = tiny_state("all_moe")
+    grams = {k: torch.from_numpy(v) for k, v in tiny_grams().items()}
+    halved = lambda k: ".l." in k and k.endswith(".weight") and "norm" not in k  # the language experts' linear weights
+    sd_mixed = {k: (torch.from_numpy(v).cuda().half() if halved(k) else torch.from_numpy(v).cuda()) for k, v in base.items()}
+    sd_round = {k: (torch.from_numpy(v).cuda().half().float() if halved(k) else torch.from_numpy(v).cuda()) for k, v in base.items()}
+    assert any(halved(k) for k in base)
+    got = rm.regmean(sd_mixed, cfg, gram_matrices=grams)
+    want = rm.regmean(sd_round, cfg, gram_matrices=grams)
+    torch.cuda.synchronize()
+    n = 0
+    for k, w in want.items():
+        if torch.is_tensor(w) and w.dtype == torch.float64:
+            np.testing.assert_allclose(got[k].cpu().numpy(), w.cpu().numpy(), rtol=1e-10, atol=1e-12, err_msg=k)
+            n += 1
+    assert n > 0
+
+
 def test_regmean_base_size_matches_reference(pkg, golden_dir):
     """configs[3], RegMean half, at base size (D = 768, F = 3072): layers 0 and 11 of an all_moe state through the
     MFMA-f64 GEMMs + blocked Cholesky solve against the reference's `W.double() @ G` / torch.inverse results

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
   ad[8] = voffK; ad[9] = voffV; ad[10] = drow; ad[11] = bvoff;
   ad[12] = hh == 0 ? lds0 + F2_KM + 512 + r * 4 : zword;
   ad[13] = 0xFFFFFFF0u;
-  ad[14] = 0u; ad[15] = 0u;
+  ad[14] = 0u; ad[15] = 0x3F803F80u;  // (1, 1) in bf16: the row sums' v_dot2c operand
   {
     f16x8 sel0, sel1;
     att_select_frags(lane, sel0, sel1);

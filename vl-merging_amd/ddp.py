@@ -345,6 +345,7 @@ class FlatGradReducer:
                 self.expected = dict(self.seen)
                 self.counting = False
             return
+        self.flat.finish_layerscale()  # nothing pending in a normal step (end-of-backward callback / per-bucket finish)
         if self.counting:
             # first step: use counts were unknown during backward -> reduce every block now, remember the counts
             self.expected = dict(self.seen)

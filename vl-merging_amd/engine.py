@@ -212,6 +212,18 @@ class FlatParams:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        # Folded LayerScale: in a normal step nothing is pending here (the end-of-backward callback, or the reducer right
+        # before a bucket left, turned the raw sums into gradients and zeroed them).  A backward pass that RAISED (out of
+        # memory inside a retry loop, a kernel error) leaves raw sums of the failed step behind and the callback latch set:
+        # without this reset no later backward would arm its finish again and the stale sums would be added to the next step.
+        if getattr(self, "ls_pending", None) or getattr(self, "_ls_armed", False):
+            for jobs in getattr(self, "_ls_jobs", {}).values():
+                for j in jobs:
+                    j["raw_w"].zero_()
+                    if j["raw_b"] is not None:
+                        j["raw_b"].zero_()
+            self.ls_pending.clear()
+            self._ls_armed = False
 
     def slice_of(self, names):
         """(start, end) of the contiguous flat range covering `names` (a DDP bucket)."""

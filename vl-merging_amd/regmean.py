@@ -137,9 +137,18 @@ class _Products:
     def __init__(self):
         self.groups = {}
         self.small_event = None  # recorded after the latest launch of products whose reduction is <= 1 024 long
+        self.last_group = {}     # id(num) -> the group that holds the numerator's latest term
 
     def add(self, term, W, Gs, num):
         key = (tuple(W.shape), W.dtype)
+        # A weight's terms are ordered by construction only INSIDE a group.  If its modalities differ in dtype (an fp32 master
+        # beside an fp16 tensor widened to float64), term 1 (beta = 1) lands in another group than term 0 (beta = 0), and a
+        # later flush of that group could run it first -- term 0 would then overwrite the accumulated numerator.  So the group
+        # holding the earlier term is flushed before the later term is queued anywhere else.
+        prev = self.last_group.get(id(num))
+        if prev is not None and prev != key and prev in self.groups:
+            self._flush(prev)
+        self.last_group[id(num)] = key
         g = self.groups.setdefault(key, {})
         g.setdefault(term, []).append((W, Gs, num))
         tiles = -(-W.shape[0] // 64) * -(-Gs.shape[1] // 64)
@@ -163,6 +172,7 @@ class _Products:
         for key in sorted(self.groups, key=lambda k: k[0][1]):  # short reductions first: their solves may start under the long ones
             self._flush(key)
         self.groups = {}
+        self.last_group = {}
 
 
 def regmean(state_dict, config, gram_matrices=None, device="cuda", plan_out=None):
