@@ -89,13 +89,30 @@ def feat_close(got, ref, what, tol=1.7e-2):
     assert err <= tol * scale, "%s: max err %.4g vs scale %.4g" % (what, err, scale)
 
 
-def grad_elementwise_close(got, ref, name, tol_small=0.2, tol=0.15):
+def roundoff_model_bound(n_elements, roundings=144, cancellation=1.5):
+    """Expected max over a tensor's elements of |gradient error| / max |gradient| under the bf16 round-off model, as a bound.
+    Every activation and every gradient is rounded to bf16 where it crosses a kernel boundary: a relative error uniform in
+    +-2^-9 (rms 2^-9 / sqrt 3 = 1.13e-3).  On the longest path of a training step a value crosses about 12 such boundaries per
+    block (forward: LayerNorm output, qkv, attention output, proj input, LayerNorm output, fc1 / GELU output; backward: the
+    mirror images) x 12 blocks = 144 independent roundings, which add as a random walk: sigma = sqrt(144) x 1.13e-3 = 1.35 % of
+    the signal.  The largest of N such errors is about sqrt(2 ln N) sigma (4.6 sigma for a 192 x 192 weight, 3.2 for a 192-vector),
+    and an element that is a sum of partly cancelling terms sees sigma times (sum |terms| / |sum|): `cancellation`, taken as 1.5.
+    => 192-vector 6.6 %, 192 x 192 weight 9.3 %, 768 x 768 weight 10.4 %.  (What the final GEMM's own operand rounding adds is
+    sqrt(K) 2^-8 of ONE product against a sum of K: two orders below this.)  For comparison, the reference's own fp16-autocast
+    run moves the worst sampled tensor by 6.3 % (ufo) on the same check at base width (amp_reference_errors.json)."""
+    import math
+    sigma = math.sqrt(roundings) * 2.0 ** -9 / math.sqrt(3.0)
+    return cancellation * math.sqrt(2.0 * math.log(max(n_elements, 2))) * sigma
+
+
+def grad_elementwise_close(got, ref, name, tol_small=0.2, tol=None):
     """Element-wise check of a sampled gradient tensor against the reference's: max |got - ref| relative to the tensor's
-    largest entry.  MEASURED (round 5, gpurun_out/r05/parity_fold{0,1}.json, recorded into parity_errors.json by every run like the
-    features' errors): 6.8-9.6 % at the tiny width (the worst tensor is cls_token, a sum of a few small rows), 3.6-4.8 % at base
-    width, the same with the LayerScale folded or not -- bf16 activations between all kernels against the reference's fp32 CPU
-    run (its own fp16-autocast run is not element-wise better on these tensors).  The bound is 2 x measured; the gradient NORMS,
-    which carry the weight of the parity claim, are checked at 2.5 % (measured <= 1.4 %)."""
+    largest entry.  The bound is DERIVED (roundoff_model_bound: 6.6-10.4 % by tensor size), not "2 x measured" as in round 5;
+    measured (recorded into parity_errors.json by every run): 6.8-9.6 % at the tiny width -- the worst tensor is cls_token, a sum
+    of a few small rows, the one case that needs the small-gradient allowance below -- and 3.6-4.8 % at base width, the same with
+    the LayerScale folded or not.  The gradient NORMS, which carry the weight of the parity claim, are checked at 2.5 %."""
+    if tol is None:
+        tol = roundoff_model_bound(ref.numel())
     err = float((got - ref).abs().max())
     mx = float(ref.abs().max())
     floor = 2.5e-4 if ref.numel() == 1 else 1e-6  # near-zero scalar (logit scale) gradients: see grad_norm_ok
@@ -826,3 +843,106 @@ def test_dense_bias_cache_dies_with_its_model(mods, golden_dir):
         torch.cuda.empty_cache()
     assert serials[0] != serials[1]
     assert not torch.equal(feats[0], feats[1])
+
+
+def test_ten_step_trajectory_follows_the_oracle(mods, golden_dir):
+    """TEN optimizer steps (eval-mode forward: no RNG; B = 2: the hard negatives are forced) on the GPU engine -- HIP kernels,
+    bf16 operands, FusedAdamW -- and in the oracle: fp32 autograd through oracle/vlmo_ref.pretrain_step on the CPU with
+    oracle/adamw_hf4.AdamWHF4 (float64 restatement of the published transformers-4.x rule; UNPINNED, see its header) under the
+    parameter groups and schedule that tests/golden/schedule_groups.json pins to the reference's own set_schedule.
+    Checked: the loss of every step (3e-2, the single-step bound) and, per tensor, how far the ten-step weight change
+    dW = W_10 - W_0 is from the oracle's.  Adam divides each gradient element by its own running magnitude: every element moves by
+    about lr per step in the direction of its gradient's SIGN, however small the gradient.  An element whose gradient is inside
+    the bf16 noise (the single-step element-wise error measured here is 4-10 % of the tensor's largest entry) therefore takes
+    steps of arbitrary sign on both sides, and over ALL elements the ten-step drift is 15-30 % for most tensors (recorded in
+    parity_errors.json; the reference's own fp16-autocast run would show the same).  The drift is therefore asserted on the
+    elements whose gradient is resolved -- the oracle's mean |g| over the ten steps at or above a quarter of its largest entry in
+    the tensor -- and must stay within 2 % there (measured <= 0.7 %; 25 % for the two scalar logit scales, whose B = 2 gradient
+    is below every reduced-precision path's noise floor: measured 12.5 %)."""
+    import copy
+    from oracle import vlmo_ref as R
+    from oracle.adamw_hf4 import AdamWHF4, polynomial_decay_with_warmup
+    cfgmod, vm = mods
+    vu = vm.vilt_utils
+    model = build(mods, "ufo", "tiny_ufo", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1})
+    cfg = model.hparams.config
+    STEPS, MAX_STEPS = 10, 100
+    (opt,), (sch,) = vu.set_schedule(model, max_steps=MAX_STEPS)
+    nb = det_batch(2, 224, 40, 1024, seed=1234)
+    batch = gpu_batch(nb)
+    w0 = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    # ---- oracle side --------------------------------------------------------------------------------------------------------
+    idx = {k: getattr(model, k).cpu() for k in ("relative_position_index", "text_relative_position_index",
+                                                "text_imag_relative_position_index")}
+    heads = vu.head_names(cfg)
+    spec = vu.group_spec(cfg)
+    groups = {n: (spec[vu.param_group_of(n, heads)][1], spec[vu.param_group_of(n, heads)][0]) for n in w0}
+    warm = cfg["warmup_steps"]
+    warm = int(MAX_STEPS * warm) if isinstance(warm, float) else warm
+    master = {n: w.double().numpy().copy() for n, w in w0.items()}
+    oopt = AdamWHF4(master, groups, betas=(0.9, cfg["beta_2"]), eps=1e-8)
+    ob = {k: torch.from_numpy(v) for k, v in nb.items()}
+    arch = R.Arch("ufo", hidden=192, heads=3)
+    extra = {k: v.detach().cpu() for k, v in model.state_dict().items() if k not in w0 and v.is_floating_point()}
+    gpu_losses, ora_losses, gabs = [], [], {}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    for it in range(STEPS):
+        loss = model.training_step({"vl": batch}, it)
+        loss.backward()
+        opt.step()
+        sch["scheduler"].step()
+        gpu_losses.append(float(loss.detach()))
+        osd = {n: torch.from_numpy(master[n]).float().requires_grad_(True) for n in master}
+        full = dict(extra)
+        full.update(osd)
+        ref = R.pretrain_step(full, arch, idx, ob)
+        ref["total_loss"].backward()
+        ora_losses.append(float(ref["total_loss"].detach()))
+        fac = polynomial_decay_with_warmup(it, warm, MAX_STEPS, cfg["learning_rate"], cfg["end_lr"], cfg["decay_power"])
+        og = {n: (t.grad.numpy() if t.grad is not None else None) for n, t in osd.items()}
+        for n, g_ in og.items():
+            if g_ is not None:
+                gabs[n] = gabs.get(n, 0.0) + np.abs(g_) / STEPS
+        oopt.step(og, fac)
+    torch.cuda.synchronize()
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    rec = MEASURED.setdefault(test, {})
+    rec["loss max abs err over 10 steps"] = max(abs(a - b) for a, b in zip(gpu_losses, ora_losses))
+    for a, b in zip(gpu_losses, ora_losses):
+        assert abs(a - b) <= 3e-2, (gpu_losses, ora_losses)
+    assert ora_losses[-1] < ora_losses[0] and gpu_losses[-1] < gpu_losses[0]
+    worst_all, worst_big, n_checked = ("", 0.0), ("", 0.0), 0
+    table, failed = [], []
+    for n, p in model.named_parameters():
+        dw_o = torch.from_numpy(master[n]).float() - w0[n]
+        if float(dw_o.abs().max()) == 0.0:
+            assert torch.equal(p.detach().cpu(), w0[n]), n  # no gradient on either side: untouched (no decay either)
+            continue
+        dw_g = p.detach().cpu() - w0[n]
+        rel_all = float((dw_g - dw_o).norm() / dw_o.norm())
+        ga = torch.from_numpy(np.asarray(gabs[n], dtype=np.float32))
+        big = ga >= 0.25 * ga.max()
+        rel_big = float((dw_g - dw_o)[big].norm() / dw_o[big].norm())
+        n_checked += 1
+        if rel_all > worst_all[1]:
+            worst_all = (n, rel_all)
+        if rel_big > worst_big[1] and p.numel() > 1:
+            worst_big = (n, rel_big)
+        # scalars (the two logit scales): one number whose gradient at B = 2 is below the noise floor of any reduced-precision
+        # path (grad_norm_ok) -- the update's SIGN must agree, its size within 25 %
+        lim = 0.25 if p.numel() == 1 else 0.02  # measured: <= 0.7 % on every tensor, 12.5 % on logit_vl_scale
+        table.append((rel_big, rel_all, n))
+        if rel_big > lim:
+            failed.append((n, round(rel_big, 4), round(rel_all, 4), lim))
+    table.sort(reverse=True)
+    print("largest drifts (update-carrying elements, all elements, tensor):")
+    for t in table[:12]:
+        print("   %.4f  %.4f  %s" % t)
+    med = sorted(t[0] for t in table)[len(table) // 2]
+    rec["weight drift, elements that carry the update, median tensor"] = med
+    assert not failed, failed
+    rec["weight drift, elements that carry the update, worst tensor"] = worst_big[1]
+    rec["weight drift, all elements, worst tensor"] = worst_all[1]
+    assert n_checked > 100
+    print("trajectory: loss err %.2e; drift worst (update-carrying elements) %s %.3f; (all elements) %s %.3f"
+          % (rec["loss max abs err over 10 steps"], worst_big[0], worst_big[1], worst_all[0], worst_all[1]))
