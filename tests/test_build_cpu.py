@@ -84,3 +84,19 @@ def test_generated_stream_is_current():
     import sys
     gen = os.path.join(CSRC, "gen", "attn_fwd2_gen.py")
     assert subprocess.call([sys.executable, gen, "--check"]) == 0, "run python vl-merging_amd/csrc/gen/attn_fwd2_gen.py"
+
+
+def test_hand_placed_dq_fits_two_waves_per_simd(resources):
+    """attn_bwd_dq2_kernel: v32..v201 + 32 accumulator registers, two workgroups of 34 KiB per CU."""
+    r = [v for k, v in resources.items() if "attn_bwd_dq2_kernel" in k]
+    assert len(r) == 1
+    r = r[0]
+    assert r["Occupancy"] == 2 and r["VGPRs"] + r["AGPRs"] <= 256 and r["AGPRs"] == 32, r
+    assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and 2 * r["LDS Size"] <= 160 * 1024, r
+
+
+def test_generated_dq_stream_is_current():
+    import subprocess
+    import sys
+    gen = os.path.join(CSRC, "gen", "attn_dq2_gen.py")
+    assert subprocess.call([sys.executable, gen, "--check"]) == 0, "run python vl-merging_amd/csrc/gen/attn_dq2_gen.py"

@@ -34,6 +34,7 @@ struct attn_bwd_params_t {
 };
 
 #include "attention_bwd_dkvb.h"
+#include "attention_bwd_dq2.h"
 
 // ----------------------------------------------------------------------------------------------------- dQ kernel
 // Query-stationary: workgroup = 128 query positions of one (sample, head), lane <-> query, streams 64-key tiles.
@@ -918,12 +919,14 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
   if (pl.W) {
     // dQ (+ delta), then dK / dV and the bias-table gradient in ONE launch: 7 MFMA products per score instead of 9
     bp.nstat = nullptr;  // (the 16-wave kernel's C operands are not needed)
+    if (!att_dq2_launch(bp, grid, s)) {  // the hand-placed stream (attention_bwd_dq2.h) takes the calls it covers
 #ifdef VLM_DIAG  // harness only: VLM_DIAG_DQ_PAD_LDS=bytes of unused dynamic LDS (40960: one workgroup per CU instead of two)
-    static const size_t dq_pad = [] { const char* e = getenv("VLM_DIAG_DQ_PAD_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, dq_pad, s, bp);
+      static const size_t dq_pad = [] { const char* e = getenv("VLM_DIAG_DQ_PAD_LDS"); return e ? (size_t)atoi(e) : (size_t)0; }();
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, dq_pad, s, bp);
 #else
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
 #endif
+    }
     VLM_CHECK_LAUNCH();
     const size_t need = hr + (size_t)pl.items * p.R;
     bp.dbias_part = ws_floats >= need ? delta_ws + hr : nullptr;
@@ -942,7 +945,7 @@ extern "C" int vlm_attention_bwd(const vlm_attn_desc_t* d, const void* out, int 
                          gm.nkb[0] + gm.nkb[1], dbias_t, p.head_row0);
     }
   } else if (p.bias_t) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
+    if (!att_dq2_launch(bp, grid, s)) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, block, 0, s, bp);
     VLM_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), grid, block, 0, s, bp);
     if (dbias_t) {

@@ -75,7 +75,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
   b0w[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff, 0, 0));
   b0w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff + 1024, 0, 0));
   const uint32_t drow = (uint32_t)wave * 8u + (uint32_t)(lane >> 3), c16 = lane & 7;
-  const uint32_t voffK = (drow * p.ld_qkv + ((c16 ^ (drow & 7)) << 3)) * 2u;
+  // K: the image of attention_bwd_dkvb.h (chunk ^ f(row): conflict-free for the LDS-DMA writes AND ds_read_b128; the round-2 row
+  // image chunk ^ (row & 7) is 2-way on every ds_read_b128, tools/lds_layout_check.py); LDS-DMA writes linearly, so the swizzle
+  // goes on the SOURCE chunk
+  const uint32_t fswK = ((drow >> 2) & 3u) | (((drow >> 1) & 1u) << 2);
+  const uint32_t voffK = (drow * p.ld_qkv + ((c16 ^ fswK) << 3)) * 2u;
   const uint32_t voffV = (drow * p.ld_qkv + (((((c16 >> 1) ^ (((drow >> 1) & 1) << 1)) << 1) | (c16 & 1)) << 3)) * 2u;
   auto stage_block = [&](int blk, int s) {
     const int kp0 = sp.s_lo + blk * 32, pq = kp0 + (int)drow;
@@ -87,19 +91,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rkv, (att_lds_void*)dst, 16, ok ? rowoff + (uint32_t)(D + h * 64) * 2u + voffK : 0xFFFFFFF0u, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rkv, (att_lds_void*)(dst + 8192), 16, ok ? rowoff + (uint32_t)(2 * D + h * 64) * 2u + voffV : 0xFFFFFFF0u, 0, 0, 0);
   };
-  stage_block(0, 0);
-  stage_block(0, 1);
-  stage_block(1, 0);
-  stage_block(1, 1);
-  stage_block(2, 0);
-  {
-    const int t = tid >> 7, s = (tid >> 6) & 1, k = tid & 63;
-    const float mk = att_key_mask(ps, bs[s], sp.s_lo + t * ATT_BK + k, sp.s_hi, p.keep0, p.keep1);
-    *reinterpret_cast<uint32_t*>(lds + F2_KM + tid * 4) = mk < 0.f ? 0xC6EAu : 0u;  // bf16(-30 000) in k-slot 2
-    *reinterpret_cast<uint32_t*>(lds + F2_KM + 1024 + tid * 4) = 0u;
-  }
-
-  // ---- prologue (2): Q fragments and the per-lane constants of the stream, while the tiles are in flight -------------------
+  // plain loads and their uses BEFORE the LDS-DMA pieces: hipcc waits vmcnt(0) at the first use of a plain load's result while an
+  // LDS-DMA is in flight (a plain load issued after the pieces costs its own round trip behind theirs)
+  // this thread's mask word: key position (tile tid >> 7, sample (tid >> 6) & 1, key tid & 63); its keep byte comes through a
+  // descriptor, out of range where there is nothing to read (a load under a branch would be waited for inside it)
+  const int ms = (tid >> 6) & 1, mpos = sp.s_lo + (tid >> 7) * ATT_BK + (tid & 63);
+  const bool mtxt = mpos < ps.n0, mimg = mpos >= ps.pos1 && mpos < ps.NP;
+  const bool mok = (mtxt || mimg) && mpos < sp.s_hi;
+  const __amdgpu_buffer_rsrc_t rkeep0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.keep0 ? p.keep0 : reinterpret_cast<const uint8_t*>(p.qkv)), 0, p.keep0 ? (uint32_t)(ps.B * ps.n0) : 0u, 0x00020000);
+  const uint32_t keep_raw = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(
+      rkeep0, (mok && mtxt) ? (uint32_t)((ms ? bs[1] : bs[0]) * ps.n0 + mpos) : 0xFFFFFFF0u, 0, 0);
   const int qp = sp.p0 + wave * 32 + r;
   u32x16 qv[2];
   const float c1 = p.scale * ATT_LOG2E;
@@ -119,10 +121,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
       for (int e = 0; e < 4; ++e) qv[s][4 * ss + e] = w[e];
     }
   }
+  stage_block(0, 0);
+  stage_block(0, 1);
+  stage_block(1, 0);
+  stage_block(1, 1);
+  stage_block(2, 0);
+  *reinterpret_cast<uint32_t*>(lds + F2_KM + tid * 4) = (mok && !(mtxt && p.keep0 && keep_raw == 0)) ? 0u : 0xC6EAu;  // bf16(-30 000) in k-slot 2
+  *reinterpret_cast<uint32_t*>(lds + F2_KM + 1024 + tid * 4) = 0u;
+
   u32x16 ad;
   u32x8 cs;
 #pragma unroll
-  for (int ss = 0; ss < 4; ++ss) ad[ss] = lds0 + r * 128 + (((2 * ss + hh) ^ (r & 7)) << 4);
+  for (int ss = 0; ss < 4; ++ss) {
+    const uint32_t fr = (((uint32_t)r >> 2) & 3u) | ((((uint32_t)r >> 1) & 1u) << 2);
+    ad[ss] = lds0 + r * 128 + ((((uint32_t)(2 * ss + hh)) ^ fr) << 4);
+  }
   {
     const int g16 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
@@ -145,10 +158,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
 #pragma unroll
     for (int e = 0; e < 4; ++e) { cs[e] = a0[e]; cs[4 + e] = a1[e]; }
   }
+  // descriptor words for the stream's own buffer operations: uniform by construction, and SAID to be (readfirstlane) -- the
+  // compiler may hold the base pointer in vector registers for the plain loads above and has no vector -> scalar copy
   const uint64_t qa = (uint64_t)(uintptr_t)p.qkv;
-  const u32x4 rkv4 = {(uint32_t)qa, (uint32_t)(qa >> 32) & 0xffffu, (uint32_t)((size_t)p.total_rows * p.ld_qkv * 2), 0x00020000u};
+  const u32x4 rkv4 = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qa),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(qa >> 32) & 0xffffu)),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((size_t)p.total_rows * p.ld_qkv * 2)), 0x00020000u};
   const uint64_t ba = (uint64_t)(uintptr_t)bias_col;
-  const u32x4 rb4 = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, rb_bytes, 0x00020000u};
+  const u32x4 rb4 = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ba),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(ba >> 32) & 0xffffu)),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)rb_bytes), 0x00020000u};
   u32x8 bwv;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { bwv[e] = b0w[0][e]; bwv[4 + e] = b0w[1][e]; }
@@ -166,6 +185,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
     sc[5] = (uint32_t)(sp.s_hi - kp2);
     sc[6] = lds0 + (uint32_t)wave * 1024u;
     sc[7] = (uint32_t)p.ld_qkv * 64u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sc[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc[e]);  // uniform, and said to be
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

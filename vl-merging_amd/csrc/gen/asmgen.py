@@ -96,7 +96,8 @@ def place_waits(pre, body, vm_history=0):
                     t = t0.lstrip("^")
                     if t in lds_tags:
                         i = last_index(lgkm_q, t, skip)
-                        assert i is not None, "LDS result %s is not from this trip (%s)" % (t, op.text)
+                        if i is None:
+                            continue  # an earlier wait of this trip already covered it (LDS results return in order)
                         k = len(lgkm_q) - 1 - i
                         wl = k if wl is None else min(wl, k)
                     elif t in vm_tags:

@@ -58,6 +58,7 @@ S_BOFF = 60      # bias scalar offset of the current trip's SECOND key block (tr
 S_TMP = 61
 S_LO = 62        # s[62:63] = lower half-wave
 
+PRIO = os.environ.get("VLM_GEN_PRIO", "slot")
 MF_BF = "v_mfma_f32_32x32x16_bf16"
 MF_F16 = "v_mfma_f32_32x32x16_f16"
 
@@ -141,12 +142,8 @@ def exp_cvt(u):
     def ex(i): return Op("v_exp_f32_e32 %s, %s" % (Sr(s, i), Sr(s, i)), "trans", [Sr(s, i)], [Sr(s, i)])
     def cv(d): return valu("v_cvt_pk_bf16_f32 %s, %s, %s" % (Pr(s, d), Sr(s, 2 * d), Sr(s, 2 * d + 1)), [Sr(s, 2 * d), Sr(s, 2 * d + 1)], [Pr(s, d)])
     def dt(d): return valu("v_dot2c_f32_bf16_e32 %s, %s, %s" % (Lr(s, d & 1), Pr(s, d), ones), [Lr(s, d & 1), Pr(s, d), ones], [Lr(s, d & 1)], cost=8)
-    out += [ex(0), ex(1)]
-    for i in range(2, 16, 2):
-        out += [ex(i), ex(i + 1), cv((i - 2) >> 1)]
-        if i >= 4:
-            out.append(dt((i - 4) >> 1))
-    out += [cv(7), dt(6), dt(7)]
+    # sixteen exponentials, then the conversions, then the sums: every input was written eight or more instructions earlier
+    out += [ex(i) for i in range(16)] + [cv(d) for d in range(8)] + [dt(d) for d in range(8)]
     return out
 
 
@@ -342,6 +339,18 @@ def build():
     pre.append(valu("v_mov_b32_e32 %s, 0x3f80" % t0, [], [t0]))
     for s in range(2):
         pre.append(valu("v_cndmask_b32_e64 v%d, 0, %s, s[%d:%d]" % (V_QM + 4 * s + 1, t0, S_LO, S_LO + 1), [t0], ["v%d" % (V_QM + 4 * s + 1)]))
+    # Two waves share a SIMD (two workgroups per CU) and run the same program: left alone they fall into lockstep and take
+    # turns MFMA by MFMA (both stretch their matrix phases, both then sit in their vector phases together).  The wave in the ODD
+    # hardware slot of its SIMD runs at priority 1 for the whole stream -- one static s_setprio, no flips
+    # (MI355X_MICROARCH.md, "Two waves per SIMD", items 4 and 9) -- so that one wave's matrix chain runs through while its
+    # partner does its vector work.  PRIO_EXPERIMENT (env-less switch of the generator): "none" leaves it out.
+    if PRIO == "slot":
+        pre += [Op("s_getreg_b32 s%d, hwreg(HW_REG_HW_ID, 0, 4)" % S_TMP, "salu", [], ["s%d" % S_TMP]),
+                Op("s_and_b32 s%d, s%d, 1" % (S_TMP, S_TMP), "salu", ["s%d" % S_TMP], ["s%d" % S_TMP]),
+                Op("s_cmp_eq_u32 s%d, 1" % S_TMP, "salu", ["s%d" % S_TMP], ["scc"]),
+                Op("s_cbranch_scc0 L_noprio_%=", "salu"),
+                Op("s_setprio 1", "salu"),
+                Op("L_noprio_%=:", "raw")]
     pre += dma_offsets()
     pre.append(valu("v_mov_b32_e32 v%d, v%d" % (V_KMC, V_ADDR + 6), [], ["v%d" % V_KMC]))
     # A(0) of trip 0 alone, then its maximum / decision
@@ -381,7 +390,7 @@ def build():
         sites += [(tag + "1", 1), (tag + "2", 0), (tag + "3", 1), (tag + "0", 0)]
     for site, s in sites:
         tail += rare_block(site, s)
-    tail += ["L_done_%=:", "s_nop 15", "s_nop 15"]
+    tail += ["L_done_%=:", "s_setprio 0", "s_nop 15", "s_nop 15"]
     text = emit(pre_h) + emit(body_h) + "".join(("" if l.endswith(":") else "  ") + l + "\n" for l in tail)
     return text, pre_h, body_h
 
