@@ -33,7 +33,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 8
+#define VLM_ABI_VERSION 9
 int vlm_abi_version(void);
 /* Number of compute units grid sizing and split-K slice counts plan for, or negative error: the current device's count,
  * or the smaller budget set by VLM_GEMM_CUS=n (environment, read once) / vlm_set_cu_budget(n) -- room for RCCL's kernels
@@ -273,6 +273,27 @@ int vlm_cross_entropy_fwd(const void* logits_bf16, int ld, int rows, int V, cons
                           float* loss_rows, float* lse, void* stream);
 int vlm_cross_entropy_bwd(const void* logits_bf16, int ld, int rows, int V, const int64_t* labels, int64_t ignore_index,
                           const float* lse, const float* scale_dev, void* dlogits_bf16, int ld_d, void* stream);
+
+/* Round 6: the rest of the loss tail (the [B, *] algebra of modules/objectives.py that was ~120 torch-native launches per step).
+ *   vlm_l2norm_fwd / _bwd: y = x / ||x||_2 per row in fp32 (the contrastive heads' feature normalisation, objectives.py:248-300,
+ *        vilt_module.py:1329-1375 `/ norm(dim=-1, keepdim=True)`); backward dx = (g - y (g . y)) / ||x|| in x's dtype.
+ *   vlm_contrastive: the symmetric cross-entropy of compute_ifm / compute_irtr (objectives.py:274-300, :393-445) on gathered,
+ *        normalised features [n, D] (this rank's B rows first, as the reference re-inserts them, :277-286), s = exp(log_scale[0]):
+ *        logits [n, n] = s img txt^T; out3 = (loss, d loss / d log_scale, s); d_img / d_txt [B, D] = gradients of the OWN rows.
+ *        ws: vlm_contrastive_ws_floats(n) floats.
+ *   vlm_small_cross_entropy: F.cross_entropy(logits [rows, V], labels) (mean) and dlogits [rows, V] fp32 = its gradient
+ *        (compute_itm_hardneg, objectives.py:239-245: [3B, 2] logits).
+ *   vlm_cross_entropy_reduce: out2 = (sum of the counted rows' losses / count, 1 / count) after vlm_cross_entropy_fwd.
+ *   vlm_scale_by_scalar: out_k = in_k * scalar_dev[0] for up to 4 buffers in one launch (a scalar loss's upstream gradient). */
+int vlm_l2norm_fwd(const void* x, int x_is_bf16, int ld, int rows, int D, float* y, float* inv_norm, void* stream);
+int vlm_l2norm_bwd(const float* g, const float* y, const float* inv_norm, int rows, int D, void* dx, int dx_is_bf16, int ld, void* stream);
+size_t vlm_contrastive_ws_floats(int n);
+int vlm_contrastive(const float* all_img, const float* all_txt, int n, int B, int D, const float* log_scale, float* logits, float* out3,
+                    float* d_img, float* d_txt, float* ws, void* stream);
+int vlm_small_cross_entropy(const void* logits, int is_bf16, int ld, int rows, int V, const int64_t* labels, float* loss, float* dlogits,
+                            void* stream);
+int vlm_cross_entropy_reduce(const float* loss_rows, const int64_t* labels, int rows, int V, int64_t ignore_index, float* out2, void* stream);
+int vlm_scale_by_scalar(const float* const* in, float* const* out, const int* n, int count, const float* scalar_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flat-buffer elementwise kernels.

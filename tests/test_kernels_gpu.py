@@ -952,3 +952,76 @@ def test_layerscale_fold_and_finish_match_autograd(pkg, ops, M, N, K, with_rs):
     assert_close(dW - 0.25, Wr.grad, 2e-2, 1e-2 * float(Wr.grad.abs().max()), "dW")
     assert_close(db + 0.5, br.grad, 2e-2, 1e-2 * float(br.grad.abs().max()), "db")
     assert_close(dg - 2.0, gr.grad, 2e-2, 1e-2 * float(gr.grad.abs().max()), "dgamma")
+
+
+# ---- round 6: the loss tail (csrc/lossops.hip) against torch ------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,D", [(22, 768), (3, 192), (1, 64), (67, 200)])
+def test_l2norm_fwd_bwd_match_autograd(ops, rows, D, dtype):
+    g = torch.Generator(device="cuda"); g.manual_seed(rows * 7 + D)
+    x = (torch.randn(rows, D, device="cuda", generator=g) * 3).to(dtype)
+    y, inv = ops.l2norm_fwd(x)
+    xr = x.float().requires_grad_(True)
+    yr = xr / xr.norm(dim=-1, keepdim=True)
+    assert_close(y, yr.detach(), 1e-6, 1e-6, "l2norm y")
+    gy = torch.randn(rows, D, device="cuda", generator=g)
+    (gx,) = torch.autograd.grad(yr, xr, gy)
+    dx = ops.l2norm_bwd(gy.contiguous(), y, inv, dtype)
+    assert dx.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert_close(dx.float(), gx, tol, tol * float(gx.abs().max()), "l2norm dx")
+
+
+@pytest.mark.parametrize("B,n,D", [(22, 22, 768), (3, 3, 192), (2, 6, 64), (22, 176, 768), (5, 20, 200)])
+def test_contrastive_loss_and_gradients_match_torch(ops, B, n, D):
+    """vlm_contrastive against the reference's formulation (objectives.py:274-300): gathered features with this rank's B rows
+    first, gradients through the own rows only, the logit scale's gradient from every entry."""
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 1000 + n)
+    img = torch.nn.functional.normalize(torch.randn(n, D, device="cuda", generator=g), dim=-1).contiguous()
+    txt = torch.nn.functional.normalize(torch.randn(n, D, device="cuda", generator=g), dim=-1).contiguous()
+    ls = torch.tensor([2.3], device="cuda")
+    out3, logits, d_img, d_txt = ops.contrastive(img, txt, B, ls)
+    io = img[:B].clone().requires_grad_(True); to = txt[:B].clone().requires_grad_(True); lsr = ls.clone().requires_grad_(True)
+    ai = torch.cat([io, img[B:]]); at = torch.cat([to, txt[B:]])
+    li = lsr.exp() * ai @ at.t()
+    gt = torch.arange(n, device="cuda")
+    loss = (torch.nn.functional.cross_entropy(li, gt) + torch.nn.functional.cross_entropy(li.t(), gt)) / 2
+    loss.backward()
+    assert_close(logits, li.detach(), 1e-5, 1e-5, "logits")
+    assert abs(float(out3[0]) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    assert abs(float(out3[2]) - float(ls.exp())) <= 1e-5 * float(ls.exp())
+    assert abs(float(out3[1]) - float(lsr.grad)) <= 1e-4 * max(1.0, abs(float(lsr.grad)))
+    assert_close(d_img, io.grad, 1e-4, 1e-6, "d img")
+    assert_close(d_txt, to.grad, 1e-4, 1e-6, "d txt")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,V", [(66, 2), (6, 2), (300, 5), (1, 3)])
+def test_small_cross_entropy_matches_torch(ops, rows, V, dtype):
+    g = torch.Generator(device="cuda"); g.manual_seed(rows + V)
+    buf = (torch.randn(rows, 64, device="cuda", generator=g) * 2).to(dtype)
+    logits = buf[:, :V]  # a view with a row stride, like the ITM head's padded output
+    labels = torch.randint(0, V, (rows,), device="cuda", generator=g)
+    loss, d = ops.small_cross_entropy(logits, labels)
+    lr = logits.float().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert_close(d, lr.grad, 1e-5, 1e-6, "small ce grad")
+
+
+def test_cross_entropy_reduce_and_scale_by_scalar(ops):
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    rows, V = 880, 30522
+    loss_rows = torch.rand(rows, device="cuda", generator=g)
+    labels = torch.randint(0, V, (rows,), device="cuda", generator=g)
+    labels[::3] = -100
+    labels[5] = V + 3  # outside the vocabulary: not counted either
+    out2 = ops.cross_entropy_reduce(loss_rows, labels, V, -100)
+    keep = (labels != -100) & (labels >= 0) & (labels < V)
+    assert abs(float(out2[0]) - float(loss_rows[keep].sum() / keep.sum())) <= 1e-5
+    assert abs(float(out2[1]) - 1.0 / float(keep.sum())) <= 1e-9
+    a, b, c = torch.randn(22, 768, device="cuda", generator=g), torch.randn(7, device="cuda", generator=g), torch.randn(1, device="cuda", generator=g)
+    sc = torch.tensor([0.37], device="cuda")
+    oa, ob, oc = ops.scale_by_scalar([a, b, c], sc)
+    assert torch.equal(oa, a * sc) and torch.equal(ob, b * sc) and torch.equal(oc, c * sc)

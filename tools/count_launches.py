@@ -43,7 +43,8 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
         step()
     torch.cuda.synchronize()
 OURS = ("vlm_", "attn_", "ln_", "scale_bwd", "colsum", "colreduce", "adamw", "cast_kernel", "im2col", "embedding_bwd", "bias_dense",
-        "transpose_tiles", "droppath", "splitk", "merge")
+        "transpose_tiles", "droppath", "splitk", "merge", "l2norm", "scale_by_scalar", "contrastive", "small_ce", "ce_reduce",
+        "cross_entropy", "layerscale", "gram", "potrf", "trsm")
 cnt, tim = collections.Counter(), collections.Counter()
 names = collections.Counter()
 for e in prof.events():

@@ -149,6 +149,14 @@ SIGNATURES = {
     "vlm_cross_entropy_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
     "vlm_cross_entropy_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                       c_void_p]),
+    "vlm_l2norm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "vlm_contrastive_ws_floats": (c_size_t, [c_int]),
+    "vlm_contrastive": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
+    "vlm_small_cross_entropy": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlm_cross_entropy_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    "vlm_scale_by_scalar": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_embedding_bwd": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int,
                                   ctypes.c_int64, c_void_p]),

@@ -962,6 +962,9 @@ class _LinearFn(torch.autograd.Function):
                 and _is_padded_grad(gy2, M, Np)):
             # the fused cross-entropy's gradient: already the zero-padded bf16 [M, Np] operand (registered by _CrossEntropyFn)
             dy = torch.as_strided(gy2, (M, Np), (Np, 1))
+        elif not ctx.gelu and Np == N:
+            # nothing to pad: the gradient itself (cast once if it arrives in fp32) is the GEMMs' operand
+            dy = gy2 if (gy2.dtype == BF16 and gy2.is_contiguous()) else gy2.to(BF16).contiguous()
         else:
             dy = torch.zeros(M, Np, device=x2.device, dtype=BF16)
             if ctx.gelu:
@@ -1001,33 +1004,94 @@ def linear(x, weight, bias=None, gelu=False):
 
 
 class _L2NormFn(torch.autograd.Function):
-    """y = x / ||x||_2 over the last dim in fp32 (the contrastive heads' feature normalisation, objectives.py:248-300): two kernels
-    forward and four backward -- dx = (g - y (g . y)) / ||x|| -- instead of the dozen autograd derives for x / x.norm(...)."""
+    """y = x / ||x||_2 over the last dim in fp32 (the contrastive heads' feature normalisation, objectives.py:248-300): ONE HIP
+    kernel forward and one backward -- dx = (g - y (g . y)) / ||x||, written in x's dtype (round 6; round 4's form took two torch
+    kernels forward, four backward, and autograd cast the fp32 gradient back to bf16 in another)."""
 
     @staticmethod
     def forward(ctx, x):
-        x = x.float()
-        n = x.norm(dim=-1, keepdim=True)
-        y = x / n
-        ctx.save_for_backward(y, n)
-        return y
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        y, inv = ops.l2norm_fwd(x2)
+        ctx.save_for_backward(y, inv)
+        ctx.dtype, ctx.shape = x.dtype, x.shape
+        return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, g):
-        y, n = ctx.saved_tensors
-        g = g.float()
-        t = (g * y).sum(-1, keepdim=True)
-        return torch.addcmul(g, y, t, value=-1.0).div_(n)
+        y, inv = ctx.saved_tensors
+        g2 = g.reshape(y.shape)
+        if g2.dtype != F32 or not g2.is_contiguous():
+            g2 = g2.float().contiguous()
+        return ops.l2norm_bwd(g2, y, inv, ctx.dtype).view(ctx.shape)
 
 
 _FUSED_LOSS = os.environ.get("VLM_FUSED_LOSS", "1") != "0"  # A/B switch: 0 = torch's cross_entropy / x / x.norm() graphs
 
 
 def l2_normalize(x):
-    if not _FUSED_LOSS:
+    if not _FUSED_LOSS or not x.is_cuda or x.dtype not in (BF16, F32):
         x = x.float()
         return x / x.norm(dim=-1, keepdim=True)
     return _L2NormFn.apply(x)
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    """(loss, logits_per_image, exp(log_scale)) of the symmetric contrastive cross-entropy on normalised features, forward AND
+    gradient in two launches (csrc/lossops.hip vlm_contrastive; reference objectives.py:274-300 / :393-445):
+    all_* = this rank's B rows first, then the other ranks' (no gradient through those, as in the reference).  The loss is a
+    scalar: its upstream gradient scales the stored feature / scale gradients in ONE launch (vlm_scale_by_scalar)."""
+
+    @staticmethod
+    def forward(ctx, img, txt, log_scale, others_img, others_txt):
+        B = img.shape[0]
+        all_img = img if others_img is None else torch.cat([img, others_img])
+        all_txt = txt if others_txt is None else torch.cat([txt, others_txt])
+        ls = log_scale.detach().reshape(1).float()
+        out3, logits, d_img, d_txt = ops.contrastive(all_img.contiguous(), all_txt.contiguous(), B, ls)
+        ctx.save_for_backward(out3, d_img, d_txt)
+        ctx.ls_shape = log_scale.shape
+        ctx.mark_non_differentiable(logits)
+        return out3[0], logits, out3[2]
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_logits, g_scale):
+        out3, d_img, d_txt = ctx.saved_tensors
+        gi, gt, gs = ops.scale_by_scalar([d_img, d_txt, out3[1:2]], g_loss.reshape(1).float())
+        gs = gs.view(ctx.ls_shape)
+        if g_scale is not None:  # somebody differentiates the returned scale itself (d exp(l) / d l = exp(l)): not on the hot path
+            gs = gs + (g_scale * out3[2]).view(ctx.ls_shape)
+        return gi, gt, gs, None, None
+
+
+def contrastive_loss(img, txt, log_scale, others_img=None, others_txt=None):
+    """loss, logits_per_image [n, n], exp(log_scale): img / txt = this rank's normalised fp32 features [B, D]."""
+    return _ContrastiveFn.apply(img, txt, log_scale, others_img, others_txt)
+
+
+class _SmallCrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits [rows, V], labels) for a handful of classes (the ITM head's [3B, 2]): loss and gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, d = ops.small_cross_entropy(logits, labels)
+        ctx.save_for_backward(d)
+        ctx.dtype = logits.dtype
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        (gd,) = ops.scale_by_scalar([d], g.reshape(1).float())
+        return (gd if ctx.dtype == F32 else gd.to(ctx.dtype)), None
+
+
+def small_cross_entropy(logits, labels):
+    if (_FUSED_LOSS and logits.is_cuda and logits.dim() == 2 and logits.dtype in (BF16, F32) and logits.stride(1) == 1
+            and logits.shape[1] <= 64 and labels.dtype == torch.int64):
+        return _SmallCrossEntropyFn.apply(logits, labels.contiguous())
+    return torch.nn.functional.cross_entropy(logits.float(), labels)
 
 
 _PADDED_GRADS = {}  # data_ptr -> (weakref to the buffer, rows, padded columns) of gradient buffers born zero-padded (consumed once by _LinearFn.backward)
@@ -1047,16 +1111,16 @@ class _CrossEntropyFn(torch.autograd.Function):
     def forward(ctx, logits, labels, ignore_index):
         loss_rows, lse = ops.cross_entropy_fwd(logits, labels, ignore_index)
         # the kernels' own validity rule (a label outside [0, V) gets neither loss nor gradient, where torch raises a device
-        # assert): such rows must not sit in the denominator either
-        count = ((labels != ignore_index) & (labels >= 0) & (labels < logits.shape[1])).sum().to(F32)
-        ctx.save_for_backward(logits, labels, lse, count)
+        # assert): such rows must not sit in the denominator either.  One launch: (mean over the counted rows, 1 / count)
+        out2 = ops.cross_entropy_reduce(loss_rows, labels, logits.shape[1], ignore_index)
+        ctx.save_for_backward(logits, labels, lse, out2)
         ctx.ignore_index = ignore_index
-        return loss_rows.sum() / count  # no counted row: 0 / 0 = nan, like F.cross_entropy
+        return out2[0]  # no counted row: 0 / 0 = nan, like F.cross_entropy
 
     @staticmethod
     def backward(ctx, g):
-        logits, labels, lse, count = ctx.saved_tensors
-        scale = (g.to(F32) / count).reshape(1)
+        logits, labels, lse, out2 = ctx.saved_tensors
+        (scale,) = ops.scale_by_scalar([out2[1:2]], g.reshape(1).float())  # upstream gradient / count, on the device
         d = ops.cross_entropy_bwd(logits, labels, lse, scale, ctx.ignore_index)
         if len(_PADDED_GRADS) > 64:
             _PADDED_GRADS.clear()  # entries nobody consumed (a caller that is not _LinearFn): never grow

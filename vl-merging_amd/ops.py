@@ -340,6 +340,88 @@ def cross_entropy_bwd(logits, labels, lse, scale, ignore_index=-100):
     return buf[:, :V]
 
 
+def l2norm_fwd(x):
+    """(y f32 [rows, D] = x / ||x||_2 per row, inv_norm f32 [rows]) of a bf16 / fp32 matrix with unit column stride."""
+    L.require_cuda(x)
+    rows, D = x.shape
+    if x.dtype not in (BF16, F32) or x.stride(1) != 1:
+        raise L.VlmError("l2norm: bf16 / fp32 [rows, D] with unit column stride")
+    y = torch.empty(rows, D, device=x.device, dtype=F32)
+    inv = torch.empty(rows, device=x.device, dtype=F32)
+    L.check(L.get_lib().vlm_l2norm_fwd(L.ptr(x), int(x.dtype == BF16), _ld(x), rows, D, L.ptr(y), L.ptr(inv), L.stream_ptr()), "vlm_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(g, y, inv, dtype):
+    """dx = (g - y (g . y)) * inv_norm in `dtype` (bf16 / fp32), g and y fp32 contiguous."""
+    L.require_cuda(g, y, inv)
+    rows, D = y.shape
+    if g.dtype != F32 or not g.is_contiguous() or g.shape != y.shape:
+        raise L.VlmError("l2norm_bwd: contiguous fp32 gradient of y's shape")
+    dx = torch.empty(rows, D, device=y.device, dtype=dtype)
+    L.check(L.get_lib().vlm_l2norm_bwd(L.ptr(g), L.ptr(y), L.ptr(inv), rows, D, L.ptr(dx), int(dtype == BF16), D, L.stream_ptr()), "vlm_l2norm_bwd")
+    return dx
+
+
+def contrastive(all_img, all_txt, B, log_scale):
+    """Symmetric contrastive loss of normalised features (include/vlm_hip.h vlm_contrastive): returns (out3 = [loss, d loss / d
+    log_scale, exp(log_scale)], logits [n, n], d_img [B, D], d_txt [B, D])."""
+    L.require_cuda(all_img, all_txt, log_scale)
+    n, D = all_img.shape
+    for t in (all_img, all_txt):
+        if t.dtype != F32 or not t.is_contiguous() or t.shape != (n, D):
+            raise L.VlmError("contrastive: contiguous fp32 [n, D] features")
+    if log_scale.dtype != F32 or log_scale.numel() != 1:
+        raise L.VlmError("contrastive: log_scale is one fp32 number")
+    dev = all_img.device
+    logits = torch.empty(n, n, device=dev, dtype=F32)
+    out3 = torch.empty(3, device=dev, dtype=F32)
+    d_img = torch.empty(B, D, device=dev, dtype=F32)
+    d_txt = torch.empty(B, D, device=dev, dtype=F32)
+    ws = torch.empty(max(1, L.get_lib().vlm_contrastive_ws_floats(n)), device=dev, dtype=F32)
+    L.check(L.get_lib().vlm_contrastive(L.ptr(all_img), L.ptr(all_txt), n, B, D, L.ptr(log_scale), L.ptr(logits), L.ptr(out3), L.ptr(d_img),
+                                        L.ptr(d_txt), L.ptr(ws), L.stream_ptr()), "vlm_contrastive")
+    return out3, logits, d_img, d_txt
+
+
+def small_cross_entropy(logits, labels):
+    """(loss f32 [1], dlogits f32 [rows, V]) of F.cross_entropy(logits, labels) (mean) for small V; logits bf16 / fp32, unit column stride."""
+    L.require_cuda(logits, labels)
+    rows, V = logits.shape
+    if logits.dtype not in (BF16, F32) or logits.stride(1) != 1 or labels.dtype != torch.int64 or not labels.is_contiguous() or labels.numel() != rows:
+        raise L.VlmError("small_cross_entropy: bf16 / fp32 logits [rows, V], contiguous int64 labels [rows]")
+    loss = torch.empty(1, device=logits.device, dtype=F32)
+    d = torch.empty(rows, V, device=logits.device, dtype=F32)
+    L.check(L.get_lib().vlm_small_cross_entropy(L.ptr(logits), int(logits.dtype == BF16), _ld(logits), rows, V, L.ptr(labels), L.ptr(loss),
+                                                L.ptr(d), L.stream_ptr()), "vlm_small_cross_entropy")
+    return loss, d
+
+
+def cross_entropy_reduce(loss_rows, labels, V, ignore_index=-100):
+    """out2 = [mean loss over the counted rows, 1 / count] (device)."""
+    L.require_cuda(loss_rows, labels)
+    out2 = torch.empty(2, device=loss_rows.device, dtype=F32)
+    L.check(L.get_lib().vlm_cross_entropy_reduce(L.ptr(loss_rows), L.ptr(labels), loss_rows.numel(), int(V), int(ignore_index), L.ptr(out2),
+                                                 L.stream_ptr()), "vlm_cross_entropy_reduce")
+    return out2
+
+
+def scale_by_scalar(tensors, scalar):
+    """[t * scalar for t in tensors] (fp32 contiguous, at most four) in ONE launch; `scalar` is a device tensor with one element."""
+    L.require_cuda(scalar, *tensors)
+    k = len(tensors)
+    if k == 0:
+        return []
+    if k > 4 or any(t.dtype != F32 or not t.is_contiguous() for t in tensors) or scalar.dtype != F32:
+        raise L.VlmError("scale_by_scalar: up to four contiguous fp32 tensors and an fp32 device scalar")
+    outs = [torch.empty_like(t) for t in tensors]
+    P = ctypes.c_void_p * k
+    I = ctypes.c_int * k
+    L.check(L.get_lib().vlm_scale_by_scalar(P(*[L.ptr(t) for t in tensors]), P(*[L.ptr(o) for o in outs]), I(*[t.numel() for t in tensors]), k,
+                                            L.ptr(scalar), L.stream_ptr()), "vlm_scale_by_scalar")
+    return outs
+
+
 def colsum(a, out):
     """out[n] += sum_m a[m,n]  (a bf16)."""
     L.require_cuda(a, out)

@@ -64,16 +64,51 @@ def compute_mlm(pl_module, batch):
             "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
 
 
-def _contrastive(image_features, text_features, logit_scale):
+def _others(t):
+    """The other ranks' rows of a feature matrix (no autograd), in rank order without this rank's: what _gather_first_own appends."""
+    world, rank = _world()
+    if world == 1:
+        return None
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t.detach().contiguous())
+    return torch.cat(gathered[:rank] + gathered[rank + 1:])
+
+
+def _contrastive_pair(image_features, text_features, log_scale_param):
+    """(loss, logits_per_image, logits_per_text, exp(scale)) of the symmetric contrastive cross-entropy (objectives.py:274-300):
+    own features first, the gathered ones behind them without gradient.  GPU: engine.contrastive_loss (two launches, forward
+    and gradient); otherwise the reference's torch formulation."""
+    if image_features.is_cuda and engine._FUSED_LOSS and log_scale_param.numel() == 1:
+        loss, li, scale = engine.contrastive_loss(image_features.float(), text_features.float(), log_scale_param,
+                                                  _others(image_features.float()), _others(text_features.float()))
+        return loss, li, li.t(), scale
+    logit_scale = log_scale_param.exp().mean()
     all_img = _gather_first_own(image_features)
     all_txt = _gather_first_own(text_features)
-    logits_per_image = logit_scale * all_img @ all_txt.t()
-    return logits_per_image, logits_per_image.t()
-
-
-def _sym_ce(li, lt):
+    li = logit_scale * all_img @ all_txt.t()
     gt = torch.arange(len(li), device=li.device)
-    return (F.cross_entropy(li.float(), gt) + F.cross_entropy(lt.float(), gt)) / 2, gt
+    return (F.cross_entropy(li.float(), gt) + F.cross_entropy(li.t().float(), gt)) / 2, li, li.t(), logit_scale
+
+
+def _itm_labels(bsz, device):
+    """(float, int64) labels of the ITM head: B positives then 2B negatives (objectives.py:187-190); built once per batch size."""
+    key = ("itm", bsz, str(device))
+    t = _ARANGE.get(key)
+    if t is None:
+        f = torch.cat([torch.ones(bsz, device=device), torch.zeros(2 * bsz, device=device)])
+        t = _ARANGE[key] = (f, f.long())
+    return t
+
+
+def _labels_arange(n, device):
+    key = (n, str(device))
+    t = _ARANGE.get(key)
+    if t is None:
+        t = _ARANGE[key] = torch.arange(n, device=device)
+    return t
+
+
+_ARANGE = {}
 
 
 def compute_ifm(pl_module, batch, aggregate=True):
@@ -82,14 +117,11 @@ def compute_ifm(pl_module, batch, aggregate=True):
     else:
         infer_imag = pl_module.infer_image(batch, mask_image=False)
         infer_text = pl_module.infer_text(batch, mask_text=False)
-    logit_scale = pl_module.logit_scale.exp().mean()
-    logit_vl_scale = pl_module.logit_vl_scale.exp().mean()
-    li, lt = _contrastive(infer_imag["cls_feats"], infer_text["cls_feats"], logit_scale)
-    lvi, lvt = _contrastive(infer_imag["cls_vlffn_feats"], infer_text["cls_vlffn_feats"], logit_vl_scale)
-    ifm_loss, gt = _sym_ce(li, lt)
-    ifm_vlffn_loss, _ = _sym_ce(lvi, lvt)
+    ifm_loss, li, lt, logit_scale = _contrastive_pair(infer_imag["cls_feats"], infer_text["cls_feats"], pl_module.logit_scale)
+    ifm_vlffn_loss, _, _, logit_vl_scale = _contrastive_pair(infer_imag["cls_vlffn_feats"], infer_text["cls_vlffn_feats"],
+                                                             pl_module.logit_vl_scale)
     total = (pl_module.hparams.config["ifm_weight"] * ifm_loss + ifm_vlffn_loss) * 0.5
-    return {"ifm_loss": total, "ifm_i2t_logits": li, "ifm_t2i_logits": lt, "ifm_labels": gt,
+    return {"ifm_loss": total, "ifm_i2t_logits": li, "ifm_t2i_logits": lt, "ifm_labels": _labels_arange(len(li), li.device),
             "ifm_logit_scale": logit_scale, "ifm_logit_vl_scale": logit_vl_scale}
 
 
@@ -99,10 +131,8 @@ def compute_irtr(pl_module, batch, aggregate=True):
     else:
         infer_imag = pl_module.infer_image_ft(batch, mask_image=False)
         infer_text = pl_module.infer_text_ft(batch, mask_text=False)
-    logit_scale = pl_module.logit_scale.exp().mean()
-    li, lt = _contrastive(infer_imag["cls_feats"], infer_text["cls_feats"], logit_scale)
-    loss, gt = _sym_ce(li, lt)
-    return {"irtr_loss": loss, "irtr_i2t_logits": li, "irtr_t2i_logits": lt, "irtr_labels": gt,
+    loss, li, lt, logit_scale = _contrastive_pair(infer_imag["cls_feats"], infer_text["cls_feats"], pl_module.logit_scale)
+    return {"irtr_loss": loss, "irtr_i2t_logits": li, "irtr_t2i_logits": lt, "irtr_labels": _labels_arange(len(li), li.device),
             "irtr_logit_scale": logit_scale}
 
 
@@ -199,9 +229,9 @@ def compute_mlm_itm_fused(pl_module, batch, sim_i2t, sim_t2i):
     mlm_logits = pl_module.mlm_score(infer["text_feats"][:bsz])
     mlm_labels = batch["text_labels_mlm"]
     mlm_loss = engine.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), ignore_index=-100)
-    itm_labels = torch.cat([torch.ones(bsz, device=img.device), torch.zeros(2 * bsz, device=img.device)])
+    itm_labels, itm_long = _itm_labels(bsz, img.device)
     itm_logits = pl_module.itm_score(infer["cls_feats"][bsz:])
-    itm_loss = F.cross_entropy(itm_logits.float(), itm_labels.long())
+    itm_loss = engine.small_cross_entropy(itm_logits, itm_long)
     return {"mlm_loss": mlm_loss * pl_module.hparams.config["vl_mlm_weight"], "mlm_logits": mlm_logits,
             "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"], "itm_loss": itm_loss,
             "itm_logits": itm_logits, "itm_labels": itm_labels}
@@ -213,7 +243,7 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
     host round trip."""
     bsz = batch["text_ids_mlm"].size(0)
     dev = batch["text_ids"].device
-    itm_labels = torch.cat([torch.ones(bsz, device=dev), torch.zeros(2 * bsz, device=dev)])
+    itm_labels, itm_long = _itm_labels(bsz, dev)
     infer_pos = pl_module.infer(batch, mask_text=False, mask_image=False)
     with torch.no_grad():
         all_text_ids = _gather_cat(infer_pos["text_ids"])
@@ -236,7 +266,7 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
     infer_text_neg = pl_module.infer(batch_text_neg, mask_text=False, mask_image=False)
     all_cls_feats = torch.cat([infer_pos["cls_feats"], infer_imags_neg["cls_feats"], infer_text_neg["cls_feats"]], dim=0)
     itm_logits = pl_module.itm_score(all_cls_feats)
-    itm_loss = F.cross_entropy(itm_logits.float(), itm_labels.long())
+    itm_loss = engine.small_cross_entropy(itm_logits, itm_long)
     return {"itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
 
 
