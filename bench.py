@@ -105,7 +105,7 @@ GEMM_KERNELS = ("vlm_gemm_big_kernel", "vlm_gemm_bigT_kernel", "vlm_gemm_kernel"
 GEMM_HELPERS = ("splitk_reduce_kernel",)  # second launch of a wgrad call: its bytes count, its launches do not
 
 
-ATTN_KERNELS = {"fwd": ("attn_fwd2_kernel",), "bwd": ("attn_bwd_dq_kernel", "attn_bwd_dkvb_kernel", "attn_dbias_fold_kernel")}
+ATTN_KERNELS = {"fwd": ("attn_fwd2_kernel",), "bwd": ("attn_bwd_dq2_kernel", "attn_bwd_dkvb_kernel", "attn_dbias_fold_kernel")}
 # what a default pretrain step launches from the attention / GEMM families: a committed PMC file that lacks one of them was
 # made from another build of the kernels and must not vouch for this run
 EXPECTED_IN_PROFILE = GEMM_KERNELS + GEMM_HELPERS + ATTN_KERNELS["fwd"] + ATTN_KERNELS["bwd"]

@@ -37,7 +37,7 @@ def test_bench_json_contract():
         a = ra[kind]
         assert a["bound"] == "mfma" and a["peak"] == 2500.0 and a["unit"] == "TFLOP/s" and a["launches"] > 0, a
         assert abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-9 and 0.02 < a["frac"] < 1.0, a
-    assert "attn_fwd2_kernel" in ra["fwd"]["kernel"] and "attn_bwd_dq_kernel" in ra["bwd"]["kernel"]
+    assert "attn_fwd2_kernel" in ra["fwd"]["kernel"] and "attn_bwd_dq2_kernel" in ra["bwd"]["kernel"]
     m = d["merge"]
     assert m["roofline"]["bound"] == "hbm" and m["algorithmic_bytes"] == 1077239808 and 0.3 < m["roofline"]["frac"] < 1.0
     # parity gate beside the number: the buffer the merge leg has just timed, against the CPU oracle on layers 0 and 11

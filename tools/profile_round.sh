@@ -1,13 +1,15 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel-trace stats + three separate PMC passes over the SAME bench command, condensed into
 # gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: tools/profile_round.sh r02
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export VLM_BENCH_SETUP_STEPS=0  # the traces cover exactly warm-up + timed steps (6 steps), as in rounds 1-4
-CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary"
+# (--no-merge: the traces cover the training steps only -- round 5's also held the merge bench's set-up, ~770 copyBuffer and ~850
+# elementwise launches that are not part of a step; the merge kernel keeps its own line through the PMC passes below)
+CMD="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary --no-merge"
 # Two kernel traces of the same command.  (1) VLM_WGRAD_STREAM=0: every launch alone on the chip -- the per-kernel durations
 # that bench.py's roofline figure (whose bracketed steps also run without the side stream) has to agree with; the PMC passes
 # below run the same way.  (2) the default schedule (weight-gradient GEMMs on a second stream): what the timed steps execute.
@@ -30,8 +32,8 @@ python3 tools/prof_summary.py $OUT/trace_moe/run_kernel_stats.csv $OUT/${TAG}_tr
 python3 tools/prof_summary.py $OUT/trace_f64/run_kernel_stats.csv $OUT/${TAG}_f64_leg_kernel_stats.csv "tools/bench_f64_leg.py (RegMean at base size x2, Gram capture D = 768 / 3072 at 54 296 rows x4) under rocprofv3 --kernel-trace --stats"
 grep -E "^(regmean|gram capture)" $OUT/trace_f64.log > $OUT/${TAG}_f64_leg_log.txt
 grep -E '^\{"metric' $OUT/trace_moe.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_all_moe_under_trace.txt
-python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "VLM_WGRAD_STREAM=0 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps + merge bench; every launch alone on the chip (the durations the roofline figure agrees with)"
-python3 tools/prof_summary.py $OUT/trace_overlap/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_overlap_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps + merge bench; default schedule (weight-gradient GEMMs on a second stream: overlapping kernels stretch each other's durations)"
+python3 tools/prof_summary.py $OUT/trace/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv "VLM_WGRAD_STREAM=0 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps; every launch alone on the chip (the durations the roofline figure agrees with)"
+python3 tools/prof_summary.py $OUT/trace_overlap/run_kernel_stats.csv $OUT/${TAG}_train_ufo384_b22_overlap_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-calibrate --no-secondary under rocprofv3 --kernel-trace --stats; 6 steps; default schedule (weight-gradient GEMMs on a second stream: overlapping kernels stretch each other's durations)"
 grep -E '^\{"metric' $OUT/trace_overlap.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_under_trace_overlap.txt
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/traffic.txt
 python3 - <<PY
@@ -55,7 +57,7 @@ try:
     for r in csv.DictReader(open("$OUT/trace/run_kernel_stats.csv")):
         nm = re.sub(r"[<(].*", "", r["Name"]).replace("void ", "")
         t[nm] = t.get(nm, 0.0) + float(r["TotalDurationNs"]) / 6e6  # ms per step
-    fwd = t.get("attn_fwd_kernel", 0.0)
+    fwd = sum(v for k, v in t.items() if k.startswith("attn_fwd"))
     bwd = sum(v for k, v in t.items() if k.startswith("attn_bwd_") or k == "attn_dbias_fold_kernel")
     alg = {"fwd_tflop_per_step": 1.427, "fwd_ms_per_step": fwd, "fwd_tflops": 1.427 / fwd * 1e3 if fwd else None,
            "fwd_frac_of_2500": 1.427 / fwd * 1e3 / 2500 if fwd else None,
@@ -69,3 +71,17 @@ print(json.dumps(res, indent=1))
 PY
 grep -E '^\{"metric' $OUT/trace.log | tail -1 | cut -c1-600 > $OUT/${TAG}_bench_line_under_trace.txt
 head -25 $OUT/${TAG}_train_ufo384_b22_kernel_stats.csv
+# launches of one step by origin (this library / torch-native / copies), and the attention kernels standalone: the hand-placed
+# streams against the round-3 kernels, with the in-kernel clock (s_memtime / s_memrealtime stamps of the -DVLM_DIAG harness)
+python3 tools/count_launches.py > $OUT/${TAG}_launches_per_step.txt 2>&1
+{
+  for args in "88 0 1 0" "22 0 1 0"; do for v in 0 1; do
+    echo -n "forward  hand-placed=$v  B mode bias = $args: "; VLM_ATT_FWD2=$v bash tools/scratch/trace_attn.sh attn_bench $args 2>&1 | grep -E "attn_fwd" | awk '{print $1, $(NF-1), $NF}'
+  done; done
+  for args in "88 0 1 1 1" "22 0 1 1 1"; do for v in 0 1; do
+    echo -n "backward hand-placed dQ=$v  $args: "; VLM_ATT_DQ2=$v bash tools/scratch/trace_attn.sh attn_bench $args 2>&1 | grep -E "attn_bwd" | awk '{printf "%s %s us; ", $1, $(NF-1)} END {print ""}'
+  done; done
+  for v in 0 1; do echo "stamps forward hand-placed=$v:"; VLM_ATT_FWD2=$v tools/scratch/attn_bench_diag 88 0 1 0 2>&1 | grep -E "wave 0 clock"; done
+  for v in 0 1; do echo "stamps backward (dQ kernel) hand-placed=$v:"; VLM_ATT_DQ2=$v tools/scratch/attn_bench_diag 88 0 1 1 1 2>&1 | grep -E "wave 0 clock"; done
+} > $OUT/${TAG}_attention_harness.txt 2>&1
+cat $OUT/${TAG}_attention_harness.txt
