@@ -33,7 +33,7 @@ extern "C" {
 #define VLM_ERR_WORKSPACE (-3)
 #define VLM_ERR_UNSUPPORTED (-4)
 
-#define VLM_ABI_VERSION 9
+#define VLM_ABI_VERSION 10
 int vlm_abi_version(void);
 /* Number of compute units grid sizing and split-K slice counts plan for, or negative error: the current device's count,
  * or the smaller budget set by VLM_GEMM_CUS=n (environment, read once) / vlm_set_cu_budget(n) -- room for RCCL's kernels
@@ -294,6 +294,58 @@ int vlm_small_cross_entropy(const void* logits, int is_bf16, int ld, int rows, i
                             void* stream);
 int vlm_cross_entropy_reduce(const float* loss_rows, const int64_t* labels, int rows, int V, int64_t ignore_index, float* out2, void* stream);
 int vlm_scale_by_scalar(const float* const* in, float* const* out, const int* n, int count, const float* scalar_dev, void* stream);
+
+/* Round 6: the two ends of a pass as single launches (csrc/frontops.hip).
+ *   vlm_text_rows_fwd: BertEmbeddings.forward + the modality type row (reference vilt_module.py:51-63, :1111-1113):
+ *        out[r] = dropout(LayerNorm(word[ids[r]] + add0; gamma, beta, eps)) + add1, fp32 rows (leading dimension ld_out: the rows of
+ *        the pass's token matrix), stats[r] = (mean, rstd).  u: optional fp32 [n, D]; an element is kept where u >= p and scaled by
+ *        `scale` (nn.Dropout(p): scale = 1 / (1 - p)).  D % 4 == 0, D <= 1024.
+ *   vlm_text_rows_bwd: g = gradient of those rows; adds into d_word[ids[r]] (rows with ids == padding_idx excepted: nn.Embedding's
+ *        padding_idx), d_add1, d_beta, d_gamma, d_add0 (each may be null).  ws: vlm_text_rows_bwd_ws_floats(D) floats.
+ *   vlm_image_rows_prep: out2[0] = conv_bias + type_row (the patch-embed GEMM's bias), out2[1] = cls + type_row (the lead row) --
+ *        visual_embed's cls concat + token_type_embeddings add, vision_transformer.py:952-991, vilt_module.py:1114-1117.
+ *   vlm_image_lead_rows: x[b * rows] = lead for b < B.
+ *   vlm_image_rows_bwd: g fp32 [B * rows, D] -> g16 bf16 (lead rows zero: the wgrad GEMM's operand); d_bias += column sums over the
+ *        patch rows, d_type_row += over all rows, d_cls += over the lead rows.  ws: vlm_image_rows_bwd_ws_floats(D) floats.
+ *   vlm_tanh_fwd: y fp32 = tanh(x bf16) (Pooler, heads.py:8-19).
+ *   vlm_act_bwd: dy bf16 [M, Np] (columns >= N zero) = g * act'(.): mode 0 exact GELU from the saved bf16 pre-activation (MLM
+ *        transform, heads.py:36-46), mode 1 tanh from the saved fp32 output, mode 2 no activation (cast + padding; saved unused).
+ *   vlm_colsum_small: out[c] += sum_r a[r][c], N <= 64 columns (ITMHead.fc bias gradient: N = 2).
+ *   vlm_sample_negatives: idx[0][i] ~ softmax(sim_a[i, :]) without entry i, idx[1][i] likewise from sim_b (objectives.py:176-229:
+ *        F.softmax, fill_diagonal_(0), torch.multinomial(., 1)), inverse CDF on the uniforms u[2][B]; strides in elements (logits_per_text
+ *        is the transposed view of logits_per_image).
+ *   vlm_weighted_sum: out[0] = sum_k weights[k] * terms[k][0] (device scalars, count <= 8): the loss sum of training_step. */
+int vlm_text_rows_fwd(const int64_t* ids, int n, const float* word, int ld_word, const float* add0, const float* gamma, const float* beta,
+                      float eps, const float* u, float p, float scale, const float* add1, float* out, int ld_out, float* stats, int D,
+                      void* stream);
+size_t vlm_text_rows_bwd_ws_floats(int D);
+int vlm_text_rows_bwd(const float* g, int ld_g, const int64_t* ids, int n, const float* word, int ld_word, const float* add0,
+                      const float* gamma, const float* stats, const float* u, float p, float scale, int D, float* d_word,
+                      int64_t padding_idx, float* d_add1, float* d_beta, float* d_gamma, float* d_add0, float* ws, void* stream);
+int vlm_image_rows_prep(const float* conv_bias, const float* type_row, const float* cls, int D, float* out2, void* stream);
+int vlm_image_lead_rows(float* x, int ld_x, int B, int rows, int D, const float* lead, void* stream);
+size_t vlm_image_rows_bwd_ws_floats(int D);
+int vlm_image_rows_bwd(const float* g, int ld_g, int B, int rows, int D, void* g16, float* d_bias, float* d_type_row, float* d_cls, float* ws,
+                       void* stream);
+int vlm_tanh_fwd(const void* x_bf16, int ld_x, int M, int N, float* y, void* stream);
+int vlm_act_bwd(const void* g, int g_is_f32, int ld_g, const void* saved, int ld_saved, int mode, int M, int N, int Np, void* dy_bf16,
+                void* stream);
+int vlm_colsum_small(const void* a_bf16, int lda, int M, int N, float* out, void* stream);
+int vlm_sample_negatives(const float* sim_a, int a_row_stride, int a_col_stride, const float* sim_b, int b_row_stride, int b_col_stride, int B,
+                         int n, const float* u, int64_t* idx, void* stream);
+int vlm_weighted_sum(const float* const* terms, const float* weights, int count, float* out, void* stream);
+
+/* vlm_scatter_rows: dx [R, D] (bf16 or fp32) = sum over the sources of g_k [count_k, D] placed at rows first_row + j * row_step, zero
+ *        elsewhere -- the gradient of the row views a pass's result exposes (text_feats = x[:B T], the cls rows x[b T], a leading block
+ *        of samples: vilt_module.py:1136-1156, objectives.py:97 `infer["text_feats"]`, heads.py:17 `hidden_states[:, 0]`) in one pass
+ *        instead of autograd's zero fill + strided copy per view and an addition per extra view.  D % 4 == 0, at most 4 sources. */
+typedef struct {
+  const void* g; /* [count, D] rows, bf16 or fp32 */
+  int g_is_f32;
+  int ld;        /* row stride of g in elements */
+  int first_row, row_step, count;
+} vlm_scatter_src_t;
+int vlm_scatter_rows(void* dx, int dx_is_f32, int ld_dx, int R, int D, const vlm_scatter_src_t* src, int n_src, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flat-buffer elementwise kernels.

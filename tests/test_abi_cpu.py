@@ -25,7 +25,7 @@ def test_header_symbols_exported(pkg):
     for s in syms:
         assert hasattr(lib, s), "library does not export " + s
         assert s in L.SIGNATURES, "ctypes binding lacks " + s
-    assert lib.vlm_abi_version() == 9
+    assert lib.vlm_abi_version() == 10
 
 
 def test_cpu_tensors_are_rejected(pkg):

@@ -1025,3 +1025,160 @@ def test_cross_entropy_reduce_and_scale_by_scalar(ops):
     sc = torch.tensor([0.37], device="cuda")
     oa, ob, oc = ops.scale_by_scalar([a, b, c], sc)
     assert torch.equal(oa, a * sc) and torch.equal(ob, b * sc) and torch.equal(oc, c * sc)
+
+
+# ---- round 6: the two ends of a pass (csrc/frontops.hip) against torch --------------------------------------------------------
+@pytest.mark.parametrize("B,T,D,V,drop", [(4, 40, 768, 3000, True), (3, 7, 192, 50, False), (22, 40, 768, 30522, True), (1, 1, 64, 9, True)])
+def test_text_rows_fwd_bwd_match_torch(ops, B, T, D, V, drop):
+    """vlm_text_rows_fwd / _bwd against BertEmbeddings.forward + the modality type row written with torch ops (reference
+    vilt_module.py:51-63, :1111-1113): gather, + bert type 0, LayerNorm(1e-12), dropout with a given keep mask, + vilt type 0."""
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 100 + T)
+    n = B * T
+    ids = torch.randint(0, V, (n,), device="cuda", generator=g)
+    ids[::5] = 0  # padding rows: looked up like any row, no gradient
+    word = torch.randn(V, D, device="cuda", generator=g)
+    bt = torch.randn(D, device="cuda", generator=g) * 0.1
+    gamma = 1 + 0.1 * torch.randn(D, device="cuda", generator=g); beta = 0.1 * torch.randn(D, device="cuda", generator=g)
+    vt = torch.randn(D, device="cuda", generator=g) * 0.1
+    u = torch.rand(n, D, device="cuda", generator=g) if drop else None
+    p, scale = (0.1, 1 / 0.9) if drop else (0.0, 1.0)
+    x = torch.zeros(n + 5, D, device="cuda")
+    stats = ops.text_rows_fwd(ids, word, bt, gamma, beta, 1e-12, x[:n], u, p, scale, add1=vt)
+    wr, btr, gr, br, vtr = [t.clone().requires_grad_(True) for t in (word, bt, gamma, beta, vt)]
+    e = torch.nn.functional.embedding(ids, wr, padding_idx=0) + btr
+    y = torch.nn.functional.layer_norm(e, (D,), gr, br, 1e-12)
+    if drop:
+        y = y * (u >= p).float() * scale
+    ref = y + vtr
+    assert_close(x[:n], ref.detach(), 1e-5, 2e-5, "text rows")
+    assert float(x[n:].abs().max()) == 0.0
+    gy = torch.randn(n + 5, D, device="cuda", generator=g)
+    ref.backward(gy[:n])
+    dword = torch.full((V, D), 0.5, device="cuda"); d1 = torch.full((D,), 1.0, device="cuda"); db = torch.full((D,), 2.0, device="cuda")
+    dg = torch.full((D,), 3.0, device="cuda"); d0 = torch.full((D,), 4.0, device="cuda")
+    ops.text_rows_bwd(gy[:n], ids, word, bt, gamma, stats, u, p, scale, dword, 0, d1, db, dg, d0)
+    torch.cuda.synchronize()
+    for got, want, base, what in ((dword, wr.grad, 0.5, "d word"), (d1, vtr.grad, 1.0, "d type row"), (db, br.grad, 2.0, "d beta"),
+                                  (dg, gr.grad, 3.0, "d gamma"), (d0, btr.grad, 4.0, "d bert type")):
+        assert_close(got - base, want, 2e-4, 2e-4 * float(want.abs().max()) + 1e-5, what)
+    assert float((dword[0] - 0.5).abs().max()) == 0.0  # the padding row
+
+
+@pytest.mark.parametrize("B,rows,D", [(22, 577, 768), (3, 10, 192), (1, 2, 64), (88, 577, 768)])
+def test_image_rows_kernels_match_torch(ops, B, rows, D):
+    g = torch.Generator(device="cuda"); g.manual_seed(B + rows)
+    cb = torch.randn(D, device="cuda", generator=g); tt = torch.randn(D, device="cuda", generator=g); cls = torch.randn(1, 1, D, device="cuda", generator=g)
+    pre = ops.image_rows_prep(cb, tt, cls)
+    assert torch.equal(pre[0], cb + tt) and torch.equal(pre[1], cls.view(-1) + tt)
+    assert torch.equal(ops.image_rows_prep(None, tt, cls)[0], tt)
+    x = torch.randn(B * rows + 3, D, device="cuda", generator=g)
+    keep = x.clone()
+    ops.image_lead_rows(x[3:], B, rows, pre[1])
+    want = keep.clone(); want[3:].view(B, rows, D)[:, 0] = pre[1]
+    assert torch.equal(x, want)
+    gy = torch.randn(B * rows + 3, D, device="cuda", generator=g)
+    dbias = torch.full((D,), 1.0, device="cuda"); dtt = torch.full((D,), 2.0, device="cuda"); dcls = torch.full((1, 1, D), 3.0, device="cuda")
+    g16 = ops.image_rows_bwd(gy[3:], B, rows, dbias, dtt, dcls)
+    gv = gy[3:].view(B, rows, D)
+    ref16 = gv.clone(); ref16[:, 0] = 0
+    assert torch.equal(g16.view(B, rows, D), ref16.to(torch.bfloat16))
+    lead = gv[:, 0].double().sum(0); patch = gv[:, 1:].double().sum((0, 1))
+    tol = 1e-5 * float(gv.abs().max()) * (B * rows) ** 0.5 + 1e-6
+    assert_close(dbias - 1.0, patch.float(), 1e-5, tol, "d conv bias")
+    assert_close(dtt - 2.0, (patch + lead).float(), 1e-5, tol, "d type row")
+    assert_close(dcls.view(-1) - 3.0, lead.float(), 1e-5, tol, "d cls")
+    g16b = ops.image_rows_bwd(gy[3:], B, rows, None, None, None)  # nothing wanted: the cast alone
+    assert torch.equal(g16b, g16)
+
+
+@pytest.mark.parametrize("M,N,Np", [(66, 2, 64), (22, 768, 768), (880, 768, 768), (5, 30, 64)])
+@pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
+def test_head_activation_kernels_match_torch(ops, M, N, Np, gdtype):
+    g = torch.Generator(device="cuda"); g.manual_seed(M + N)
+    pre = (torch.randn(M, Np, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    gy = torch.randn(M, N, device="cuda", generator=g).to(gdtype)
+    y = ops.tanh_fwd(pre[:, :N])
+    assert_close(y, torch.tanh(pre[:, :N].float()), 1e-6, 1e-6, "tanh")
+    h = pre[:, :N].float().requires_grad_(True)
+    (gh,) = torch.autograd.grad(torch.nn.functional.gelu(h), h, gy.float())
+    for mode, saved, want in ((ops.ACT_BWD_GELU, pre[:, :N], gh), (ops.ACT_BWD_TANH, y, gy.float() * (1 - y * y)), (ops.ACT_BWD_NONE, None, gy.float())):
+        dy = ops.act_bwd(gy, saved, mode, Np)
+        assert dy.shape == (M, Np) and dy.dtype == torch.bfloat16
+        assert_close(dy[:, :N], want, 2 ** -7, 1e-6, "act_bwd mode %d" % mode)
+        if Np > N:
+            assert float(dy[:, N:].abs().max()) == 0.0
+    if N <= 64:
+        out = torch.full((N,), 1.5, device="cuda")
+        a = gy.to(torch.bfloat16)
+        ops.colsum_small(a, out)
+        assert_close(out - 1.5, a.float().sum(0), 1e-5, 1e-4, "colsum_small")
+
+
+def test_sample_negatives_distribution_and_edge_cases(ops):
+    """vlm_sample_negatives against F.softmax + fill_diagonal_(0) + multinomial's DISTRIBUTION (objectives.py:197-215): never the
+    own index, frequencies within 5 sigma of the weights over 4 000 draws, a forced draw at n = 2, a transposed second matrix."""
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    B, n = 6, 20
+    sim = torch.randn(n, n, device="cuda", generator=g) * 2
+    a, b = sim[:B], sim.t()[:B]
+    draws = 4000
+    counts = torch.zeros(2, B, n, device="cuda")
+    for _ in range(draws // 50):
+        for _ in range(50):
+            idx = ops.sample_negatives(a, b, B, torch.rand(2, B, device="cuda", generator=g))
+            counts.scatter_add_(2, idx.unsqueeze(-1), torch.ones(2, B, 1, device="cuda"))
+    for d, m in ((0, a), (1, b)):
+        w = torch.softmax(m.float(), dim=1)
+        w[torch.arange(B), torch.arange(B)] = 0
+        w = w / w.sum(1, keepdim=True)
+        assert float(counts[d][torch.arange(B), torch.arange(B)].max()) == 0.0
+        sigma = (w * (1 - w) / draws).sqrt()
+        assert bool(((counts[d] / draws - w).abs() <= 5 * sigma + 1e-3).all())
+    two = torch.randn(2, 2, device="cuda", generator=g)
+    for _ in range(5):
+        idx = ops.sample_negatives(two, two.t(), 2, torch.rand(2, 2, device="cuda", generator=g))
+        assert idx.tolist() == [[1, 0], [1, 0]]
+    for uval in (0.0, 0.99999994):  # the ends of the uniform range pick the first / last candidate with weight
+        idx = ops.sample_negatives(a, b, B, torch.full((2, B), uval, device="cuda"))
+        assert bool((idx != torch.arange(B, device="cuda")).all()) and bool(((idx >= 0) & (idx < n)).all())
+
+
+def test_weighted_sum_matches_torch(ops):
+    t = [torch.tensor(v, device="cuda") for v in (1.5, -2.25, 8.0)]
+    out = ops.weighted_sum(t, [0.5, 2.0, 1.0])
+    assert abs(float(out) - (0.75 - 4.5 + 8.0)) < 1e-6 and out.dim() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,I,D", [(4, 40, 577, 768), (2, 5, 3, 64), (3, 8, 0, 192), (2, 0, 7, 64)])
+def test_feature_views_gradient_matches_autograd_views(pkg, ops, B, T, I, D, dtype):
+    """engine.feature_views / row_range against the plain views they replace: same values (they ARE views), same gradient of x
+    whichever subset of the views is used downstream."""
+    engine = importlib.import_module("vl_merging_amd.engine")
+    g = torch.Generator(device="cuda"); g.manual_seed(B + T + I)
+    x0 = torch.randn(B * T + B * I, D, device="cuda", generator=g).to(dtype)
+    w = [torch.randn(s, device="cuda", generator=g).to(dtype) for s in ((B, T, D), (B, I, D), (B, D), (B, D))]
+    for used in ((0, 1, 2, 3), (2, 3), (0, 2), (3,), (1,)):
+        xa = x0.clone().requires_grad_(True)
+        xb = x0.clone().requires_grad_(True)
+        va = engine.feature_views(xa, B, T, I)
+        nt = B * T
+        tb, ib = xb[:nt].view(B, T, D), xb[nt:].view(B, I, D)
+        vb = (tb, ib, tb[:, 0] if T else xb[:0], ib[:, 0] if I else xb[:0])
+        for k in range(4):
+            assert torch.equal(va[k], vb[k])
+        la = sum((va[k].float() * w[k].float()).sum() for k in used if va[k].numel())
+        lb = sum((vb[k].float() * w[k].float()).sum() for k in used if vb[k].numel())
+        if not torch.is_tensor(la):
+            continue
+        la.backward(); lb.backward()
+        tol = 0.0 if dtype == torch.float32 else 2 ** -7
+        assert_close(xa.grad, xb.grad, tol, 1e-6, "feature_views grad %s" % (used,))
+    ta = x0.view(-1, D)[: B * 2].view(B, 2, D).clone().requires_grad_(True) if (B * T + B * I) >= 2 * B else None
+    if ta is not None:
+        tb_ = ta.detach().clone().requires_grad_(True)
+        ra, rb = engine.row_range(ta, 1, None), tb_[1:]
+        assert torch.equal(ra, rb)
+        gg = torch.randn(ra.shape, device="cuda", generator=g).to(dtype)
+        ra.backward(gg); rb.backward(gg)
+        assert torch.equal(ta.grad, tb_.grad)

@@ -671,12 +671,15 @@ def test_zero_gradient_is_not_no_gradient(mods, golden_dir):
     assert torch.equal(b.detach(), b0)                   # bias: no decay group, zero update
 
 
+@pytest.mark.parametrize("front", ["fused", "stock"])
 @pytest.mark.parametrize("arch", ["ufo", "all_moe"])
-def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
+def test_train_mode_step_with_injected_masks(mods, golden_dir, arch, front):
     """TRAIN mode (DropPath + text-embedding dropout live) against the REFERENCE's train-mode step on the same injected
     masks (tests/golden/train_tiny_*.npz, oracle/detweights.py::det_keep / det_dropout_mask).  The engine runs its
     shipped pass structure (pair pass + fused 4B pass), so the masks are re-keyed from the reference's
-    (pass tag, site, sample) to the engine's (pass, site, stream, sample)."""
+    (pass tag, site, sample) to the engine's (pass, site, stream, sample).  front = "fused": the text rows come from the one-launch
+    front end (csrc/frontops.hip) with the keep mask injected through `dropout_source`; "stock": the torch module path with a
+    replaced dropout module (what a caller with a custom dropout gets)."""
     from oracle.detweights import det_keep, det_dropout_mask
     gold = np.load(os.path.join(golden_dir, f"train_tiny_{arch}.npz"))
     model = build(mods, arch, f"tiny_{arch}", golden_dir, {"itm": 1, "mlm": 1, "ifm": 1}, train=True)
@@ -715,7 +718,17 @@ def test_train_mode_step_with_injected_masks(mods, golden_dir, arch):
             m = torch.stack([torch.from_numpy(det_dropout_mask(tags[b], b % B, T, D, 1.0 - p)) for b in range(n)])
             return x * m.to(x.device) / (1.0 - p)
 
-    model.text_embeddings.dropout = DetDropout()
+    def keep_mask(n, T_, D_):
+        tags = ["txt"] * n if n == B else [t for t in ("mlm", "pos", "negimg", "negtxt") for _ in range(B)]
+        calls.append(n)
+        return torch.stack([torch.from_numpy(det_dropout_mask(tags[b], b % B, T_, D_, 1.0 - p)) for b in range(n)])
+
+    if front == "fused":
+        model.text_embeddings.dropout_source = keep_mask
+        assert model._text_spec(torch.zeros(B, T, dtype=torch.int64, device="cuda")) is not None
+        calls.clear()
+    else:
+        model.text_embeddings.dropout = DetDropout()
     batch = gpu_batch(det_batch(2, 224, 40, 1024, seed=1234))
     model.zero_grad()
     mods[1].vilt_utils.set_task(model)

@@ -44,7 +44,8 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 OURS = ("vlm_", "attn_", "ln_", "scale_bwd", "colsum", "colreduce", "adamw", "cast_kernel", "im2col", "embedding_bwd", "bias_dense",
         "transpose_tiles", "droppath", "splitk", "merge", "l2norm", "scale_by_scalar", "contrastive", "small_ce", "ce_reduce",
-        "cross_entropy", "layerscale", "gram", "potrf", "trsm")
+        "cross_entropy", "layerscale", "gram", "potrf", "trsm", "text_rows", "image_rows", "image_lead", "fold_parts", "tanh_fwd", "act_bwd",
+        "sample_negatives", "weighted_sum", "scatter_rows")
 cnt, tim = collections.Counter(), collections.Counter()
 names = collections.Counter()
 for e in prof.events():

@@ -30,9 +30,10 @@ class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        if any(x in name for x in ("aten.view", "aten._unsafe_view", "aten.t.", "aten.transpose", "aten.expand", "aten.detach", "aten.alias", "aten.slice", "aten.select", "aten.unsqueeze", "aten.squeeze", "aten.permute", "aten.as_strided", "aten.empty", "aten.reshape", "aten.unbind", "aten.split", "aten.is_", "aten.sym_", "aten._local_scalar", "aten.lift_fresh", "prim.")):
+        if "backward" not in name and any(x in name for x in ("aten.view", "aten._unsafe_view", "aten.t.", "aten.transpose", "aten.expand", "aten.detach", "aten.alias", "aten.slice", "aten.select", "aten.unsqueeze", "aten.squeeze", "aten.permute", "aten.as_strided", "aten.empty", "aten.reshape", "aten.unbind", "aten.split", "aten.record_stream", "aten.new_empty", "aten.is_", "aten.sym_", "aten._local_scalar", "aten.lift_fresh", "prim.")):
             return out
         where = "(autograd engine)"
+        chain = []
         for fr in reversed(traceback.extract_stack()):
             if ("vl-merging_amd" in fr.filename or "vl_merging_amd" in fr.filename) :
                 where = "%s:%d %s" % (fr.filename.split("/")[-1], fr.lineno, fr.name); break
@@ -44,6 +45,6 @@ torch.cuda.synchronize()
 by_line = collections.Counter()
 for (w, n), c in agg.items(): by_line[w] += c
 print("dispatched non-view aten ops in one step: %d" % sum(agg.values()))
-for w, c in by_line.most_common(40):
-    ops_ = ", ".join("%s x%d" % (n, k) for (ww, n), k in sorted(agg.items(), key=lambda kv: -kv[1]) if ww == w)[:150]
+for w, c in by_line.most_common():
+    ops_ = ", ".join("%s x%d" % (n, k) for (ww, n), k in sorted(agg.items(), key=lambda kv: -kv[1]) if ww == w)[:400]
     print("%4d  %-52s %s" % (c, w, ops_))

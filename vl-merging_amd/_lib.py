@@ -28,6 +28,12 @@ class MergeJob(ctypes.Structure):
     ]
 
 
+class ScatterSrc(ctypes.Structure):
+    """vlm_scatter_src_t of include/vlm_hip.h."""
+    _fields_ = [("g", c_void_p), ("g_is_f32", ctypes.c_int32), ("ld", ctypes.c_int32), ("first_row", ctypes.c_int32),
+                ("row_step", ctypes.c_int32), ("count", ctypes.c_int32)]
+
+
 class Epilogue(ctypes.Structure):
     _fields_ = [
         ("bias", c_void_p), ("col_scale", c_void_p), ("row_scale", c_void_p), ("residual", c_void_p),
@@ -157,6 +163,21 @@ SIGNATURES = {
     "vlm_small_cross_entropy": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlm_cross_entropy_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     "vlm_scale_by_scalar": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p, c_void_p]),
+    "vlm_text_rows_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_float,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "vlm_text_rows_bwd_ws_floats": (c_size_t, [c_int]),
+    "vlm_text_rows_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                  c_int, c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlm_image_rows_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vlm_image_lead_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_image_rows_bwd_ws_floats": (c_size_t, [c_int]),
+    "vlm_image_rows_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlm_tanh_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_act_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_colsum_small": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlm_sample_negatives": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_weighted_sum": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_float), c_int, c_void_p, c_void_p]),
+    "vlm_scatter_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "vlm_cast_f32_bf16": (c_int, [c_void_p, c_void_p, c_u64, c_void_p]),
     "vlm_embedding_bwd": (c_int, [c_void_p, c_int, c_void_p, ctypes.c_int64, c_int, ctypes.c_int64, c_void_p, c_int,
                                   ctypes.c_int64, c_void_p]),

@@ -415,21 +415,47 @@ class RelPos:
         return self.holder["dbias_t"]
 
 
+_ZERO = {}
+
+
+def _zero_scalar(dev):
+    """A constant fp32 zero on `dev` (never written): the placeholder gradient autograd needs to reach _TableT.backward."""
+    z = _ZERO.get(str(dev))
+    if z is None:
+        z = _ZERO[str(dev)] = torch.zeros((), device=dev, dtype=F32)
+    return z
+
+
 class _TableT(torch.autograd.Function):
-    """bias_t = table^T (contiguous).  Backward hands back the gradient the attention kernels accumulated."""
+    """bias_t = table^T (contiguous).  Backward adds the gradient the attention kernels accumulated straight into the table's
+    slice of the flat gradient buffer.  The transpose is taken once per (optimizer step, in-place edit) and shared by the passes
+    of a step (round 6: one copy instead of one per pass)."""
 
     @staticmethod
     def forward(ctx, table, holder):
-        ctx.holder = holder
-        return table.detach().t().contiguous()
+        ctx.holder, ctx.table = holder, table
+        flat = getattr(table, "_vlm_flat", None)
+        if flat is None or flat.dirty:
+            return table.detach().t().contiguous()
+        key = (flat.version, table._version, table.data_ptr())
+        ent = getattr(flat, "table_t", None)
+        if ent is None or ent[0] != key:
+            ent = flat.table_t = (key, table.detach().t().contiguous())
+        return ent[1].view_as(ent[1])  # a fresh tensor object per pass over the shared storage (nobody writes bias_t)
 
     @staticmethod
     def backward(ctx, g):
         acc = ctx.holder.pop("dbias_t", None)
         ctx.holder.pop("routed", None)
+        table = ctx.table
+        placeholder = g.stride() == (0,) * g.dim()  # _BlockFn's expanded zero: carries nothing
         if acc is None:
-            return g.t(), None
-        return (acc + g).t(), None
+            return (None if placeholder else g.t()), None
+        if getattr(table, "_vlm_flat", None) is not None and table.requires_grad and table.grad is not None:
+            touch(table)
+            table.grad.add_(acc.t() if placeholder else (acc + g).t())
+            return None, None
+        return (acc if placeholder else acc + g).t(), None
 
 
 # The cross-pass cache of dense bias tables lives ON the model's FlatParams (`flat.dense_cache`: it dies with the model and a
@@ -921,7 +947,7 @@ class _BlockFn(torch.autograd.Function):
             # the real gradient sits in relpos.holder["dbias_t"]; autograd only needs ONE defined tensor per table handle to
             # reach _TableT.backward (a zero from every block evaluation cost 22 [144, R] additions per step)
             rp.holder["routed"] = True
-            dbias = torch.zeros((), device=dev, dtype=F32).expand_as(bias_t)
+            dbias = _zero_scalar(dev).expand_as(bias_t)
         return dx, dbias, None, None, None, None
 
 
@@ -932,51 +958,61 @@ def run_block(x, plan: BlockPlan, pc: PassCtx, training: bool, hook=None):
 
 # ----------------------------------------------------------------------------------------------------------------
 class _LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) through the MFMA GEMM; bf16 in/out, wgrad accumulated into W.grad in place.
-    Covers heads.py (Pooler.dense, ITMHead.fc, IFMHead.fc, MLMHead.transform.dense / decoder)."""
+    """y = act(x W^T + b) through the MFMA GEMM; bf16 in/out (fp32 out for act = "tanh"), wgrad accumulated into W.grad in place.
+    Covers heads.py (Pooler.dense + tanh, ITMHead.fc, IFMHead.fc, MLMHead.transform.dense + GELU / decoder).  x may be a row-strided
+    view (the cls rows hidden[:, 0] of a [B, N, D] tensor): the GEMMs take its leading dimension, no gather copy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gelu):
+    def forward(ctx, x, weight, bias, act):
         x2 = x.reshape(-1, x.shape[-1])
         if x2.dtype != BF16:
             x2 = x2.to(BF16)
-        x2 = x2.contiguous()
+        if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+            x2 = x2.contiguous()
         M, K = x2.shape
         N = weight.shape[0]
         Np = (N + 63) // 64 * 64
+        gelu = act == "gelu"
         buf = torch.empty(M, Np, device=x.device, dtype=BF16)
         pre = torch.empty(M, Np, device=x.device, dtype=BF16) if gelu else None
         ops.gemm(x2, w16(weight), buf[:, :N], bias=bias, act=L.ACT_GELU if gelu else L.ACT_NONE,
                  aux=pre[:, :N] if gelu else None)
-        ctx.save_for_backward(x2, pre if gelu else x2.new_empty(0))
-        ctx.weight, ctx.bias, ctx.gelu, ctx.shape, ctx.N, ctx.Np = weight, bias, gelu, x.shape, N, Np
-        return buf[:, :N].view(*x.shape[:-1], N)
+        y = ops.tanh_fwd(buf[:, :N]) if act == "tanh" else None
+        ctx.save_for_backward(x2, pre if gelu else (y if y is not None else x2.new_empty(0)))
+        ctx.weight, ctx.bias, ctx.act, ctx.shape, ctx.N, ctx.Np = weight, bias, act, x.shape, N, Np
+        return (y if y is not None else buf[:, :N]).view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, gy):
-        x2, pre = ctx.saved_tensors
-        weight, bias, N, Np = ctx.weight, ctx.bias, ctx.N, ctx.Np
+        x2, saved = ctx.saved_tensors
+        weight, bias, N, Np, act = ctx.weight, ctx.bias, ctx.N, ctx.Np, ctx.act
         M, K = x2.shape
         gy2 = gy.reshape(M, N)
-        if (not ctx.gelu and gy2.dtype == BF16 and gy2.stride() == (Np, 1) and gy2.storage_offset() == 0
+        if gy2.dtype not in (BF16, F32):
+            gy2 = gy2.float()
+        if gy2.stride(1) != 1:
+            gy2 = gy2.contiguous()
+        if (act is None and gy2.dtype == BF16 and gy2.stride() == (Np, 1) and gy2.storage_offset() == 0
                 and _is_padded_grad(gy2, M, Np)):
             # the fused cross-entropy's gradient: already the zero-padded bf16 [M, Np] operand (registered by _CrossEntropyFn)
             dy = torch.as_strided(gy2, (M, Np), (Np, 1))
-        elif not ctx.gelu and Np == N:
-            # nothing to pad: the gradient itself (cast once if it arrives in fp32) is the GEMMs' operand
-            dy = gy2 if (gy2.dtype == BF16 and gy2.is_contiguous()) else gy2.to(BF16).contiguous()
+        elif act is None and Np == N and gy2.dtype == BF16:
+            dy = gy2  # nothing to pad or cast: the gradient itself is the GEMMs' operand
         else:
-            dy = torch.zeros(M, Np, device=x2.device, dtype=BF16)
-            if ctx.gelu:
-                hh = pre[:, :N].float().requires_grad_(True)
-                with torch.enable_grad():
-                    act = torch.nn.functional.gelu(hh)
-                gy2 = torch.autograd.grad(act, hh, gy2.float())[0]
-            dy[:, :N].copy_(gy2)
+            # ONE launch: upstream gradient x activation derivative -> the zero-padded bf16 operand (csrc/frontops.hip)
+            mode = {"gelu": ops.ACT_BWD_GELU, "tanh": ops.ACT_BWD_TANH, None: ops.ACT_BWD_NONE}[act]
+            dy = ops.act_bwd(gy2, saved[:, :N] if act is not None else None, mode, Np)
         touch(weight if weight.requires_grad else None, bias if bias is not None and bias.requires_grad else None)
         if bias is not None and bias.requires_grad:
             if N % 8 == 0:
                 ops.colsum(dy[:, :N], bias.grad)
+            elif N <= 64:
+                ops.colsum_small(dy[:, :N], bias.grad)
+            elif bias.grad.is_contiguous():
+                # ragged vocabulary (30 522 = 8 * 3 815 + 2): the vector kernel over the whole 8-column groups, the tail apart
+                N8 = N // 8 * 8
+                ops.colsum(dy[:, :N8], bias.grad[:N8])
+                ops.colsum_small(dy[:, N8:N], bias.grad[N8:])
             else:
                 bias.grad.add_(dy[:, :N].float().sum(0))
         if weight.requires_grad:
@@ -999,8 +1035,9 @@ class _LinearFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-def linear(x, weight, bias=None, gelu=False):
-    return _LinearFn.apply(x, weight, bias, gelu)
+def linear(x, weight, bias=None, gelu=False, act=None):
+    """act: None, "gelu" (bf16 out, `gelu=True` is the older spelling) or "tanh" (fp32 out)."""
+    return _LinearFn.apply(x, weight, bias, "gelu" if gelu else act)
 
 
 class _L2NormFn(torch.autograd.Function):
@@ -1053,11 +1090,14 @@ class _ContrastiveFn(torch.autograd.Function):
         ctx.save_for_backward(out3, d_img, d_txt)
         ctx.ls_shape = log_scale.shape
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)  # an unused exp(log_scale) output arrives as None, not as a zero to multiply and add
         return out3[0], logits, out3[2]
 
     @staticmethod
     def backward(ctx, g_loss, _g_logits, g_scale):
         out3, d_img, d_txt = ctx.saved_tensors
+        if g_loss is None:
+            g_loss = torch.zeros((), device=out3.device, dtype=F32)
         gi, gt, gs = ops.scale_by_scalar([d_img, d_txt, out3[1:2]], g_loss.reshape(1).float())
         gs = gs.view(ctx.ls_shape)
         if g_scale is not None:  # somebody differentiates the returned scale itself (d exp(l) / d l = exp(l)): not on the hot path
@@ -1068,6 +1108,46 @@ class _ContrastiveFn(torch.autograd.Function):
 def contrastive_loss(img, txt, log_scale, others_img=None, others_txt=None):
     """loss, logits_per_image [n, n], exp(log_scale): img / txt = this rank's normalised fp32 features [B, D]."""
     return _ContrastiveFn.apply(img, txt, log_scale, others_img, others_txt)
+
+
+_WVEC = {}
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """sum_k w_k * loss_k of scalar device losses in ONE launch (training_step's `sum(losses)`, compute_ifm's
+    `(ifm_weight * a + b) * 0.5`: torch issues a multiply / add per term forward and a multiply per term backward)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights, ctx.dev = weights, terms[0].device
+        return ops.weighted_sum([t.detach().reshape(1) for t in terms], weights)
+
+    @staticmethod
+    def backward(ctx, g):
+        w = ctx.weights
+        if all(x == 1.0 for x in w):
+            return (None,) + (g,) * len(w)
+        key = (w, str(ctx.dev))
+        wv = _WVEC.get(key)
+        if wv is None:
+            if len(_WVEC) > 64:
+                _WVEC.clear()
+            wv = _WVEC[key] = torch.tensor(w, dtype=F32).to(ctx.dev)
+        gw = g * wv  # one launch for all terms
+        return (None,) + tuple(gw[k] for k in range(len(w)))
+
+
+def weighted_sum(terms, weights=None):
+    """sum_k weights[k] * terms[k] for scalar losses (weights default to 1); anything that is not a handful of fp32 CUDA scalars
+    goes through torch."""
+    terms = list(terms)
+    weights = tuple(float(w) for w in (weights if weights is not None else [1.0] * len(terms)))
+    if (_FUSED_LOSS and 1 <= len(terms) <= 8 and all(torch.is_tensor(t) and t.is_cuda and t.dtype == F32 and t.numel() == 1 for t in terms)):
+        return _WeightedSumFn.apply(weights, *terms)
+    out = 0
+    for t, w in zip(terms, weights):
+        out = out + (t if w == 1.0 else t * w)
+    return out
 
 
 class _SmallCrossEntropyFn(torch.autograd.Function):
@@ -1172,6 +1252,87 @@ def layer_norm(x, weight, bias, eps, out_f32=False):
     return _LayerNormFn.apply(x, weight, bias, eps, out_f32)
 
 
+def _rows2d(g, D):
+    g2 = g.reshape(-1, D)
+    if g2.dtype not in (BF16, F32):
+        g2 = g2.float()
+    return g2 if g2.stride(1) == 1 else g2.contiguous()
+
+
+class _FeatureViewsFn(torch.autograd.Function):
+    """The views of a pass's final feature matrix x [B T + B I, D] (segment-major) that its result exposes -- text_feats [B, T, D],
+    image_feats [B, I, D], and the cls rows of both as [B, D] views (reference vilt_module.py:1136-1156, :1199-1223, :1346-1375:
+    `x[:, :T]`, `x[:, T:]`, `[:, 0]`) -- as ONE autograd node: the gradient of x is assembled from whichever views received one in a
+    single launch (ops.scatter_rows), where autograd materialises a zero tensor + a strided copy per view and adds them up."""
+
+    @staticmethod
+    def forward(ctx, x, B, T, I):
+        ctx.set_materialize_grads(False)
+        D = x.shape[1]
+        nt = B * T
+        ctx.geom = (x.shape[0], D, B, T, I, x.dtype)
+        text = x[:nt].view(B, T, D)
+        image = x[nt:].view(B, I, D)
+        tcls = torch.as_strided(x, (B, D), (T * D, 1), x.storage_offset()) if T else x[:0]
+        icls = torch.as_strided(x, (B, D), (I * D, 1), x.storage_offset() + nt * D) if I else x[:0]
+        return text, image, tcls, icls
+
+    @staticmethod
+    def backward(ctx, g_text, g_image, g_tcls, g_icls):
+        R, D, B, T, I, dtype = ctx.geom
+        nt = B * T
+        src = []
+        if g_text is not None and T:
+            src.append((_rows2d(g_text, D), 0, 1))
+        if g_image is not None and I:
+            src.append((_rows2d(g_image, D), nt, 1))
+        if g_tcls is not None and T:
+            src.append((_rows2d(g_tcls, D), 0, T))
+        if g_icls is not None and I:
+            src.append((_rows2d(g_icls, D), nt, I))
+        dev = src[0][0].device if src else None
+        if not src:
+            return None, None, None, None
+        return ops.scatter_rows(R, D, dtype, src, dev), None, None, None
+
+
+def feature_views(x, B, T, I):
+    """(text_feats [B, T, D], image_feats [B, I, D], text cls rows [B, D], image cls rows [B, D]) of x [B T + B I, D]: see
+    _FeatureViewsFn.  Falls back to plain views where the kernel does not apply (CPU, a width that is not a multiple of 4)."""
+    D = x.shape[1]
+    nt = B * T
+    if x.is_cuda and x.is_contiguous() and x.dtype in (BF16, F32) and D % 4 == 0 and torch.is_grad_enabled() and x.requires_grad:
+        return _FeatureViewsFn.apply(x, B, T, I)
+    text, image = x[:nt].view(B, T, D), x[nt:].view(B, I, D)
+    return text, image, text[:, 0], image[:, 0]
+
+
+class _RowRangeFn(torch.autograd.Function):
+    """t[a:b] along the first dim as one autograd node whose backward is ONE launch (zero fill and copy together)."""
+
+    @staticmethod
+    def forward(ctx, t, a, b):
+        ctx.shape, ctx.dtype, ctx.a = t.shape, t.dtype, a
+        return t[a:b]
+
+    @staticmethod
+    def backward(ctx, g):
+        D = ctx.shape[-1]
+        inner = 1
+        for d in ctx.shape[1:-1]:
+            inner *= d
+        g2 = _rows2d(g, D)
+        return ops.scatter_rows(ctx.shape[0] * inner, D, ctx.dtype, [(g2, ctx.a * inner, 1)], g2.device).view(ctx.shape), None, None
+
+
+def row_range(t, a, b):
+    """t[a:b] (first dim); on the GPU with a one-launch backward (objectives.py: `infer["text_feats"][:bsz]`, `cls_feats[bsz:]`)."""
+    if (t.is_cuda and t.dim() >= 2 and t.is_contiguous() and t.dtype in (BF16, F32) and t.shape[-1] % 4 == 0 and torch.is_grad_enabled()
+            and t.requires_grad):
+        return _RowRangeFn.apply(t, a, t.shape[0] if b is None else b)
+    return t[a:b]
+
+
 class _EmbeddingFn(torch.autograd.Function):
     """nn.Embedding gather (BertEmbeddings.word_embeddings, vilt_module.py:63) whose backward adds the token rows straight
     into the flat gradient buffer instead of torch's sort + dense [vocab, D] gradient + accumulate."""
@@ -1243,64 +1404,93 @@ def patch_embed(image, weight, bias, patch):
     return _PatchEmbedFn.apply(image, weight, bias, patch)
 
 
+class TextSpec:
+    """What _PassRowsFn needs to produce the text rows of a pass itself (BertEmbeddings.forward + the modality type row 0,
+    reference vilt_module.py:51-63, :1111-1113): ids [B, T] int64, the word table, BERT's own token-type table (row 0 is added
+    before the LayerNorm), the LayerNorm, and the dropout as (u fp32 [B * T, D] or None, p, scale): an element is kept where
+    u >= p and multiplied by scale."""
+    __slots__ = ("ids", "word", "padding_idx", "bert_type", "gamma", "beta", "eps", "u", "p", "scale")
+
+    def __init__(self, ids, word, padding_idx, bert_type, gamma, beta, eps, u=None, p=0.0, scale=1.0):
+        self.ids, self.word, self.padding_idx, self.bert_type = ids, word, padding_idx, bert_type
+        self.gamma, self.beta, self.eps, self.u, self.p, self.scale = gamma, beta, eps, u, p, scale
+
+
+def _g(p):
+    return p.grad if (p is not None and p.requires_grad) else None
+
+
 class _PassRowsFn(torch.autograd.Function):
-    """The token matrix a pass starts from, x = [text rows ; image rows] (segment-major, fp32), with the image side of
-    visual_embed fused into the patch-embed GEMM (reference vision_transformer.py:952-991 + vilt_module.py:1111-1117):
+    """The token matrix a pass starts from, x = [text rows ; image rows] (segment-major, fp32), both halves produced in place:
+      text rows (`text`: a TextSpec)  dropout(LayerNorm(word[ids] + bert_type[0])) + token_type[0] -- ONE launch (csrc/frontops.hip;
+                                      torch: gather, add, LayerNorm, dropout, add, copy into x), or `trows` copied in;
+      image rows                      visual_embed fused into the patch-embed GEMM (reference
+                                      vision_transformer.py:952-991 + vilt_module.py:1111-1117):
         image row (b, 0)     = cls_token + token_type[idx]
         image row (b, 1 + p) = conv(patch p) + conv_bias + token_type[idx]
-    The GEMM writes its rows straight into x with (conv_bias + token_type[idx]) as its bias; B lead rows are then overwritten
-    with the cls row.  Replaces three passes over the [B * rows, D] fp32 image rows (the cls concat, the token-type add, the
-    text / image concat) and, backward, the column sum over all image rows for the token-type gradient plus the slice copies.
-    Gradients: conv weight through the wgrad GEMM (in place into .grad), conv bias += colsum over the patch rows, token_type[idx]
-    = that colsum + the lead rows' sum, cls_token = the lead rows' sum; the text rows' gradient is the matching slice of dx."""
+      The GEMM writes its rows straight into x with (conv_bias + token_type[idx]) as its bias; the B lead rows are then overwritten.
+    Backward writes every parameter gradient straight into the flat gradient buffer (touch()): the word rows by atomics, the
+    LayerNorm / type-row / conv-bias / cls gradients as column sums folded in a fixed order, the conv weight through the wgrad GEMM.
+    Only `trows` (when the caller made the text rows itself) gets a gradient through autograd."""
 
     @staticmethod
-    def forward(ctx, trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch):
-        B, C, Hh, Ww = image.shape
-        Dm = weight.shape[0]
-        rows = 1 + (Hh // patch) * (Ww // patch)
-        K = C * patch * patch
-        nt = 0 if trows is None else trows.shape[0]
-        dev = image.device
+    def forward(ctx, trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch, text):
+        Dm = tt_weight.shape[1]
+        dev = tt_weight.device
+        B = rows = K = 0
+        if image is not None:
+            B, C, Hh, Ww = image.shape
+            rows = 1 + (Hh // patch) * (Ww // patch)
+            K = C * patch * patch
+        nt = text.ids.numel() if text is not None else (0 if trows is None else trows.shape[0])
         x = torch.empty(nt + B * rows, Dm, device=dev, dtype=F32)
-        if nt:
+        stats = None
+        if text is not None:
+            stats = ops.text_rows_fwd(text.ids.reshape(-1), text.word.detach(), text.bert_type.detach()[0], text.gamma.detach(),
+                                      text.beta.detach(), text.eps, x[:nt], text.u, text.p, text.scale, add1=tt_weight.detach()[0])
+        elif nt:
             x[:nt].copy_(trows)
-        cols = torch.empty(B * rows, K, device=dev, dtype=BF16)
-        ops.patch_im2col(image.contiguous().float(), cols, patch, 1)
-        tt = tt_weight.detach()[tt_idx].float()
-        ops.gemm(cols, w16(weight).view(Dm, K), x[nt:], bias=(bias.detach().float() + tt).contiguous())
-        x[nt:].view(B, rows, Dm)[:, 0] = cls_token.detach().reshape(Dm).float() + tt
-        ctx.save_for_backward(cols)
-        ctx.weight, ctx.bias, ctx.geom = weight, bias, (B, rows, Dm, nt, tt_idx)
-        ctx.cls_shape, ctx.tt_shape = cls_token.shape, tt_weight.shape
+        cols = None
+        if image is not None:
+            cols = torch.empty(B * rows, K, device=dev, dtype=BF16)
+            im = image if (image.dtype == F32 and image.is_contiguous()) else image.contiguous().float()
+            ops.patch_im2col(im, cols, patch, 1)
+            pre = ops.image_rows_prep(bias.detach() if bias is not None else None, tt_weight.detach()[tt_idx], cls_token.detach())
+            ops.gemm(cols, w16(weight).view(Dm, K), x[nt:], bias=pre[0])
+            ops.image_lead_rows(x[nt:], B, rows, pre[1])
+        ctx.save_for_backward(*[t for t in (cols, stats) if t is not None])
+        ctx.has = (cols is not None, stats is not None)
+        ctx.weight, ctx.bias, ctx.cls, ctx.tt, ctx.text = weight, bias, cls_token, tt_weight, text
+        ctx.geom = (B, rows, Dm, nt, tt_idx)
         return x
 
     @staticmethod
     def backward(ctx, gx):
-        (cols,) = ctx.saved_tensors
-        weight, bias = ctx.weight, ctx.bias
+        saved = list(ctx.saved_tensors)
+        cols = saved.pop(0) if ctx.has[0] else None
+        stats = saved.pop(0) if ctx.has[1] else None
+        weight, bias, cls, tt, text = ctx.weight, ctx.bias, ctx.cls, ctx.tt, ctx.text
         B, rows, Dm, nt, tt_idx = ctx.geom
-        g = gx[nt:]
-        lead = g.view(B, rows, Dm)[:, 0].float().sum(0)                     # d(cls row) = sum over the samples' lead rows
-        g16 = torch.empty(B * rows, Dm, device=g.device, dtype=BF16)
-        g16.copy_(g)
-        g16.view(B, rows, Dm)[:, 0].zero_()                                 # lead rows carry no patch
-        touch(weight if weight.requires_grad else None, bias if bias is not None and bias.requires_grad else None)
-        if weight.requires_grad:
-            ops.gemm(g16, cols, weight.grad.view(Dm, -1), ta=True, tb=True, accumulate=True)
-        csum = torch.zeros(Dm, device=g.device, dtype=F32)
-        ops.colsum(g16, csum)                                               # sum over the patch rows (= d conv_bias)
-        if bias is not None and bias.requires_grad:
-            bias.grad.add_(csum)
-        d_tt = None
-        if ctx.needs_input_grad[5]:
-            d_tt = torch.zeros(ctx.tt_shape, device=g.device, dtype=F32)
-            d_tt[tt_idx] = csum + lead
-        d_cls = lead.view(ctx.cls_shape) if ctx.needs_input_grad[4] else None
-        return (gx[:nt] if nt and ctx.needs_input_grad[0] else None), None, None, None, d_cls, d_tt, None, None
+        if gx.dtype != F32 or gx.stride(1) != 1:
+            gx = gx.float().contiguous()
+        if cols is not None:
+            touch(*[p for p in (weight, bias, cls, tt) if p is not None and p.requires_grad])
+            g16 = ops.image_rows_bwd(gx[nt:], B, rows, _g(bias), _g(tt)[tt_idx] if _g(tt) is not None else None, _g(cls))
+            if weight.requires_grad:
+                ops.gemm(g16, cols, weight.grad.view(Dm, -1), ta=True, tb=True, accumulate=True)
+        if text is not None:
+            touch(*[p for p in (text.word, text.bert_type, text.gamma, text.beta, tt) if p.requires_grad])
+            gb, gt = _g(text.bert_type), _g(tt)
+            ops.text_rows_bwd(gx[:nt], text.ids.reshape(-1), text.word.detach(), text.bert_type.detach()[0], text.gamma.detach(), stats,
+                              text.u, text.p, text.scale, _g(text.word), text.padding_idx, gt[0] if gt is not None else None,
+                              _g(text.beta), _g(text.gamma), gb[0] if gb is not None else None)
+        return (gx[:nt] if (text is None and nt and ctx.needs_input_grad[0]) else None), None, None, None, None, None, None, None, None
 
 
-def pass_rows(trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch):
-    """x = [trows ; image rows of `image`] for a pass (trows may be None: an image-only pass); see _PassRowsFn."""
-    return _PassRowsFn.apply(trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch)
+def pass_rows(trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch, text=None):
+    """x = [text rows ; image rows of `image`] for a pass: the text rows either given (`trows`) or made here from `text` (a
+    TextSpec); `image` may be None (a text-only pass from a TextSpec); see _PassRowsFn."""
+    if text is not None and trows is not None:
+        raise ValueError("pass_rows: text rows OR a TextSpec")
+    return _PassRowsFn.apply(trows, image, weight, bias, cls_token, tt_weight, tt_idx, patch, text)
 

@@ -422,6 +422,187 @@ def scale_by_scalar(tensors, scalar):
     return outs
 
 
+_FRONT_WS = {}
+
+
+def _front_ws(kind, D, device):
+    """Per-(kind, D, device) scratch of the front-end backward kernels (column partials, folded in the same call)."""
+    key = (kind, D, str(device))
+    ws = _FRONT_WS.get(key)
+    if ws is None:
+        lib = L.get_lib()
+        n = lib.vlm_text_rows_bwd_ws_floats(D) if kind == "text" else lib.vlm_image_rows_bwd_ws_floats(D)
+        ws = _FRONT_WS[key] = torch.empty(max(1, n), device=device, dtype=F32)
+    return ws
+
+
+def _rowvec(t, D, what):
+    if t is None:
+        return 0
+    if t.dtype != F32 or t.numel() != D or not t.is_contiguous():
+        raise L.VlmError("%s: a contiguous fp32 vector of %d elements" % (what, D))
+    return L.ptr(t)
+
+
+def text_rows_fwd(ids, word, add0, gamma, beta, eps, out, u=None, p=0.0, scale=1.0, add1=None):
+    """out[r] = dropout(LayerNorm(word[ids[r]] + add0)) + add1 (include/vlm_hip.h vlm_text_rows_fwd); out: fp32 [n, D] rows with unit
+    column stride (a slice of the pass's token matrix); returns stats fp32 [n, 2]."""
+    L.require_cuda(ids, word, add0, gamma, beta, out, u, add1)
+    n, D = out.shape
+    if ids.dtype != torch.int64 or ids.numel() != n or not ids.is_contiguous():
+        raise L.VlmError("text_rows: contiguous int64 ids, one per output row")
+    if word.dtype != F32 or word.shape[1] != D or word.stride(1) != 1 or out.dtype != F32 or out.stride(1) != 1:
+        raise L.VlmError("text_rows: fp32 word table [V, D] and fp32 output rows")
+    if u is not None and (u.dtype != F32 or u.numel() != n * D or not u.is_contiguous()):
+        raise L.VlmError("text_rows: u is a contiguous fp32 [n, D]")
+    stats = torch.empty(n, 2, device=out.device, dtype=F32)
+    L.check(L.get_lib().vlm_text_rows_fwd(L.ptr(ids), n, L.ptr(word), _ld(word), _rowvec(add0, D, "add0"), _rowvec(gamma, D, "gamma"),
+                                          _rowvec(beta, D, "beta"), float(eps), L.ptr(u) if u is not None else 0, float(p), float(scale),
+                                          _rowvec(add1, D, "add1"), L.ptr(out), _ld(out), L.ptr(stats), D, L.stream_ptr()), "vlm_text_rows_fwd")
+    return stats
+
+
+def text_rows_bwd(g, ids, word, add0, gamma, stats, u, p, scale, d_word, padding_idx, d_add1, d_beta, d_gamma, d_add0):
+    """Backward of text_rows_fwd: ADDS into d_word rows and the four vectors (None = not wanted)."""
+    L.require_cuda(g, ids, word, add0, gamma, stats, u, d_word, d_add1, d_beta, d_gamma, d_add0)
+    n, D = g.shape
+    if g.dtype != F32 or g.stride(1) != 1:
+        raise L.VlmError("text_rows_bwd: fp32 gradient rows with unit column stride")
+    if d_word is not None and (d_word.dtype != F32 or d_word.shape != word.shape or d_word.stride() != word.stride()):
+        raise L.VlmError("text_rows_bwd: d_word has the word table's layout")
+    L.check(L.get_lib().vlm_text_rows_bwd(L.ptr(g), _ld(g), L.ptr(ids), n, L.ptr(word), _ld(word), _rowvec(add0, D, "add0"),
+                                          _rowvec(gamma, D, "gamma"), L.ptr(stats), L.ptr(u) if u is not None else 0, float(p), float(scale), D,
+                                          L.ptr(d_word) if d_word is not None else 0, -1 if padding_idx is None else int(padding_idx),
+                                          _rowvec(d_add1, D, "d_add1"), _rowvec(d_beta, D, "d_beta"), _rowvec(d_gamma, D, "d_gamma"),
+                                          _rowvec(d_add0, D, "d_add0"), L.ptr(_front_ws("text", D, g.device)), L.stream_ptr()),
+            "vlm_text_rows_bwd")
+
+
+def image_rows_prep(conv_bias, type_row, cls):
+    """fp32 [2, D]: row 0 = conv_bias + type_row (the patch-embed GEMM's bias), row 1 = cls + type_row (the lead row)."""
+    L.require_cuda(conv_bias, type_row, cls)
+    D = cls.numel()
+    out2 = torch.empty(2, D, device=cls.device, dtype=F32)
+    L.check(L.get_lib().vlm_image_rows_prep(_rowvec(conv_bias, D, "conv_bias"), _rowvec(type_row, D, "type_row"), _rowvec(cls.reshape(-1), D, "cls"),
+                                            D, L.ptr(out2), L.stream_ptr()), "vlm_image_rows_prep")
+    return out2
+
+
+def image_lead_rows(x, B, rows, lead):
+    """x[b * rows] = lead for b < B (x: fp32 [B * rows, D] rows with unit column stride)."""
+    L.require_cuda(x, lead)
+    D = x.shape[1]
+    if x.dtype != F32 or x.stride(1) != 1 or x.shape[0] != B * rows:
+        raise L.VlmError("image_lead_rows: fp32 [B * rows, D]")
+    L.check(L.get_lib().vlm_image_lead_rows(L.ptr(x), _ld(x), B, rows, D, _rowvec(lead, D, "lead"), L.stream_ptr()), "vlm_image_lead_rows")
+
+
+def image_rows_bwd(g, B, rows, d_bias, d_type_row, d_cls):
+    """g fp32 [B * rows, D] -> bf16 copy with the lead rows zeroed (returned); ADDS the column sums into d_bias (patch rows),
+    d_type_row (all rows), d_cls (lead rows); None = not wanted."""
+    L.require_cuda(g, d_bias, d_type_row, d_cls)
+    n, D = g.shape
+    if g.dtype != F32 or g.stride(1) != 1 or n != B * rows:
+        raise L.VlmError("image_rows_bwd: fp32 [B * rows, D] gradient rows")
+    g16 = torch.empty(n, D, device=g.device, dtype=BF16)
+    L.check(L.get_lib().vlm_image_rows_bwd(L.ptr(g), _ld(g), B, rows, D, L.ptr(g16), _rowvec(d_bias, D, "d_bias"),
+                                           _rowvec(d_type_row, D, "d_type_row"), _rowvec(d_cls.reshape(-1) if d_cls is not None else None, D, "d_cls"),
+                                           L.ptr(_front_ws("image", D, g.device)), L.stream_ptr()), "vlm_image_rows_bwd")
+    return g16
+
+
+def tanh_fwd(x):
+    """fp32 tanh of a bf16 [M, N] matrix with unit column stride."""
+    L.require_cuda(x)
+    M, N = x.shape
+    if x.dtype != BF16 or x.stride(1) != 1:
+        raise L.VlmError("tanh_fwd: bf16 [M, N] with unit column stride")
+    y = torch.empty(M, N, device=x.device, dtype=F32)
+    L.check(L.get_lib().vlm_tanh_fwd(L.ptr(x), _ld(x), M, N, L.ptr(y), L.stream_ptr()), "vlm_tanh_fwd")
+    return y
+
+
+ACT_BWD_GELU, ACT_BWD_TANH, ACT_BWD_NONE = 0, 1, 2
+
+
+def act_bwd(g, saved, mode, Np=None):
+    """bf16 [M, Np] (columns >= N zero) = g * act'(.): ACT_BWD_GELU from the saved bf16 pre-activation, ACT_BWD_TANH from the saved
+    fp32 output, ACT_BWD_NONE: the cast / padding alone (saved = None)."""
+    L.require_cuda(g, saved)
+    M, N = g.shape
+    Np = N if Np is None else Np
+    if g.dtype not in (BF16, F32) or g.stride(1) != 1:
+        raise L.VlmError("act_bwd: bf16 / fp32 gradient [M, N] with unit column stride")
+    if mode != ACT_BWD_NONE:
+        if saved.stride(1) != 1 or saved.shape[0] != M or saved.shape[1] < N:
+            raise L.VlmError("act_bwd: saved [M, >= N] with unit column stride")
+        if saved.dtype != (BF16 if mode == ACT_BWD_GELU else F32):
+            raise L.VlmError("act_bwd: saved pre-activation is bf16 (GELU) / saved output is fp32 (tanh)")
+    dy = torch.empty(M, Np, device=g.device, dtype=BF16)
+    L.check(L.get_lib().vlm_act_bwd(L.ptr(g), int(g.dtype == F32), _ld(g), L.ptr(saved) if saved is not None else 0,
+                                    _ld(saved) if saved is not None else 0, mode, M, N, Np, L.ptr(dy), L.stream_ptr()), "vlm_act_bwd")
+    return dy
+
+
+def colsum_small(a, out):
+    """out[c] += sum_r a[r][c] for a bf16 matrix with at most 64 columns."""
+    L.require_cuda(a, out)
+    M, N = a.shape
+    if a.dtype != BF16 or a.stride(1) != 1 or out.dtype != F32 or out.numel() < N or not out.is_contiguous():
+        raise L.VlmError("colsum_small: bf16 [M, N <= 64], fp32 out")
+    L.check(L.get_lib().vlm_colsum_small(L.ptr(a), _ld(a), M, N, L.ptr(out), L.stream_ptr()), "vlm_colsum_small")
+    return out
+
+
+def sample_negatives(sim_a, sim_b, B, u):
+    """int64 [2, B]: row 0 drawn from softmax(sim_a[i, :]) without entry i, row 1 likewise from sim_b (fp32 [>= B, n], any strides);
+    u: fp32 [2, B] uniforms."""
+    L.require_cuda(sim_a, sim_b, u)
+    n = sim_a.shape[1]
+    for t in (sim_a, sim_b):
+        if t.dtype != F32 or t.dim() != 2 or t.shape[0] < B or t.shape[1] != n:
+            raise L.VlmError("sample_negatives: two fp32 similarity matrices [>= B, n]")
+    if u.dtype != F32 or u.numel() != 2 * B or not u.is_contiguous():
+        raise L.VlmError("sample_negatives: u is fp32 [2, B]")
+    idx = torch.empty(2, B, device=sim_a.device, dtype=torch.int64)
+    L.check(L.get_lib().vlm_sample_negatives(L.ptr(sim_a), sim_a.stride(0), sim_a.stride(1), L.ptr(sim_b), sim_b.stride(0), sim_b.stride(1), B, n,
+                                             L.ptr(u), L.ptr(idx), L.stream_ptr()), "vlm_sample_negatives")
+    return idx
+
+
+def scatter_rows(R, D, dtype, sources, device):
+    """[R, D] tensor of `dtype` (bf16 / fp32) = the sources placed at their rows, zero elsewhere.  sources: up to four
+    (g [count, D] bf16 / fp32 with unit column stride, first_row, row_step)."""
+    if dtype not in (BF16, F32) or len(sources) > 4:
+        raise L.VlmError("scatter_rows: bf16 / fp32 output, at most four sources")
+    dx = torch.empty(R, D, device=device, dtype=dtype)
+    arr = (L.ScatterSrc * max(1, len(sources)))()
+    for a, (g, first, step) in zip(arr, sources):
+        L.require_cuda(g)
+        if g.dim() != 2 or g.shape[1] != D or g.dtype not in (BF16, F32) or g.stride(1) != 1:
+            raise L.VlmError("scatter_rows: sources are bf16 / fp32 [count, D] with unit column stride")
+        if first + (g.shape[0] - 1) * step >= R and g.shape[0]:
+            raise L.VlmError("scatter_rows: source rows %d + %d * j (j < %d) leave the %d output rows" % (first, step, g.shape[0], R))
+        a.g, a.g_is_f32, a.ld, a.first_row, a.row_step, a.count = L.ptr(g), int(g.dtype == F32), _ld(g), first, step, g.shape[0]
+    L.check(L.get_lib().vlm_scatter_rows(L.ptr(dx), int(dtype == F32), D, R, D, ctypes.cast(arr, ctypes.c_void_p), len(sources), L.stream_ptr()),
+            "vlm_scatter_rows")
+    return dx
+
+
+def weighted_sum(terms, weights):
+    """fp32 scalar = sum_k weights[k] * terms[k] (device scalars, host weights, at most 8)."""
+    L.require_cuda(*terms)
+    k = len(terms)
+    if k == 0 or k > 8 or len(weights) != k or any(t.dtype != F32 or t.numel() != 1 for t in terms):
+        raise L.VlmError("weighted_sum: 1..8 fp32 device scalars with one host weight each")
+    out = torch.empty((), device=terms[0].device, dtype=F32)
+    P = ctypes.c_void_p * k
+    W = ctypes.c_float * k
+    L.check(L.get_lib().vlm_weighted_sum(P(*[L.ptr(t) for t in terms]), W(*[float(w) for w in weights]), k, L.ptr(out), L.stream_ptr()),
+            "vlm_weighted_sum")
+    return out
+
+
 def colsum(a, out):
     """out[n] += sum_m a[m,n]  (a bf16)."""
     L.require_cuda(a, out)

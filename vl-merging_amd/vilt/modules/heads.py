@@ -11,8 +11,10 @@ class Pooler(nn.Module):
         super().__init__()
         self.dense = nn.Linear(hidden_size, hidden_size)
 
-    def forward(self, hidden_states):
-        return torch.tanh(engine.linear(hidden_states[:, 0], self.dense.weight, self.dense.bias).float())
+    def forward(self, hidden_states, cls_rows=None):
+        """cls_rows: hidden_states[:, 0] when the caller already holds that view (engine.feature_views)."""
+        x = hidden_states[:, 0] if cls_rows is None else cls_rows
+        return engine.linear(x, self.dense.weight, self.dense.bias, act="tanh")  # fp32, like tanh(x.float())
 
 
 class ITMHead(nn.Module):

@@ -7,7 +7,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import engine
+from ... import engine, ops
 
 
 _LOCAL_ONLY = [False]
@@ -60,7 +60,8 @@ def compute_mlm(pl_module, batch):
     mlm_logits = pl_module.mlm_score(infer["text_feats"])
     mlm_labels = infer["text_labels"]
     mlm_loss = engine.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), ignore_index=-100)
-    return {"mlm_loss": mlm_loss * pl_module.hparams.config["vl_mlm_weight"], "mlm_logits": mlm_logits,
+    w = pl_module.hparams.config["vl_mlm_weight"]
+    return {"mlm_loss": mlm_loss if w == 1 else engine.weighted_sum([mlm_loss], [w]), "mlm_logits": mlm_logits,
             "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
 
 
@@ -120,7 +121,7 @@ def compute_ifm(pl_module, batch, aggregate=True):
     ifm_loss, li, lt, logit_scale = _contrastive_pair(infer_imag["cls_feats"], infer_text["cls_feats"], pl_module.logit_scale)
     ifm_vlffn_loss, _, _, logit_vl_scale = _contrastive_pair(infer_imag["cls_vlffn_feats"], infer_text["cls_vlffn_feats"],
                                                              pl_module.logit_vl_scale)
-    total = (pl_module.hparams.config["ifm_weight"] * ifm_loss + ifm_vlffn_loss) * 0.5
+    total = engine.weighted_sum([ifm_loss, ifm_vlffn_loss], [0.5 * pl_module.hparams.config["ifm_weight"], 0.5])  # (w a + b) * 0.5
     return {"ifm_loss": total, "ifm_i2t_logits": li, "ifm_t2i_logits": lt, "ifm_labels": _labels_arange(len(li), li.device),
             "ifm_logit_scale": logit_scale, "ifm_logit_vl_scale": logit_vl_scale}
 
@@ -191,6 +192,26 @@ def _gather_cat(t):
     return torch.cat([t] + gathered[:rank] + gathered[rank + 1:])
 
 
+_TORCH_MULTINOMIAL = torch.multinomial
+
+
+def _draw_negatives(sim_i2t, sim_t2i, bsz):
+    """(neg_img, neg_txt) int64 [bsz]: one draw per row from softmax(sim_t2i[i]) / softmax(sim_i2t[i]) with the own pair removed
+    (:197-215: F.softmax, fill_diagonal_(0), torch.multinomial(., 1)).  On the GPU: ONE launch from 2 * bsz uniforms
+    (csrc/frontops.hip vlm_sample_negatives, inverse CDF: the same distribution) instead of torch's softmax / fill / multinomial
+    chains.  A test that replaces torch.multinomial (a deterministic stand-in) gets the torch form."""
+    a, b = sim_t2i[:bsz], sim_i2t[:bsz]
+    if (torch.multinomial is _TORCH_MULTINOMIAL and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+            and a.dim() == 2 and a.shape == b.shape):
+        idx = ops.sample_negatives(a, b, bsz, torch.rand(2, bsz, device=a.device, dtype=torch.float32))
+        return idx[0], idx[1]
+    weights_i2t = F.softmax(b.float(), dim=1)
+    weights_t2i = F.softmax(a.float(), dim=1)
+    weights_i2t.fill_diagonal_(0)
+    weights_t2i.fill_diagonal_(0)
+    return torch.multinomial(weights_t2i, 1).squeeze(1), torch.multinomial(weights_i2t, 1).squeeze(1)
+
+
 def _sample_hard_negatives(pl_module, batch, sim_i2t, sim_t2i):
     """ONE batched multinomial per direction over the (gathered) candidates, device-side gathers (:176-229)."""
     bsz = batch["text_ids"].size(0)
@@ -202,12 +223,7 @@ def _sample_hard_negatives(pl_module, batch, sim_i2t, sim_t2i):
             all_text_ids = _gather_cat(batch["text_ids"])
             all_text_masks = _gather_cat(batch["text_masks"])
             all_image = _gather_images(batch["image"][0])
-        weights_i2t = F.softmax(sim_i2t[:bsz, :].float(), dim=1)
-        weights_t2i = F.softmax(sim_t2i[:bsz, :].float(), dim=1)
-        weights_i2t.fill_diagonal_(0)
-        weights_t2i.fill_diagonal_(0)
-        neg_img = torch.multinomial(weights_t2i, 1).squeeze(1)
-        neg_txt = torch.multinomial(weights_i2t, 1).squeeze(1)
+        neg_img, neg_txt = _draw_negatives(sim_i2t, sim_t2i, bsz)
         return all_image[neg_img], all_text_ids[neg_txt], all_text_masks[neg_txt]
 
 
@@ -226,13 +242,14 @@ def compute_mlm_itm_fused(pl_module, batch, sim_i2t, sim_t2i):
         "image": [torch.cat([img, img, images_neg, img])],
     }
     infer = pl_module.infer(big, mask_text=False, mask_image=False)
-    mlm_logits = pl_module.mlm_score(infer["text_feats"][:bsz])
+    mlm_logits = pl_module.mlm_score(engine.row_range(infer["text_feats"], 0, bsz))
     mlm_labels = batch["text_labels_mlm"]
     mlm_loss = engine.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), ignore_index=-100)
     itm_labels, itm_long = _itm_labels(bsz, img.device)
-    itm_logits = pl_module.itm_score(infer["cls_feats"][bsz:])
+    itm_logits = pl_module.itm_score(engine.row_range(infer["cls_feats"], bsz, None))
     itm_loss = engine.small_cross_entropy(itm_logits, itm_long)
-    return {"mlm_loss": mlm_loss * pl_module.hparams.config["vl_mlm_weight"], "mlm_logits": mlm_logits,
+    w = pl_module.hparams.config["vl_mlm_weight"]
+    return {"mlm_loss": mlm_loss if w == 1 else engine.weighted_sum([mlm_loss], [w]), "mlm_logits": mlm_logits,
             "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"], "itm_loss": itm_loss,
             "itm_logits": itm_logits, "itm_labels": itm_labels}
 
@@ -249,12 +266,7 @@ def compute_itm_hardneg(pl_module, batch, sim_i2t, sim_t2i):
         all_text_ids = _gather_cat(infer_pos["text_ids"])
         all_text_masks = _gather_cat(infer_pos["text_masks"])
         all_image = _gather_images(infer_pos["image"])
-        weights_i2t = F.softmax(sim_i2t[:bsz, :].float(), dim=1)
-        weights_t2i = F.softmax(sim_t2i[:bsz, :].float(), dim=1)
-        weights_i2t.fill_diagonal_(0)
-        weights_t2i.fill_diagonal_(0)
-        neg_img = torch.multinomial(weights_t2i, 1).squeeze(1)
-        neg_txt = torch.multinomial(weights_i2t, 1).squeeze(1)
+        neg_img, neg_txt = _draw_negatives(sim_i2t, sim_t2i, bsz)
         images_neg = all_image[neg_img]
         text_ids_neg = all_text_ids[neg_txt]
         text_masks_neg = all_text_masks[neg_txt]

@@ -196,6 +196,7 @@ class ViLTransformerSS(nn.Module):
         self.fuse_unimodal_passes = os.environ.get("VLM_FUSE_UNIMODAL", "1") != "0"
         self._flat = None
         self._idx_cache = {}
+        self._ones_cache = {}
         self._grad_hook = None
         self._gram = None
         self.trainer = None
@@ -349,22 +350,62 @@ class ViLTransformerSS(nn.Module):
         e = e + self.token_type_embeddings.weight[0]
         return e.reshape(-1, e.shape[-1])
 
+    def _text_spec(self, text_ids):
+        """engine.TextSpec for the fused front end (the text rows made in place by ONE launch inside engine.pass_rows), or None
+        when the stock path has to run: a replaced dropout module, parameters outside the flat buffers, a width the kernel
+        does not take.  Train-mode dropout: a uniform draw per element, kept where u >= p (nn.Dropout's Bernoulli(1 - p) keep,
+        scale 1 / (1 - p)); `text_embeddings.dropout_source(B, T, D) -> keep mask` injects the draw (parity tests)."""
+        te = self.text_embeddings
+        w = te.word_embeddings.weight
+        D = w.shape[1]
+        if (type(te.dropout) is not nn.Dropout or getattr(w, "_vlm_flat", None) is None or not w.is_cuda or D % 4 or D > 1024
+                or text_ids.dtype != torch.int64 or not text_ids.is_cuda):
+            return None
+        u, p, scale = None, 0.0, 1.0
+        if self.training and te.dropout.p > 0.0:
+            n = text_ids.numel()
+            scale = 1.0 / (1.0 - te.dropout.p)
+            src = getattr(te, "dropout_source", None)
+            if src is not None:
+                u, p = src(text_ids.shape[0], text_ids.shape[1], D).to(device=w.device, dtype=torch.float32).reshape(n, D).contiguous(), 0.5
+            else:
+                u, p = torch.rand(n, D, device=w.device, dtype=torch.float32), te.dropout.p
+        ln = te.LayerNorm
+        return engine.TextSpec(text_ids.contiguous(), w, te.word_embeddings.padding_idx, te.token_type_embeddings.weight, ln.weight, ln.bias,
+                               ln.eps, u, p, scale)
+
+    def _text_rows_any(self, text_ids, text_masks, spec):
+        """The text rows as a tensor (paths that concatenate them themselves, text-only passes)."""
+        if spec is None:
+            return self._text_rows(text_ids, text_masks)
+        tr = self.transformer
+        pe = tr.patch_embed
+        return engine.pass_rows(None, None, pe.proj.weight, pe.proj.bias, tr.cls_token, self.token_type_embeddings.weight, 0,
+                                pe.patch_size[0], text=spec)
+
     def _image_rows(self, img, image_token_type_idx=1, mask_image=False, bool_masked_pos=None):
         x, x_mask, _, _ = self.transformer.visual_embed(img, max_image_len=self.hparams.config["max_image_len"],
                                                         mask_it=mask_image, bool_masked_pos=bool_masked_pos)
         x = x + self.token_type_embeddings.weight[image_token_type_idx]
         return x.reshape(-1, x.shape[-1]), x_mask, x.shape[1]
 
-    def _pass_rows(self, trows, img, image_token_type_idx=1):
-        """x = [text rows ; image rows] of a pass with the image side of visual_embed fused into the patch-embed GEMM
-        (engine.pass_rows).  -> (x, image mask of ones [B, I], I)."""
+    def _pass_rows(self, trows, img, image_token_type_idx=1, text=None, mask_like=None):
+        """x = [text rows ; image rows] of a pass with the image side of visual_embed fused into the patch-embed GEMM and, given a
+        TextSpec, the text side made in place (engine.pass_rows).  -> (x, image mask of ones [B, I] in mask_like's dtype, I)."""
         tr = self.transformer
         pe = tr.patch_embed
         x = engine.pass_rows(trows, img, pe.proj.weight, pe.proj.bias, tr.cls_token, self.token_type_embeddings.weight,
-                             image_token_type_idx, pe.patch_size[0])
+                             image_token_type_idx, pe.patch_size[0], text=text)
         I = 1 + pe.num_patches if img.shape[-1] == pe.img_size[1] and img.shape[-2] == pe.img_size[0] \
             else 1 + (img.shape[-2] // pe.patch_size[0]) * (img.shape[-1] // pe.patch_size[1])
-        return x, torch.ones(img.shape[0], I, device=img.device), I
+        dt = mask_like.dtype if mask_like is not None else torch.float32
+        key = (img.shape[0], I, dt, str(img.device))
+        ones = self._ones_cache.get(key)
+        if ones is None:  # a constant: one fill per geometry instead of one (plus a cast) per pass
+            if len(self._ones_cache) > 16:
+                self._ones_cache.clear()
+            ones = self._ones_cache[key] = torch.ones(img.shape[0], I, device=img.device, dtype=dt)
+        return x, ones, I
 
     def _final_norm(self, x):
         n = self.transformer.norm
@@ -409,8 +450,11 @@ class ViLTransformerSS(nn.Module):
         text_labels = batch[f"text_labels{do_mlm}"]
         text_masks = batch["text_masks"]
         B, T = text_ids.shape
-        trows = self._text_rows(text_ids, text_masks)
+        spec = self._text_spec(text_ids)
+        trows = None if spec is not None else self._text_rows(text_ids, text_masks)
         keep1 = None
+        if (image_embeds is not None or image_masks is not None or mask_image) and trows is None:
+            trows = self._text_rows_any(text_ids, text_masks, spec)
         if image_embeds is not None or image_masks is not None:
             # precomputed visual_embed output (reference :1092-1108; the reference itself then fails at its result dict,
             # `"image": img` with img unbound -- here the entry is None).  Both must be given, as there (image_masks.type_as).
@@ -427,7 +471,7 @@ class ViLTransformerSS(nn.Module):
             x = torch.cat([trows, irows], 0)
         else:
             img = batch[imgkey][0]
-            x, image_masks, I = self._pass_rows(trows, img, image_token_type_idx)
+            x, image_masks, I = self._pass_rows(trows, img, image_token_type_idx, spec, text_masks)
         image_masks = image_masks.type_as(text_masks)
         index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
             else self.text_imag_relative_position_index
@@ -437,12 +481,10 @@ class ViLTransformerSS(nn.Module):
         for blk in self.transformer.blocks:
             x = blk.run(x, pc, 2, self._hook())
         x = self._final_norm(x)
-        D = x.shape[-1]
-        text_feats = x[: B * T].view(B, T, D)
-        image_feats = x[B * T:].view(B, I, D)
-        cls_feats = self.pooler(text_feats)
+        text_feats, image_feats, text_cls, _ = engine.feature_views(x, B, T, I)
+        cls_feats = self.pooler(text_feats, cls_rows=text_cls)
         return {"text_feats": text_feats, "image_feats": image_feats, "cls_feats": cls_feats,
-                "raw_cls_feats": text_feats[:, 0], "image_labels": None, "image_masks": image_masks, "image": img,
+                "raw_cls_feats": text_cls, "image_labels": None, "image_masks": image_masks, "image": img,
                 "text_labels": text_labels, "text_ids": text_ids, "text_masks": text_masks, "patch_index": None}
 
     def _unimodal(self, x, pc, type_id, with_vlffn):
@@ -471,7 +513,7 @@ class ViLTransformerSS(nn.Module):
         text_labels = batch[f"text_labels{do_mlm}"]
         text_masks = batch["text_masks"]
         B, T = text_ids.shape
-        x = self._text_rows(text_ids, text_masks)
+        x = self._text_rows_any(text_ids, text_masks, self._text_spec(text_ids))
         index = self.text_relative_position_index
         if self.max_vl_text_len is not None and T != index.shape[0]:
             index = index[:T, :T]
@@ -494,12 +536,14 @@ class ViLTransformerSS(nn.Module):
         imgkey = f"image_{image_token_type_idx - 1}" if f"image_{image_token_type_idx - 1}" in batch else "image"
         img = batch[imgkey][0]
         B, T = text_ids.shape
-        trows = self._text_rows(text_ids, text_masks)
+        spec = self._text_spec(text_ids)
         if mask_image:
+            trows = self._text_rows_any(text_ids, text_masks, spec)
             irows, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
             x = torch.cat([trows, irows], 0)
         else:
-            x, image_masks, I = self._pass_rows(trows, img, image_token_type_idx)
+            trows = None if spec is not None else self._text_rows(text_ids, text_masks)
+            x, image_masks, I = self._pass_rows(trows, img, image_token_type_idx, spec, text_masks)
         image_masks = image_masks.type_as(text_masks)
         index = self.vl_text_imag_relative_position_index if self.max_vl_text_len is not None \
             else self.text_imag_relative_position_index
@@ -519,29 +563,32 @@ class ViLTransformerSS(nn.Module):
                 v = self.transformer.blocks[i].run(v, pc, 4, self._hook())
             v = self._final_norm(v)
         x = self._final_norm(x)
-        D = x.shape[-1]
-        nt = B * T
-        text = self._text_result(x[:nt].view(B, T, D), v[:nt].view(B, T, D) if v is not None else None, text_labels,
-                                 text_ids, text_masks)
-        image = self._image_result(x[nt:].view(B, I, D), v[nt:].view(B, I, D) if v is not None else None, image_masks,
-                                   text_masks)
+        # the views the two result dicts expose, one autograd node per feature matrix (engine.feature_views)
+        lt, li, lt_cls, li_cls = engine.feature_views(x, B, T, I)
+        vt, vi, vt_cls, vi_cls = engine.feature_views(v, B, T, I) if v is not None else (None, None, None, None)
+        text = self._text_result(lt, vt, text_labels, text_ids, text_masks, lt_cls, vt_cls)
+        image = self._image_result(li, vi, image_masks, text_masks, li_cls, vi_cls)
         return image, text
 
-    def _text_result(self, l, v, text_labels, text_ids, text_masks):
-        cls = self._l2(self.ifm_text_proj(l[:, 0])) if getattr(self, "ifm_text_proj", None) is not None else None
-        cls_v = self._l2(self.ifm_vl_text_proj(v[:, 0])) if v is not None else None
+    def _text_result(self, l, v, text_labels, text_ids, text_masks, l_cls=None, v_cls=None):
+        l_cls = l[:, 0] if l_cls is None else l_cls
+        v_cls = (v[:, 0] if v_cls is None else v_cls) if v is not None else None
+        cls = self._l2(self.ifm_text_proj(l_cls)) if getattr(self, "ifm_text_proj", None) is not None else None
+        cls_v = self._l2(self.ifm_vl_text_proj(v_cls)) if v is not None else None
         return {"text_feats": l, "image_feats": None, "cls_feats": cls, "cls_vlffn_feats": cls_v,
-                "raw_cls_feats": l[:, 0], "image_labels": None, "image_masks": None, "text_labels": text_labels,
+                "raw_cls_feats": l_cls, "image_labels": None, "image_masks": None, "text_labels": text_labels,
                 "text_ids": text_ids, "text_masks": text_masks, "patch_index": None}
 
-    def _image_result(self, vf, v, image_masks, text_masks):
+    def _image_result(self, vf, v, image_masks, text_masks, vf_cls=None, v_cls=None):
+        vf_cls = vf[:, 0] if vf_cls is None else vf_cls
+        v_cls = (v[:, 0] if v_cls is None else v_cls) if v is not None else None
         if getattr(self, "ifm_image_proj", None) is not None:
-            cls = self._l2(self.ifm_image_proj(vf[:, 0]))
+            cls = self._l2(self.ifm_image_proj(vf_cls))
         else:
-            cls = self.pooler(vf)
-        cls_v = self._l2(self.ifm_vl_image_proj(v[:, 0])) if v is not None else None
+            cls = self.pooler(vf, cls_rows=vf_cls)
+        cls_v = self._l2(self.ifm_vl_image_proj(v_cls)) if v is not None else None
         return {"text_feats": None, "image_feats": vf, "cls_feats": cls, "cls_vlffn_feats": cls_v,
-                "raw_cls_feats": vf[:, 0], "image_labels": None, "image_masks": image_masks, "text_labels": None,
+                "raw_cls_feats": vf_cls, "image_labels": None, "image_masks": image_masks, "text_labels": None,
                 "text_ids": None, "text_masks": text_masks, "patch_index": None}
 
     def infer_text(self, batch, mask_text=False):  # :1159-1223
@@ -559,7 +606,7 @@ class ViLTransformerSS(nn.Module):
         if mask_image:
             x, image_masks, I = self._image_rows(img, image_token_type_idx, mask_image, bool_masked_pos)
         else:
-            x, image_masks, I = self._pass_rows(None, img, image_token_type_idx)
+            x, image_masks, I = self._pass_rows(None, img, image_token_type_idx, None, text_masks)
         image_masks = image_masks.type_as(text_masks)
         pc = self._pass_ctx(ops.Seq(B, 0, I), self.hparams.config["num_heads"],
                             self.get_rel_pos_bias(self.relative_position_index, 0))
@@ -609,7 +656,7 @@ class ViLTransformerSS(nn.Module):
     def training_step(self, batch, batch_idx=0):
         vilt_utils.set_task(self)
         output = self(batch)
-        return sum([v for k, v in output.items() if "loss" in k])
+        return engine.weighted_sum([v for k, v in output.items() if "loss" in k])
 
     def validation_step(self, batch, batch_idx=0):
         vilt_utils.set_task(self)
