@@ -140,19 +140,34 @@ __global__ __launch_bounds__(256) void text_rows_bwd_kernel(const float* __restr
     part[(size_t)blockIdx.x * 4 * D + e] = sh[e] + sh[4 * D + e] + sh[8 * D + e] + sh[12 * D + e];
 }
 
-// dst[k][c] += sum over the partials p and the vectors j selected by mask[k] (bit j) of part[p][j][c].
+// dst[k][c] += sum over the partials p and the vectors j selected by mask[k] (bit j) of part[p][j][c].  A workgroup owns 16
+// columns; its 64 thread groups take every 64th partial each and meet in LDS: a thread reads nparts / 64 * nvec values instead of
+// nparts * nvec (the first form, one thread per column over all 512 partials in 3 workgroups, took 280 us per call).
 struct fold_dst_t { float* dst[4]; unsigned mask[4]; };
-__global__ __launch_bounds__(256) void fold_parts_kernel(const float* __restrict__ part, int nparts, int nvec, int D, fold_dst_t f, int ndst) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= D) return;
+#define FOLD_COLS 16
+#define FOLD_GROUPS 64
+__global__ __launch_bounds__(1024) void fold_parts_kernel(const float* __restrict__ part, int nparts, int nvec, int D, fold_dst_t f, int ndst) {
+  __shared__ float sh[FOLD_GROUPS][4][FOLD_COLS];
+  const int cl = threadIdx.x % FOLD_COLS, grp = threadIdx.x / FOLD_COLS, c = blockIdx.x * FOLD_COLS + cl;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < nparts; ++p)
-    for (int j = 0; j < nvec; ++j) s[j] += part[((size_t)p * nvec + j) * D + c];
-  for (int k = 0; k < ndst; ++k) {
-    if (!f.dst[k]) continue;
-    float v = 0.f;
-    for (int j = 0; j < nvec; ++j) if (f.mask[k] >> j & 1) v += s[j];
-    f.dst[k][c] += v;
+  if (c < D)
+    for (int p = grp; p < nparts; p += FOLD_GROUPS)
+      for (int j = 0; j < nvec; ++j) s[j] += part[((size_t)p * nvec + j) * D + c];
+  for (int j = 0; j < 4; ++j) sh[grp][j][cl] = s[j];
+  __syncthreads();
+  if (grp < nvec && c < D) {  // thread group j finishes vector j (fixed order: deterministic)
+    float t = 0.f;
+    for (int g = 0; g < FOLD_GROUPS; ++g) t += sh[g][grp][cl];
+    sh[0][grp][cl] = t;
+  }
+  __syncthreads();
+  if (grp == 0 && c < D) {
+    for (int k = 0; k < ndst; ++k) {
+      if (!f.dst[k]) continue;
+      float v = 0.f;
+      for (int j = 0; j < nvec; ++j) if (f.mask[k] >> j & 1) v += sh[0][j][cl];
+      f.dst[k][c] += v;
+    }
   }
 }
 
@@ -169,7 +184,7 @@ extern "C" int vlm_text_rows_fwd(const int64_t* ids, int n, const float* word, i
   return VLM_OK;
 }
 
-#define FR_TEXT_PARTS 64
+#define FR_TEXT_PARTS 256
 extern "C" size_t vlm_text_rows_bwd_ws_floats(int D) { return (size_t)FR_TEXT_PARTS * 4 * D; }
 
 extern "C" int vlm_text_rows_bwd(const float* g, int ld_g, const int64_t* ids, int n, const float* word, int ld_word, const float* add0,
@@ -184,7 +199,7 @@ extern "C" int vlm_text_rows_bwd(const float* g, int ld_g, const int64_t* ids, i
                      ld_word, add0, gamma, stats, u, p, scale, D, d_word, padding_idx, ws);
   VLM_CHECK_LAUNCH();
   fold_dst_t f = {{d_add1, d_beta, d_gamma, d_add0}, {1u, 2u, 4u, 8u}};
-  hipLaunchKernelGGL(fold_parts_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, parts, 4, D, f, 4);
+  hipLaunchKernelGGL(fold_parts_kernel, dim3((D + FOLD_COLS - 1) / FOLD_COLS), dim3(1024), 0, (hipStream_t)stream, ws, parts, 4, D, f, 4);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(256) void image_rows_bwd_kernel(const float* __rest
   }
 }
 
-#define FR_IMAGE_PARTS 512
+#define FR_IMAGE_PARTS 1024
 extern "C" size_t vlm_image_rows_bwd_ws_floats(int D) { return (size_t)FR_IMAGE_PARTS * 2 * D; }
 
 // d_bias += patch sums; d_type_row += patch sums + lead sums; d_cls += lead sums (any of the three may be null).
@@ -253,7 +268,7 @@ extern "C" int vlm_image_rows_bwd(const float* g, int ld_g, int B, int rows, int
   hipLaunchKernelGGL(image_rows_bwd_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, g, ld_g, n, rows, D, (bf16_t*)g16, ws);
   VLM_CHECK_LAUNCH();
   fold_dst_t f = {{d_bias, d_type_row, d_cls, nullptr}, {1u, 3u, 2u, 0u}};
-  hipLaunchKernelGGL(fold_parts_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, parts, 2, D, f, 3);
+  hipLaunchKernelGGL(fold_parts_kernel, dim3((D + FOLD_COLS - 1) / FOLD_COLS), dim3(1024), 0, (hipStream_t)stream, ws, parts, 2, D, f, 3);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }
