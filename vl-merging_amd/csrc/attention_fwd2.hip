@@ -256,7 +256,9 @@ int att_fwd2_launch(const attn_params_t& p, hipStream_t s) {
   if (!enabled || !att_fwd2_eligible(p)) return 0;
   const int nt = att_num_tiles(p.seq.n0, p.seq.n1, p.seq.pos1, p.mode);
   dim3 grid(att_grid_size(nt, (p.seq.B + 1) / 2, p.H)), block(ATT_THREADS);
-  hipLaunchKernelGGL(attn_fwd2_kernel, grid, block, 0, s, p);
+  // diagnostic (docs/experiments.md, round 6): VLM_ATT_FWD2_LDS_PAD bytes of unused dynamic LDS leave room for ONE workgroup per CU
+  static const int lds_pad = [] { const char* e = getenv("VLM_ATT_FWD2_LDS_PAD"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(attn_fwd2_kernel, grid, block, (size_t)lds_pad, s, p);
   if (hipGetLastError() != hipSuccess) return VLM_ERR_LAUNCH;
   return 1;
 }
