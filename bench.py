@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -867,6 +868,10 @@ def main():
     timer.on = False
     exposed_comm_ms = reducer.exposed_wait_ms() / max(1, args.steps)
     loss_val = float(loss.detach())
+    if not math.isfinite(loss_val):
+        # a step whose activations are NaN runs FASTER (less switching power, higher clocks: docs/experiments.md round 6): a rate
+        # measured on such a run is not a measurement
+        raise RuntimeError("bench: the last timed step's loss is %r -- the timed steps did not compute the workload" % loss_val)
     total_samples = args.batch * world * args.steps
     value = total_samples / dt
     _, _, flop384, cfg_index, task_text = TASKS[args.task]

@@ -21,7 +21,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno
 
 
 def _deps_mtime():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]  # .inc: the generated asm streams
     hs.append(os.path.join(HERE, "..", "include", "vlm_hip.h"))
     return max(os.path.getmtime(h) for h in hs)
 

@@ -291,6 +291,8 @@ static bool att_dq2_eligible(const attn_params_t& p) {
 static int att_dq2_launch(const attn_bwd_params_t& bp, dim3 grid, hipStream_t s) {
   static const int enabled = [] { const char* e = getenv("VLM_ATT_DQ2"); return e ? atoi(e) : 1; }();
   if (!enabled || !att_dq2_eligible(bp.f)) return 0;
-  hipLaunchKernelGGL(attn_bwd_dq2_kernel, grid, dim3(ATT_THREADS), 0, s, bp);
+  // diagnostic: VLM_ATT_DQ2_LDS_PAD bytes of unused dynamic LDS leave room for fewer workgroups per CU (docs/experiments.md, round 6)
+  static const int lds_pad = [] { const char* e = getenv("VLM_ATT_DQ2_LDS_PAD"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(attn_bwd_dq2_kernel, grid, dim3(ATT_THREADS), (size_t)lds_pad, s, bp);
   return 1;
 }

@@ -33,7 +33,7 @@ typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
 typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
 
 // v88..v159 (S, P, K / V fragments), v168..v179 (statistics operands) and v186..v191 (temporaries) belong to the stream;
-// v0..v31 stay with the compiler
+// v0..v23 stay with the compiler (v24..v31: the second bias operand set, an operand of the statement)
 #define F2_CLOBBER_V \
   "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
   "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", \
@@ -71,9 +71,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
 
   // ---- prologue (1): everything that goes to memory first -- bias rows of tile 0, blocks 0 and 1 of both samples, sample 0's
   // pieces of block 2 (one LDS-DMA piece = this wave's 8 rows of a 32-key block), the mask words
-  u32x4 b0w[2];  // key block 0's operands (the stream re-requests the set for every following block)
+  u32x4 b0w[2], b1w[2];  // key blocks 0 and 1's operands (two sets; the stream re-requests a set for the NEXT trip's block)
   b0w[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff, 0, 0));
   b0w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff + 1024, 0, 0));
+  b1w[0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff + 2048, 0, 0));
+  b1w[1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, bvoff + 3072, 0, 0));
   const uint32_t drow = (uint32_t)wave * 8u + (uint32_t)(lane >> 3), c16 = lane & 7;
   // K: the image of attention_bwd_dkvb.h (chunk ^ f(row): conflict-free for the LDS-DMA writes AND ds_read_b128; the round-2 row
   // image chunk ^ (row & 7) is 2-way on every ds_read_b128, tools/lds_layout_check.py); LDS-DMA writes linearly, so the swizzle
@@ -168,9 +170,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
   const u32x4 rb4 = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ba),
                      (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(ba >> 32) & 0xffffu)),
                      (uint32_t)__builtin_amdgcn_readfirstlane((int)rb_bytes), 0x00020000u};
-  u32x8 bwv;
+  u32x8 bwv, bw1v;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { bwv[e] = b0w[0][e]; bwv[4 + e] = b0w[1][e]; }
+  for (int e = 0; e < 4; ++e) { bwv[e] = b0w[0][e]; bwv[4 + e] = b0w[1][e]; bw1v[e] = b1w[0][e]; bw1v[4 + e] = b1w[1][e]; }
   // the stream's scalar state: the DMA block is block 2 (its sample-1 pieces are the stream's first two)
   u32x8 sc;
   {
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
   ATT_STAMP(20);
   f32x16 o00, o01, o10, o11;
   u32x16 ad_out;
-  u32x8 sc_out, bw_out;
+  u32x8 sc_out, bw_out, bw1_out;
   float m_out[2], l_out[4];
   // the thread index goes THROUGH the statement: whatever the epilogue needs per lane (its rows, its validity) is recomputed
   // from the copy that comes out, so that no per-lane value has to stay in a register across the stream (the stream owns
@@ -204,8 +206,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd2_kernel(const attn_pa
 #include "attention_fwd2_body.inc"
       : "={a[0:15]}"(o00), "={a[16:31]}"(o01), "={a[32:47]}"(o10), "={a[48:63]}"(o11), "={v180}"(m_out[0]), "={v181}"(m_out[1]),
         "={v182}"(l_out[0]), "={v183}"(l_out[1]), "={v184}"(l_out[2]), "={v185}"(l_out[3]), "={v[160:167]}"(bw_out),
-        "={s[48:55]}"(sc_out), "={v[32:47]}"(ad_out), "+v"(tid2)
-      : "{v[48:55]}"(cs), "{v[56:71]}"(qv[0]), "{v[72:87]}"(qv[1]), "10"(bwv), "11"(sc), "12"(ad), "{s[40:43]}"(rkv4),
+        "={s[48:55]}"(sc_out), "={v[32:47]}"(ad_out), "={v[24:31]}"(bw1_out), "+v"(tid2)
+      : "{v[48:55]}"(cs), "{v[56:71]}"(qv[0]), "{v[72:87]}"(qv[1]), "10"(bwv), "11"(sc), "12"(ad), "13"(bw1v), "{s[40:43]}"(rkv4),
         "{s[44:47]}"(rb4)
       : F2_CLOBBER_V, "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "vcc", "scc", "memory");
 

@@ -181,10 +181,16 @@ def dma_piece(j, st):
 
 
 def dma_offsets():
-    t = "s%d" % S_TMP
-    return [salu("s_min_i32 %s, s%d, 32" % (t, S_REM), [t]), salu("s_max_i32 %s, %s, 0" % (t, t), [t]),
-            valu("v_cmp_gt_u32_e32 vcc, %s, v%d" % (t, V_ADDR + 11), [t], ["vcc"]),
-            valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF, V_ADDR + 14, V_ADDR + 10), ["vcc"], ["v%d" % V_DOFF])]
+    """voffset of the DMA block with every row IN RANGE (a row at or past the valid row count reads the last valid row: finite
+    data whose scores the dense bias switches off).  An instruction whose lanes are ALL out of range retires at once and out of
+    order, and the counted s_waitcnt vmcnt(n) then pass with an older, real piece still in flight: attn_fwd2_gen.py."""
+    t = "v%d" % (V_DOFF + 1)
+    return [valu("v_subrev_u32_e32 %s, s%d, v%d" % (t, S_REM, V_ADDR + 11), ["v%d" % (V_ADDR + 11)], [t]),   # row - rem
+            valu("v_add_u32_e32 %s, 1, %s" % (t, t), [t], [t]),
+            valu("v_max_i32_e32 %s, 0, %s" % (t, t), [t], [t]),                                              # rows to step back
+            valu("v_mul_u32_u24_e32 %s, s%d, %s" % (t, S_STEP, t), [t], [t]),                                 # x 32 rows of bytes
+            valu("v_lshrrev_b32_e32 %s, 5, %s" % (t, t), [t], [t]),
+            valu("v_sub_u32_e32 v%d, v%d, %s" % (V_DOFF, V_ADDR + 10, t), [t, "v%d" % (V_ADDR + 10)], ["v%d" % V_DOFF])]
 
 
 def dma_advance():

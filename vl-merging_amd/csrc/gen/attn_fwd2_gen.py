@@ -34,8 +34,10 @@ V_S = 88         # S[s] = v[88 + 16 s : +15]
 V_P = 120        # P = v[120:127]: one buffer (a unit's P is consumed before the next unit's conversions start)
 V_KF = 128       # K fragments, 4 x 4
 V_VF = 144       # V^T fragments, (s2, db) -> 144 + 4 (2 s2 + db)
-V_BW = 160       # bias operands of the CURRENT key block w[j] -> 160 + 4 j (re-requested for the next block once both samples'
-                 # selection MFMAs have read them)
+V_BW = 160       # bias operands of a trip's FIRST key block, w[j] -> 160 + 4 j; the SECOND block's set is V_BW1.  A set is
+                 # re-requested for the NEXT trip's block as soon as both samples' selection MFMAs have read it: a whole trip of
+                 # flight (one set re-requested for the very next block gave the load ~500 cycles against an L2 round trip of ~700)
+V_BW1 = 24       # v24..v31 (below the stream's v32..v191: handed in and out through the statement's operands)
 V_KONE = 168     # key side of the statistics step: dword 0 = (1, 1) in the lower half-wave, dword 1 = mask word
 V_QM = 172       # query side: v[172 + 4 s : +3]; dword 0 = (-m hi, -m lo), dword 1 = (1, 0)
 V_M = 180        # running reference point m_s
@@ -55,6 +57,8 @@ S_STEP = 55      # 32 * ld * 2
 S_T = 57
 S_NL = 58        # s[58:59]: all ones while a next trip exists
 S_BOFF = 60      # bias scalar offset of the current trip's SECOND key block (trip * 4096 + 2048)
+S_PF = 56        # bias prefetch base: the NEXT trip's first key block (S_BOFF + 2048) while a next trip exists, else this
+                 # trip's own (S_BOFF - 2048): the last trip's requests stay inside the table (see dma_offsets)
 S_TMP = 61
 S_LO = 62        # s[62:63] = lower half-wave
 
@@ -69,7 +73,7 @@ def P(s, half): return rr("v", V_P + 4 * half, 4)
 def Pr(s, d): return "v%d" % (V_P + d)
 def KF(ss): return rr("v", V_KF + 4 * ss, 4)
 def VF(s2, db): return rr("v", V_VF + 4 * (2 * s2 + db), 4)
-def BW(kb, j): return rr("v", V_BW + 4 * j, 4)
+def BW(kb, j): return rr("v", (V_BW1 if kb else V_BW) + 4 * j, 4)
 def QF(s, ss): return rr("v", V_Q + 16 * s + 4 * ss, 4)
 def QM(s): return rr("v", V_QM + 4 * s, 4)
 def O(s, db): return rr("a", A_O + 32 * s + 16 * db, 16)
@@ -234,12 +238,20 @@ def dma_piece(j, st, name):
 
 
 def dma_offsets():
-    """Range-masked voffsets of the DMA block: rows >= the block's valid row count point out of range (zero fill)."""
-    t = "s%d" % S_TMP
-    return [salu("s_min_i32 %s, s%d, 32" % (t, S_REM), [t]), salu("s_max_i32 %s, %s, 0" % (t, t), [t]),
-            valu("v_cmp_gt_u32_e32 vcc, %s, v%d" % (t, V_ADDR + 10), [t], ["vcc"]),
-            valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF, V_ADDR + 13, V_ADDR + 8), ["vcc"], ["v%d" % V_DOFF]),
-            valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_DOFF + 1, V_ADDR + 13, V_ADDR + 9), ["vcc"], ["v%d" % (V_DOFF + 1)])]
+    """voffsets of the DMA block with every row IN RANGE: a row at or past the block's valid row count (S_REM, may be <= 0 for a
+    block past the end) reads the LAST VALID row instead -- finite data whose scores the dense bias switches off (ATT_NEG_BIG
+    for keys outside the range).  An out-of-range offset (hardware zero fill) would do for the arithmetic, but an instruction
+    whose lanes are ALL out of range retires at once and out of order: the counted s_waitcnt vmcnt(n) in front of the barriers
+    then pass with an older, real piece still in flight (seen as wrong rows of sample 1 -- the youngest pieces -- at two
+    workgroups per CU)."""
+    t = "v%d" % (V_T + 3)
+    return [valu("v_subrev_u32_e32 %s, s%d, v%d" % (t, S_REM, V_ADDR + 10), ["v%d" % (V_ADDR + 10)], [t]),   # row - rem
+            valu("v_add_u32_e32 %s, 1, %s" % (t, t), [t], [t]),
+            valu("v_max_i32_e32 %s, 0, %s" % (t, t), [t], [t]),                                              # rows to step back
+            valu("v_mul_u32_u24_e32 %s, s%d, %s" % (t, S_STEP, t), [t], [t]),                                 # x 32 rows of bytes
+            valu("v_lshrrev_b32_e32 %s, 5, %s" % (t, t), [t], [t]),
+            valu("v_sub_u32_e32 v%d, v%d, %s" % (V_DOFF, V_ADDR + 8, t), [t, "v%d" % (V_ADDR + 8)], ["v%d" % V_DOFF]),
+            valu("v_sub_u32_e32 v%d, v%d, %s" % (V_DOFF + 1, V_ADDR + 9, t), [t, "v%d" % (V_ADDR + 9)], ["v%d" % (V_DOFF + 1)])]
 
 
 def dma_advance():
@@ -252,11 +264,12 @@ def dma_advance():
 
 
 def bias_reload(kb, after):
-    """Request key block kb's operands (kb = 1: this trip's second block, kb = 0: the next trip's first)."""
+    """Request the NEXT trip's key block kb into set kb (its current contents have been read by both samples' selection MFMAs)."""
     out = []
     for j in range(2):
-        out.append(Op("buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen offset:%d" % (BW(kb, j), V_ADDR + 11, S_RB, S_RB + 3, S_BOFF, (2 * (1 - kb) + j) * 1024),
-                      "vmem", ["v%d" % (V_ADDR + 11)], regs("v", V_BW + 4 * j, 4), tag="bias%d" % kb, after=after))
+        soff, imm = S_PF, kb * 2048 + j * 1024
+        out.append(Op("buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen offset:%d" % (BW(kb, j), V_ADDR + 11, S_RB, S_RB + 3, soff, imm),
+                      "vmem", ["v%d" % (V_ADDR + 11)], regs("v", (V_BW1 if kb else V_BW) + 4 * j, 4), tag="bias%d" % kb, after=after))
     return out
 
 
@@ -275,23 +288,24 @@ def trip(x, half):
     body = []
     body += [salu("s_add_u32 s%d, s%d, 1" % (S_TMP, S_T), ["s%d" % S_TMP]),
              salu("s_cmp_lt_u32 s%d, s%d" % (S_TMP, S_NT), ["scc"]),
-             salu("s_cselect_b64 s[%d:%d], -1, 0" % (S_NL, S_NL + 1), ["s%d" % S_NL, "s%d" % (S_NL + 1)], ["scc"])]
+             salu("s_cselect_b64 s[%d:%d], -1, 0" % (S_NL, S_NL + 1), ["s%d" % S_NL, "s%d" % (S_NL + 1)], ["scc"]),
+             salu("s_cselect_b32 s%d, 0x1000, 0" % S_PF, ["s%d" % S_PF], ["scc"]),           # (one literal per instruction)
+             salu("s_add_u32 s%d, s%d, s%d" % (S_PF, S_PF, S_BOFF), ["s%d" % S_PF], ["s%d" % S_PF, "s%d" % S_BOFF]),
+             salu("s_sub_u32 s%d, s%d, 0x800" % (S_PF, S_PF), ["s%d" % S_PF], ["s%d" % S_PF])]
     tag = "ab"[half]
     for u in (1, 2, 3):
         fill = v_reads(u - 1, st[u - 1], after=1) + exp_cvt(u - 1)
         if u & 1:
-            fill += bias_reload(1 - (u >> 1), after=2)
+            fill += bias_reload(u >> 1, after=2)   # unit u = (kb, 1) is the second and last reader of set kb in this trip
         if u == 1:
             d = dma_piece(2, nx, tag + "A")
         else:
             d = dma_piece(2 * (u - 2), (x + 3) % NSTAGE, tag + "B")
         d[0].after = d[1].after = 1
         spread(fill, d, 9)
-        lead = k_reads(u, st[u])
-        if u == 2:
-            # block x + 1 has landed for every wave (its pieces were issued in the previous trip's phases 3-6)
-            lead = [Op("s_nop 0", "salu", needs=["dma%sB3" % "ba"[half]]), Op("s_barrier", "salu")] + lead
-        body += interleave(chain(u), fill, lead=lead)
+        # (the K fragments of unit u were requested at the head of the O phase before this one: an LDS round trip is ~150 cycles,
+        # and as the lead of this phase it stood between the two bias-selection MFMAs and the first K MFMA of every chain)
+        body += interleave(chain(u), fill)
         if u == 1:
             d = dma_piece(3, nx, tag + "A")
             adv = dma_advance()
@@ -303,22 +317,29 @@ def trip(x, half):
             adv = dma_advance()
         for o in adv:
             o.after = 3
-        body += interleave(pv(u - 1), d + max_decide(u, "%s%d" % (tag, u), after=1) + adv)
-    # trip boundary: the next trip's first block has landed (pieces 0, 1 in the previous trip's phases 7-8, pieces 2, 3 above)
-    body.append(Op("s_nop 0", "salu", needs=["dma%sA3" % tag]))
-    body.append(Op("s_barrier", "salu"))
-    body += [salu("s_cmp_eq_u32 s%d, 0" % S_T, ["scc"]),
-             salu("s_cselect_b64 vcc, -1, 0", ["vcc"], ["scc"]),
-             valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_KMC, V_ADDR + 7, V_ADDR + 12), ["vcc"], ["v%d" % V_KMC])]
+        # head of the O phase: chain(u) has issued, the fragment registers are free -> request unit u + 1's K fragments
+        if u == 1:
+            # block x + 1 has landed for every wave (its pieces were issued in the previous trip's phases 3-6)
+            lead = [Op("s_nop 0", "salu", needs=["dma%sB3" % "ba"[half]]), Op("s_barrier", "salu")] + k_reads(2, st[2])
+        elif u == 2:
+            lead = k_reads(3, st[3])
+        else:
+            # trip boundary: the next trip's first block has landed (pieces 0, 1 in the previous trip's phases 7-8, 2, 3 above)
+            lead = [Op("s_nop 0", "salu", needs=["dma%sA3" % tag]), Op("s_barrier", "salu"),
+                    salu("s_cmp_eq_u32 s%d, 0" % S_T, ["scc"]),
+                    salu("s_cselect_b64 vcc, -1, 0", ["vcc"], ["scc"]),
+                    valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_KMC, V_ADDR + 7, V_ADDR + 12), ["vcc"], ["v%d" % V_KMC])] + k_reads(0, nx)
+        body += interleave(pv(u - 1), d + max_decide(u, "%s%d" % (tag, u), after=1) + adv, lead=lead)
     # phase 7: A(0) of the next trip || exp/cvt(3), V reads of unit 3
     fill = v_reads(3, st[3], after=1) + exp_cvt(3)
     d = dma_piece(0, x, tag + "C")
     d[0].after = d[1].after = 1
     spread(fill, d, 9)
-    body += interleave(chain(0), fill, lead=k_reads(0, nx))
+    body += interleave(chain(0), fill)
     d = dma_piece(1, x, tag + "C")
     body += interleave(pv(3), d + [salu("s_add_u32 s%d, s%d, 0x1000" % (S_BOFF, S_BOFF), ["s%d" % S_BOFF], ["s%d" % S_BOFF]),
-                                   salu("s_add_u32 s%d, s%d, 1" % (S_T, S_T), ["s%d" % S_T])] + max_decide(0, tag + "0", guard_last=True, after=1))
+                                   salu("s_add_u32 s%d, s%d, 1" % (S_T, S_T), ["s%d" % S_T])] + max_decide(0, tag + "0", guard_last=True, after=1),
+                       lead=k_reads(1, (x + 2) % NSTAGE))
     return body
 
 
@@ -356,6 +377,7 @@ def build():
     # A(0) of trip 0 alone, then its maximum / decision
     pre += k_reads(0, 0)
     pre += chain(0)
+    pre += k_reads(1, 0)   # unit 1's fragments: the loop requests them one phase ahead, at the head of the O phase
     pre += max_decide(0, "pre", after=0)
 
     # ---------------------------------------------------------------- the loop: two trips per pass
@@ -390,7 +412,9 @@ def build():
         sites += [(tag + "1", 1), (tag + "2", 0), (tag + "3", 1), (tag + "0", 0)]
     for site, s in sites:
         tail += rare_block(site, s)
-    tail += ["L_done_%=:", "s_setprio 0", "s_nop 15", "s_nop 15"]
+    # the last trip has requested bias operands (and DMA pieces) for a trip that never runs: they must have landed before the
+    # statement ends -- the compiler takes the operand registers back and knows nothing of a load still in flight into them
+    tail += ["L_done_%=:", "s_setprio 0", "s_waitcnt vmcnt(0)", "s_nop 15", "s_nop 15"]
     text = emit(pre_h) + emit(body_h) + "".join(("" if l.endswith(":") else "  ") + l + "\n" for l in tail)
     return text, pre_h, body_h
 
