@@ -920,7 +920,10 @@ def bias_dense(bias_t, index16, seq, mode):
         raise L.VlmError("bias_dense: bad geometry (pos1 %% 8 == 0, pos1 >= n0)")
     outs = []
     for k_major in (0, 1):
-        out = torch.empty(n_cols, nbytes // 2, device=bias_t.device, dtype=torch.float16)
+        # 16 KiB of slack behind the last column: the attention streams request a block's operands up to a trip ahead, and the
+        # last trip of the last (head, query block) asks for tiles behind the table (never used, but they must be mapped)
+        flat = torch.empty(n_cols * (nbytes // 2) + 8192, device=bias_t.device, dtype=torch.float16)
+        out = flat[: n_cols * (nbytes // 2)].view(n_cols, nbytes // 2)
         L.check(L.get_lib().vlm_bias_dense(L.ptr(bias_t), n_cols, R, L.ptr(index16), _ld(index16), seq.n0, seq.n1, seq.pos1,
                                            mode, k_major, L.ptr(out), L.stream_ptr()), "vlm_bias_dense")
         outs.append(out)
