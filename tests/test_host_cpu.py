@@ -234,3 +234,58 @@ def test_every_named_config_of_the_reference_key_for_key(pkg):
     # the README's merged-model evaluations (README.md:205-231) parse: later words win, like sacred
     cfg = C.parse_cli(["with", "task_finetune_vqa_square_randaug_base_image384_ufo", "ufo", "image_size=480", "merge_weights=True"])
     assert cfg["loss_names"]["vqa"] == 1 and cfg["use_ufo"] and cfg["image_size"] == 480 and cfg["lr_mult"] == 10
+
+
+# ---- round 6: the host-side pieces around the front-end / head kernels (their CPU behaviour and dispatch rules) ---------------
+def test_round6_host_fallbacks_and_dispatch_rules(pkg, cfgmod, vm):
+    """What the one-launch paths fall back to, and when they refuse to engage, without a GPU:
+    feature_views / row_range are plain views on CPU (values and autograd as the slices they replace); weighted_sum is the torch
+    expression; the fused hard-negative draw engages only on CUDA (and never when torch.multinomial has been replaced); the text
+    front end declines (TextSpec None) for CPU parameters or a replaced dropout module; an op called with CPU tensors raises."""
+    engine = importlib.import_module("vl_merging_amd.engine")
+    ops = importlib.import_module("vl_merging_amd.ops")
+    L = importlib.import_module("vl_merging_amd._lib")
+    obj = importlib.import_module("vl_merging_amd.vilt.modules.objectives")
+    B, T, I, D = 2, 5, 3, 8
+    x = torch.randn(B * T + B * I, D, requires_grad=True)
+    text, image, tcls, icls = engine.feature_views(x, B, T, I)
+    assert torch.equal(text, x[: B * T].view(B, T, D)) and torch.equal(image, x[B * T:].view(B, I, D))
+    assert torch.equal(tcls, text[:, 0]) and torch.equal(icls, image[:, 0])
+    (tcls.sum() * 2 + icls.sum()).backward()
+    want = torch.zeros_like(x)
+    want[0:B * T:T] = 2.0
+    want[B * T::I] = 1.0
+    assert torch.equal(x.grad, want)
+    t = torch.randn(4, 3, 8, requires_grad=True)
+    r = engine.row_range(t, 1, None)
+    assert torch.equal(r, t[1:])
+    r.sum().backward()
+    assert float(t.grad[0].abs().max()) == 0.0 and float((t.grad[1:] - 1).abs().max()) == 0.0
+    a, b = torch.tensor(1.5, requires_grad=True), torch.tensor(-2.0, requires_grad=True)
+    s = engine.weighted_sum([a, b], [0.5, 2.0])
+    assert abs(float(s.detach()) - (0.75 - 4.0)) < 1e-6
+    s.backward()
+    assert float(a.grad) == 0.5 and float(b.grad) == 2.0
+    assert float(engine.weighted_sum([a.detach(), b.detach()])) == -0.5
+    # the hard-negative draw on CPU: the torch formulation (own pair never drawn, forced choice at n = 2)
+    sim = torch.randn(6, 6)
+    for _ in range(5):
+        ni, nt = obj._draw_negatives(sim, sim.t(), 6)
+        assert bool((ni != torch.arange(6)).all()) and bool((nt != torch.arange(6)).all())
+    two = torch.randn(2, 2)
+    ni, nt = obj._draw_negatives(two, two.t(), 2)
+    assert ni.tolist() == [1, 0] and nt.tolist() == [1, 0]
+    # the text front end declines on CPU and for a replaced dropout
+    cfg = tiny_cfg(cfgmod, "ufo")
+    model = vm.ViLTransformerSS(cfg, *cfgmod.routing_configs(cfg))
+    ids = torch.zeros(2, 40, dtype=torch.long)
+    assert model._text_spec(ids) is None
+    model.text_embeddings.dropout = torch.nn.Identity()
+    assert model._text_spec(ids) is None
+    # ops refuse CPU tensors loudly (no CPU fallback of a kernel)
+    for call in (lambda: ops.tanh_fwd(torch.zeros(2, 8, dtype=torch.bfloat16)),
+                 lambda: ops.scatter_rows(4, 8, torch.float32, [(torch.zeros(1, 8), 0, 1)], torch.device("cpu")),
+                 lambda: ops.weighted_sum([torch.zeros(())], [1.0]),
+                 lambda: ops.sample_negatives(sim, sim, 6, torch.rand(2, 6))):
+        with pytest.raises(L.VlmError):
+            call()
