@@ -868,7 +868,12 @@ def main():
     timer.on = False
     exposed_comm_ms = reducer.exposed_wait_ms() / max(1, args.steps)
     loss_val = float(loss.detach())
-    if not math.isfinite(loss_val):
+    finite = math.isfinite(loss_val)
+    if world > 1:  # every rank takes the same decision (a rank that raised alone would leave the others in their next collective)
+        flag = torch.tensor([1.0 if finite else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        finite = bool(flag.item() > 0.5)
+    if not finite:
         # a step whose activations are NaN runs FASTER (less switching power, higher clocks: docs/experiments.md round 6): a rate
         # measured on such a run is not a measurement
         raise RuntimeError("bench: the last timed step's loss is %r -- the timed steps did not compute the workload" % loss_val)
