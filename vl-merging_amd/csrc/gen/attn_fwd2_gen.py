@@ -63,6 +63,7 @@ S_TMP = 61
 S_LO = 62        # s[62:63] = lower half-wave
 
 PRIO = os.environ.get("VLM_GEN_PRIO", "slot")
+KO = set(x for x in os.environ.get("VLM_GEN_KO", "").split(",") if x)  # timing-only knock-outs (wrong results): docs/experiments.md
 MF_BF = "v_mfma_f32_32x32x16_bf16"
 MF_F16 = "v_mfma_f32_32x32x16_f16"
 
@@ -143,11 +144,14 @@ def exp_cvt(u):
     out = []
     ones = "v%d" % (V_ADDR + 15)
 
-    def ex(i): return Op("v_exp_f32_e32 %s, %s" % (Sr(s, i), Sr(s, i)), "trans", [Sr(s, i)], [Sr(s, i)])
+    def ex(i):
+        if "exp" in KO:
+            return valu("v_mov_b32_e32 %s, %s" % (Sr(s, i), Sr(s, i)), [Sr(s, i)], [Sr(s, i)])
+        return Op("v_exp_f32_e32 %s, %s" % (Sr(s, i), Sr(s, i)), "trans", [Sr(s, i)], [Sr(s, i)])
     def cv(d): return valu("v_cvt_pk_bf16_f32 %s, %s, %s" % (Pr(s, d), Sr(s, 2 * d), Sr(s, 2 * d + 1)), [Sr(s, 2 * d), Sr(s, 2 * d + 1)], [Pr(s, d)])
     def dt(d): return valu("v_dot2c_f32_bf16_e32 %s, %s, %s" % (Lr(s, d & 1), Pr(s, d), ones), [Lr(s, d & 1), Pr(s, d), ones], [Lr(s, d & 1)], cost=8)
     # sixteen exponentials, then the conversions, then the sums: every input was written eight or more instructions earlier
-    out += [ex(i) for i in range(16)] + [cv(d) for d in range(8)] + [dt(d) for d in range(8)]
+    out += [ex(i) for i in range(16)] + [cv(d) for d in range(8)] + ([] if "dot" in KO else [dt(d) for d in range(8)])
     return out
 
 
@@ -320,12 +324,12 @@ def trip(x, half):
         # head of the O phase: chain(u) has issued, the fragment registers are free -> request unit u + 1's K fragments
         if u == 1:
             # block x + 1 has landed for every wave (its pieces were issued in the previous trip's phases 3-6)
-            lead = [Op("s_nop 0", "salu", needs=["dma%sB3" % "ba"[half]]), Op("s_barrier", "salu")] + k_reads(2, st[2])
+            lead = [Op("s_nop 0", "salu", needs=["dma%sB3" % "ba"[half]]), Op("s_nop 0" if "barrier" in KO else "s_barrier", "salu")] + k_reads(2, st[2])
         elif u == 2:
             lead = k_reads(3, st[3])
         else:
             # trip boundary: the next trip's first block has landed (pieces 0, 1 in the previous trip's phases 7-8, 2, 3 above)
-            lead = [Op("s_nop 0", "salu", needs=["dma%sA3" % tag]), Op("s_barrier", "salu"),
+            lead = [Op("s_nop 0", "salu", needs=["dma%sA3" % tag]), Op("s_nop 0" if "barrier" in KO else "s_barrier", "salu"),
                     salu("s_cmp_eq_u32 s%d, 0" % S_T, ["scc"]),
                     salu("s_cselect_b64 vcc, -1, 0", ["vcc"], ["scc"]),
                     valu("v_cndmask_b32_e32 v%d, v%d, v%d, vcc" % (V_KMC, V_ADDR + 7, V_ADDR + 12), ["vcc"], ["v%d" % V_KMC])] + k_reads(0, nx)
